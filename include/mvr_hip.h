@@ -1,0 +1,236 @@
+/*
+ * include/mvr_hip.h -- C-ABI of the MI355X-native ICP hot path (libmvr_hip.so).
+ *
+ * The reference (fanxiaochen/Multi-View-Registration, `mvr`) has no FFI or
+ * plugin interface for this path: the boundary is the set of PCL member
+ * functions that Registrator calls.  Each entry point
+ * below names the reference call site(s) it stands behind; the C++ shim in
+ * include/mvr/ (source-compatible PCL-style classes) is the only intended
+ * caller, and INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 (MVR_OK) or a negative
+ *    mvr_status; no exceptions cross this boundary.
+ *  - points are 16-byte records {x,y,z,w} (pcl::PointXYZ layout,
+ *    mvr/include/types.h:14) or packed 12-byte xyz; `stride_bytes` says which.
+ *    Uploads COPY: the caller keeps ownership and may mutate or alias its
+ *    clouds between calls, as the reference does (registrator.cpp:576, :920).
+ *  - poses are 4x4 column-major, column-vector convention: the memory layout
+ *    of Eigen::Matrix4f (what icp.getFinalTransformation() returns,
+ *    registrator.cpp:573).  mvr/include/types.h:20-50 (PclMatrixCaster) is the
+ *    transposing bridge to OSG's row-vector matrices.
+ *  - one mvr_ctx per host thread and GPU; a ctx is not thread-safe (the
+ *    reference drives the path from one worker thread, registrator.cpp:606).
+ *  - clouds live in numbered device "slots" of the ctx.
+ *  - the library fails loudly: with no usable GPU mvr_ctx_create returns
+ *    MVR_E_HIP; there is NO CPU fallback anywhere behind this header.
+ */
+#ifndef MVR_HIP_H
+#define MVR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvr_ctx mvr_ctx;
+
+typedef enum {
+  MVR_OK        =  0,
+  MVR_E_ARG     = -1,   /* bad argument / slot / size                       */
+  MVR_E_HIP     = -2,   /* HIP runtime error or no GPU (see mvr_last_error) */
+  MVR_E_NOCORR  = -3,   /* < 3 correspondences (PCL min_number_correspondences_ = 3;
+                           "Not enough correspondences found", App. A.1)   */
+  MVR_E_NOMEM   = -4,
+  MVR_E_SINGULAR= -5    /* singular system in a host solve (LUM)            */
+} mvr_status;
+
+#define MVR_MAX_SLOTS 64
+
+/* ---- parameters of one IterativeClosestPoint::align ----------------------
+ * Setters at mvr/src/registrator.cpp:551-560, :768-771, :901-904.           */
+typedef struct {
+  int    use_reciprocal;          /* setUseReciprocalCorrespondences(bool)  */
+  double max_corr_dist;           /* setMaxCorrespondenceDistance(double)   */
+  int    max_iterations;          /* setMaximumIterations(int)              */
+  double transformation_epsilon;  /* setTransformationEpsilon(double)       */
+  double euclidean_fitness_eps;   /* setEuclideanFitnessEpsilon(double)     */
+  int    fma_dist;                /* 0 (spec): d2 = (dx*dx+dy*dy)+dz*dz, each op
+                                     rounded (FLANN L2_Simple); 1: fma chain */
+} mvr_icp_params;
+
+/* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
+enum { MVR_CONV_NOT = 0, MVR_CONV_ITERATIONS = 1, MVR_CONV_TRANSFORM = 2,
+       MVR_CONV_ABS_MSE = 3, MVR_CONV_REL_MSE = 4, MVR_CONV_NO_CORRESPONDENCES = 5 };
+
+typedef struct {
+  int    iterations;   /* nr_iterations_                                    */
+  int    converged;    /* hasConverged()                                    */
+  int    state;        /* MVR_CONV_*                                        */
+  int    n_corr;       /* accepted correspondences, last iteration          */
+  double mse;          /* mean squared correspondence distance, last iter.  */
+  double evals;        /* point-pair distance evaluations performed (fwd + reciprocal) */
+  double fwd_queries;  /* source queries of the forward NN passes           */
+  double ms;           /* wall milliseconds spent inside the call           */
+} mvr_icp_stats;
+
+/* moments of one scan pair under its accepted correspondences (K5+K6):
+ * what TransformationEstimationSVD accumulates (App. A.3).                 */
+typedef struct {
+  double n;            /* M = number of accepted correspondences           */
+  double mean_src[3];  /* (1/M) sum p_i                                     */
+  double mean_tgt[3];  /* (1/M) sum q_i                                     */
+  double mse;          /* (1/M) sum d2_i                                    */
+  double sigma[9];     /* (1/M) sum (q_i-mean_tgt)(p_i-mean_src)^T, row-major */
+} mvr_pair_moments_t;
+
+/* raw second moments of one scan pair (K8): everything LUM::computeEdge needs
+ * for ANY pair of vertex poses (see mvr_lum_edge_from_moments).  Points are
+ * taken relative to `origin` to keep magnitudes small.                     */
+typedef struct {
+  double n;
+  double origin[3];
+  double sp[3], sq[3];        /* sum p, sum q                               */
+  double spp[6], sqq[6];      /* sum p p^T, sum q q^T : xx xy xz yy yz zz   */
+  double spq[9];              /* sum p q^T, row-major                       */
+} mvr_pair_moments2_t;
+
+/* ---- context -------------------------------------------------------------- */
+int  mvr_ctx_create(mvr_ctx **ctx, int device_id);
+/* as above, but all work is enqueued on `hip_stream` (a hipStream_t owned by
+ * the caller, e.g. torch.cuda.current_stream().cuda_stream) instead of a
+ * private stream; NULL = private stream. */
+int  mvr_ctx_create_on_stream(mvr_ctx **ctx, int device_id, void *hip_stream);
+int  mvr_ctx_destroy(mvr_ctx *ctx);
+int  mvr_ctx_sync(mvr_ctx *ctx);                 /* wait for the ctx stream   */
+const char *mvr_strerror(int status);
+const char *mvr_last_error(const mvr_ctx *ctx);  /* detail of the last failure */
+int  mvr_device_info(mvr_ctx *ctx, char *name, size_t name_cap, int *n_cu, int *clock_mhz);
+
+/* ---- clouds ----------------------------------------------------------------
+ * setInputSource/setInputTarget (registrator.cpp:566-567, 497-498, 645-646,
+ * 776-777, 913-914) and lum.addPointCloud (:636) become an upload into a slot. */
+int  mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, size_t stride_bytes);
+int  mvr_cloud_download(mvr_ctx *ctx, int slot, float *xyz, size_t cap_points, size_t stride_bytes, size_t *n);
+int  mvr_cloud_size(mvr_ctx *ctx, int slot, size_t *n);
+int  mvr_cloud_reserve(mvr_ctx *ctx, int slot, size_t capacity_points);
+int  mvr_cloud_copy(mvr_ctx *ctx, int dst_slot, int src_slot);
+/* `*target += transformed_source` (registrator.cpp:576, :833, :982). */
+int  mvr_cloud_append(mvr_ctx *ctx, int dst_slot, int src_slot);
+int  mvr_cloud_clear(mvr_ctx *ctx, int slot);
+/* PointCloud::getTransformedPoints (point_cloud.cpp:290-303): f32 points times
+ * the f64 pose (osg::Matrixd::preMult incl. the w divide), rounded to f32.
+ * dst_slot may equal src_slot. */
+int  mvr_cloud_transform(mvr_ctx *ctx, int dst_slot, int src_slot, const double T[16]);
+/* pcl transformPointCloud / ICP::transformCloud (inside align, App. A.1):
+ * x' = ((T00 x + T01 y) + T02 z) + T03 in f32, no contraction. */
+int  mvr_cloud_transform_f32(mvr_ctx *ctx, int dst_slot, int src_slot, const float T[16]);
+
+/* ---- the hot path ------------------------------------------------------------ */
+/* exact 1-NN of every point of q_slot in t_slot: tree_->nearestKSearch(p,1,..)
+ * (inside icp.align registrator.cpp:569,920,1012,1024 and :502,:649).
+ * idx/d2 are host arrays of n_q entries (either may be NULL).  Ties -> lowest
+ * index.  idx = UINT32_MAX and d2 = +inf when the target is empty. */
+int  mvr_nn(mvr_ctx *ctx, int q_slot, int t_slot, int fma_dist, uint32_t *idx, float *d2);
+
+/* CorrespondenceEstimation::determineReciprocalCorrespondences(corrs, max_d)
+ * (registrator.cpp:496-502, 644-649); reciprocal = 0 gives
+ * determineCorrespondences.  Outputs are host arrays of capacity `cap`
+ * (pcl::Correspondence fields index_query / index_match / distance(squared)),
+ * in ascending query order.  *m = number found (may exceed cap: truncated). */
+int  mvr_correspondences(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist,
+                         int reciprocal, int fma_dist,
+                         int32_t *query, int32_t *match, float *dist2, size_t cap, size_t *m);
+
+/* correspondences + TransformationEstimationSVD accumulation (K2,K3,K5,K6) of
+ * one scan pair; the correspondences stay on the device.  This is the
+ * shardable per-pair unit of the ring/global mode (registrator.cpp:482-502,
+ * 640-651).  q_begin/q_count restrict the SOURCE queries to a sub-range (for
+ * splitting one pair over ranks; sums are then partial: n, n*mean, n*mse and
+ * raw second moments add across sub-ranges) -- pass 0, SIZE_MAX for all. */
+int  mvr_pair_moments(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist,
+                      int reciprocal, int fma_dist, mvr_pair_moments_t *out);
+int  mvr_pair_moments2(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist,
+                       int reciprocal, int fma_dist, size_t q_begin, size_t q_count,
+                       const double origin[3], mvr_pair_moments2_t *out);
+/* device-output variant: writes 32 doubles {n, origin[3], sp, sq, spp, sqq,
+ * spq, 0} to `dev_out` (device pointer, e.g. a row of a torch tensor that is
+ * all-reduced over RCCL afterwards) without any host synchronisation. */
+int  mvr_pair_moments2_dev(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist,
+                           int reciprocal, int fma_dist, size_t q_begin, size_t q_count,
+                           const double origin[3], double *dev_out);
+
+/* host-side solves on the moments (3x3 SVD stays on the host) */
+/* TransformationEstimationSVD / Eigen::umeyama (App. A.3). */
+int  mvr_umeyama_from_moments(const mvr_pair_moments_t *mom, float T[16], double sv[3]);
+int  mvr_moments_from_moments2(const mvr_pair_moments2_t *m2, mvr_pair_moments_t *out);
+
+/* pcl::IterativeClosestPoint<PointXYZ,PointXYZ>::align(out)
+ * (registrator.cpp:569, :920, :1012, :1024).  out_slot receives
+ * final * input (may equal src_slot: the aliased align(*source_) of :920);
+ * out_slot < 0 skips it.  T_out = getFinalTransformation().  Returns
+ * MVR_E_NOCORR (and stats->state = NO_CORRESPONDENCES, converged = 0) when an
+ * iteration finds < 3 correspondences; T_out then holds the transformation
+ * accumulated so far, as PCL leaves it. */
+int  mvr_icp_align(mvr_ctx *ctx, int src_slot, int tgt_slot, int out_slot,
+                   const mvr_icp_params *params, float T_out[16], mvr_icp_stats *stats);
+
+/* Registration::getFitnessScore(max_range) (registrator.cpp:572,923,1015):
+ * mean squared distance of T*input to its unbounded 1-NN in the target.
+ * DBL_MAX when no point qualifies. */
+int  mvr_fitness(mvr_ctx *ctx, int input_slot, int tgt_slot, const float T[16],
+                 double max_range, int fma_dist, double *score);
+
+/* ---- LUM (pcl::registration::LUM, registrator.cpp:627-663) ------------------- */
+/* LUM::computeEdge for one edge from its raw moments and the two vertex poses
+ * (x,y,z,roll,pitch,yaw): MM (6x6 row-major), MZ, ss, n_valid. */
+int  mvr_lum_edge_from_moments(const mvr_pair_moments2_t *m2, const double pose_s[6],
+                               const double pose_t[6], double MM[36], double MZ[6],
+                               double *ss);
+/* LUM::compute on n vertices / ne edges given per-edge moments; poses n*6
+ * in/out, vertex 0 fixed.  Returns iterations done in *iters. */
+int  mvr_lum_compute(int n, int ne, const int *edge_src, const int *edge_tgt,
+                     const mvr_pair_moments2_t *edge_m2, int max_iterations,
+                     double convergence_threshold, double *poses, int *iters);
+/* pcl::getTransformation(x,y,z,roll,pitch,yaw) -> column-major 4x4. */
+void mvr_pose_to_mat4(const double pose[6], double T[16]);
+
+/* ---- turntable prior (PointCloud::initRotation point_cloud.cpp:400-413,
+ *      Registrator::getRotationMatrix registrator.cpp:331-342) --------------- */
+double mvr_turntable_angle(int view, int n_views);
+void   mvr_axis_rotation(const double pivot[3], const double axis[3], double angle, double T[16]);
+void   mvr_mat4d_mul(const double A[16], const double B[16], double C[16]);
+void   mvr_mat4f_mul(const float A[16], const float B[16], float C[16]);
+
+/* ---- instrumentation --------------------------------------------------------- */
+/* per-kernel-family device time measured with HIP events on the ctx stream.
+ * family: 0 = nn (brute-force NN, fwd + reciprocal), 1 = reductions (K5/K6/K8),
+ * 2 = transform/copy, 3 = glue (mark/compact/weights). */
+enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_COUNT = 4 };
+int  mvr_prof_enable(mvr_ctx *ctx, int on);
+int  mvr_prof_reset(mvr_ctx *ctx);
+/* launches, total ms, point-pair evals (nn family) / bytes (others) */
+int  mvr_prof_get(mvr_ctx *ctx, int family, uint64_t *launches, double *ms, double *work);
+
+/* ---- synthetic turntable scans (host only, no GPU needed) --------- */
+typedef struct {
+  int      n_views;        /* V: views at 2*pi/V                            */
+  uint64_t seed;           /* base seed; view v uses seed + v               */
+  double   noise_sigma;    /* along-normal noise, mm                        */
+  double   pivot[3];       /* true turntable pivot (point_cloud.cpp:102)    */
+  double   axis[3];        /* true turntable axis  (point_cloud.cpp:103)    */
+} mvr_synth_params;
+void mvr_synth_default(mvr_synth_params *p, int n_views, int config_id);
+/* fills xyzw (n*4 floats, w=1) and, if non-NULL, normals (n*4 floats, w=0) of
+ * the scan of `view`: object rotated by +view*2pi/V about (pivot, axis). */
+int  mvr_synth_view(const mvr_synth_params *p, int view, size_t n, float *xyzw, float *normals);
+/* the mis-calibrated prior handed to initRotation: pivot + (1.5,-1,2) mm and
+ * the axis tilted by 0.5 deg about x. */
+void mvr_synth_prior(const mvr_synth_params *p, double pivot[3], double axis[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVR_HIP_H */

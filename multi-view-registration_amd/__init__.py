@@ -1,0 +1,400 @@
+"""multi-view-registration_amd -- MI355X-native ICP hot path of
+fanxiaochen/Multi-View-Registration (`mvr`).
+
+This package is a thin ctypes view of the C-ABI in include/mvr_hip.h
+(libmvr_hip.so: hand-written HIP kernels for gfx950 + the host-side solves).
+The product host code is C++ (include/mvr/*.hpp, the PCL-style shim the
+reference's Registrator call sites compile against); Python is only used to
+drive tests and bench.py.  There is no CPU fallback: without the built
+extension the import fails, without a GPU Context() raises.
+
+Import with importlib (the directory name has hyphens):
+    mvr = importlib.import_module("multi-view-registration_amd")
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvr_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libmvr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+
+_lib = C.CDLL(LIB_PATH)
+
+MAX_SLOTS = 64
+OK, E_ARG, E_HIP, E_NOCORR, E_NOMEM, E_SINGULAR = 0, -1, -2, -3, -4, -5
+CONV_STATES = ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
+               "NO_CORRESPONDENCES")
+K_NN, K_REDUCE, K_XFORM, K_GLUE = 0, 1, 2, 3
+
+
+class MvrError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _lib.mvr_strerror(status).decode()
+        super().__init__("mvr status %d (%s)%s" % (status, msg, (": " + detail) if detail else ""))
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("use_reciprocal", C.c_int), ("max_corr_dist", C.c_double),
+                ("max_iterations", C.c_int), ("transformation_epsilon", C.c_double),
+                ("euclidean_fitness_eps", C.c_double), ("fma_dist", C.c_int)]
+
+
+class IcpStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("state", C.c_int),
+                ("n_corr", C.c_int), ("mse", C.c_double), ("evals", C.c_double),
+                ("fwd_queries", C.c_double), ("ms", C.c_double)]
+
+
+class PairMoments(C.Structure):
+    _fields_ = [("n", C.c_double), ("mean_src", C.c_double * 3), ("mean_tgt", C.c_double * 3),
+                ("mse", C.c_double), ("sigma", C.c_double * 9)]
+
+
+class PairMoments2(C.Structure):
+    _fields_ = [("n", C.c_double), ("origin", C.c_double * 3), ("sp", C.c_double * 3),
+                ("sq", C.c_double * 3), ("spp", C.c_double * 6), ("sqq", C.c_double * 6),
+                ("spq", C.c_double * 9)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("n_views", C.c_int), ("seed", C.c_uint64), ("noise_sigma", C.c_double),
+                ("pivot", C.c_double * 3), ("axis", C.c_double * 3)]
+
+
+_fp, _dp, _u32p, _i32p = (C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
+                          C.POINTER(C.c_int32))
+_vp, _sz = C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); also the list the symbol-export test checks
+SIGNATURES = {
+    "mvr_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "mvr_ctx_create_on_stream": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    "mvr_ctx_destroy": (C.c_int, [_vp]),
+    "mvr_ctx_sync": (C.c_int, [_vp]),
+    "mvr_strerror": (C.c_char_p, [C.c_int]),
+    "mvr_last_error": (C.c_char_p, [_vp]),
+    "mvr_device_info": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mvr_cloud_upload": (C.c_int, [_vp, C.c_int, _fp, _sz, _sz]),
+    "mvr_cloud_download": (C.c_int, [_vp, C.c_int, _fp, _sz, _sz, C.POINTER(_sz)]),
+    "mvr_cloud_size": (C.c_int, [_vp, C.c_int, C.POINTER(_sz)]),
+    "mvr_cloud_reserve": (C.c_int, [_vp, C.c_int, _sz]),
+    "mvr_cloud_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mvr_cloud_append": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mvr_cloud_clear": (C.c_int, [_vp, C.c_int]),
+    "mvr_cloud_transform": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "mvr_cloud_transform_f32": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
+    "mvr_nn": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _u32p, _fp]),
+    "mvr_correspondences": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                      _i32p, _i32p, _fp, _sz, C.POINTER(_sz)]),
+    "mvr_pair_moments": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                   C.POINTER(PairMoments)]),
+    "mvr_pair_moments2": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _sz, _sz,
+                                    _dp, C.POINTER(PairMoments2)]),
+    "mvr_pair_moments2_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _sz,
+                                        _sz, _dp, _vp]),
+    "mvr_umeyama_from_moments": (C.c_int, [C.POINTER(PairMoments), _fp, _dp]),
+    "mvr_moments_from_moments2": (C.c_int, [C.POINTER(PairMoments2), C.POINTER(PairMoments)]),
+    "mvr_icp_align": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), _fp,
+                                C.POINTER(IcpStats)]),
+    "mvr_fitness": (C.c_int, [_vp, C.c_int, C.c_int, _fp, C.c_double, C.c_int, _dp]),
+    "mvr_lum_edge_from_moments": (C.c_int, [C.POINTER(PairMoments2), _dp, _dp, _dp, _dp, _dp]),
+    "mvr_lum_compute": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(PairMoments2), C.c_int, C.c_double, _dp,
+                                  C.POINTER(C.c_int)]),
+    "mvr_pose_to_mat4": (None, [_dp, _dp]),
+    "mvr_turntable_angle": (C.c_double, [C.c_int, C.c_int]),
+    "mvr_axis_rotation": (None, [_dp, _dp, C.c_double, _dp]),
+    "mvr_mat4d_mul": (None, [_dp, _dp, _dp]),
+    "mvr_mat4f_mul": (None, [_fp, _fp, _fp]),
+    "mvr_prof_enable": (C.c_int, [_vp, C.c_int]),
+    "mvr_prof_reset": (C.c_int, [_vp]),
+    "mvr_prof_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), _dp, _dp]),
+    "mvr_synth_default": (None, [C.POINTER(SynthParams), C.c_int, C.c_int]),
+    "mvr_synth_view": (C.c_int, [C.POINTER(SynthParams), C.c_int, _sz, _fp, _fp]),
+    "mvr_synth_prior": (None, [C.POINTER(SynthParams), _dp, _dp]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(_lib, _name)
+    _f.restype, _f.argtypes = _res, _args
+
+
+def _chk(rc, ctx=None, allow=()):
+    if rc != OK and rc not in allow:
+        detail = _lib.mvr_last_error(ctx).decode() if ctx else ""
+        raise MvrError(rc, detail)
+    return rc
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def to_cm(T, dtype):
+    """(4,4) math layout T[r,c] -> 16 column-major values (Eigen::Matrix4f memory)."""
+    return np.ascontiguousarray(np.asarray(T, dtype=dtype).T).reshape(16)
+
+
+def from_cm(v):
+    return np.array(v).reshape(4, 4).T.copy()
+
+
+# --------------------------------------------------------------- host helpers
+
+def icp_params(reciprocal=True, max_dist=4.0, max_iter=10, teps=1e-6, feps=64.0, fma=False):
+    """Defaults = the reference's settings at mvr/src/registrator.cpp:551-560
+    (max_iterations is the caller's; with feps=64 every align is one iteration)."""
+    return IcpParams(int(reciprocal), float(max_dist), int(max_iter), float(teps), float(feps),
+                     int(fma))
+
+
+def synth_params(n_views=12, config_id=0) -> SynthParams:
+    sp = SynthParams()
+    _lib.mvr_synth_default(C.byref(sp), n_views, config_id)
+    return sp
+
+
+def synth_view(sp: SynthParams, view: int, n: int, normals=False):
+    pts = np.empty((n, 4), np.float32)
+    nrm = np.empty((n, 4), np.float32) if normals else None
+    _chk(_lib.mvr_synth_view(C.byref(sp), view, n, _p(pts, C.c_float),
+                             _p(nrm, C.c_float) if normals else None))
+    return (pts, nrm) if normals else pts
+
+
+def synth_prior(sp: SynthParams):
+    piv, ax = np.empty(3), np.empty(3)
+    _lib.mvr_synth_prior(C.byref(sp), _p(piv, C.c_double), _p(ax, C.c_double))
+    return piv, ax
+
+
+def turntable_angle(view, n_views=12) -> float:
+    return float(_lib.mvr_turntable_angle(view, n_views))
+
+
+def axis_rotation(pivot, axis, angle):
+    p, a = np.ascontiguousarray(pivot, np.float64), np.ascontiguousarray(axis, np.float64)
+    T = np.empty(16)
+    _lib.mvr_axis_rotation(_p(p, C.c_double), _p(a, C.c_double), float(angle), _p(T, C.c_double))
+    return from_cm(T)
+
+
+def mat4d_mul(A, B):
+    a, b, c = to_cm(A, np.float64), to_cm(B, np.float64), np.empty(16)
+    _lib.mvr_mat4d_mul(_p(a, C.c_double), _p(b, C.c_double), _p(c, C.c_double))
+    return from_cm(c)
+
+
+def mat4f_mul(A, B):
+    a, b, c = to_cm(A, np.float32), to_cm(B, np.float32), np.empty(16, np.float32)
+    _lib.mvr_mat4f_mul(_p(a, C.c_float), _p(b, C.c_float), _p(c, C.c_float))
+    return from_cm(c)
+
+
+def pose_to_mat4(pose):
+    p, T = np.ascontiguousarray(pose, np.float64), np.empty(16)
+    _lib.mvr_pose_to_mat4(_p(p, C.c_double), _p(T, C.c_double))
+    return from_cm(T)
+
+
+def moments_to_dict(m: PairMoments):
+    return dict(n=m.n, mean_src=np.array(m.mean_src), mean_tgt=np.array(m.mean_tgt), mse=m.mse,
+                sigma=np.array(m.sigma).reshape(3, 3))
+
+
+def umeyama_from_moments(m: PairMoments):
+    T, sv = np.empty(16, np.float32), np.empty(3)
+    rc = _lib.mvr_umeyama_from_moments(C.byref(m), _p(T, C.c_float), _p(sv, C.c_double))
+    if rc != OK:
+        return None, None
+    return from_cm(T), sv
+
+
+def moments_from_moments2(m2: PairMoments2) -> PairMoments:
+    out = PairMoments()
+    _chk(_lib.mvr_moments_from_moments2(C.byref(m2), C.byref(out)))
+    return out
+
+
+def moments2_from_row(row) -> PairMoments2:
+    """32-double device row {n, origin, sp, sq, spp, sqq, spq, 0} -> struct."""
+    m2 = PairMoments2()
+    C.memmove(C.byref(m2), np.ascontiguousarray(row, np.float64).ctypes.data, C.sizeof(m2))
+    return m2
+
+
+def lum_edge_from_moments(m2: PairMoments2, pose_s, pose_t):
+    ps, pt = np.ascontiguousarray(pose_s, np.float64), np.ascontiguousarray(pose_t, np.float64)
+    MM, MZ, ss = np.empty(36), np.empty(6), C.c_double()
+    rc = _lib.mvr_lum_edge_from_moments(C.byref(m2), _p(ps, C.c_double), _p(pt, C.c_double),
+                                        _p(MM, C.c_double), _p(MZ, C.c_double), C.byref(ss))
+    return rc, MM.reshape(6, 6), MZ, ss.value
+
+
+def lum_compute(n, edges, moments2, max_iterations=5, threshold=0.0, poses=None):
+    ne = len(edges)
+    es = (C.c_int * ne)(*[e[0] for e in edges])
+    et = (C.c_int * ne)(*[e[1] for e in edges])
+    arr = (PairMoments2 * ne)(*moments2)
+    P = np.zeros((n, 6)) if poses is None else np.array(poses, np.float64).reshape(n, 6)
+    P = np.ascontiguousarray(P)
+    its = C.c_int()
+    rc = _lib.mvr_lum_compute(n, ne, es, et, arr, int(max_iterations), float(threshold),
+                              _p(P, C.c_double), C.byref(its))
+    return rc, P, its.value
+
+
+# ------------------------------------------------------------------- context
+
+class Context:
+    """One GPU context (mvr_ctx): device clouds in numbered slots + the hot path."""
+
+    def __init__(self, device=0, stream=None):
+        h = _vp()
+        rc = _lib.mvr_ctx_create_on_stream(C.byref(h), int(device), _vp(stream) if stream else None)
+        if rc != OK:
+            raise MvrError(rc, "mvr_ctx_create: no usable GPU or HIP failure; there is no CPU fallback")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            _lib.mvr_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- clouds
+    def upload(self, slot, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        if pts.ndim != 2 or pts.shape[1] not in (3, 4):
+            raise ValueError("points must be (n,4) or (n,3) float32")
+        _chk(_lib.mvr_cloud_upload(self._h, slot, _p(pts, C.c_float), len(pts), 4 * pts.shape[1]), self._h)
+
+    def size(self, slot) -> int:
+        n = _sz()
+        _chk(_lib.mvr_cloud_size(self._h, slot, C.byref(n)), self._h)
+        return n.value
+
+    def download(self, slot, packed=False):
+        n = self.size(slot)
+        out = np.empty((n, 3 if packed else 4), np.float32)
+        got = _sz()
+        _chk(_lib.mvr_cloud_download(self._h, slot, _p(out, C.c_float), n, 12 if packed else 16,
+                                     C.byref(got)), self._h)
+        return out
+
+    def reserve(self, slot, cap):
+        _chk(_lib.mvr_cloud_reserve(self._h, slot, cap), self._h)
+
+    def copy(self, dst, src):
+        _chk(_lib.mvr_cloud_copy(self._h, dst, src), self._h)
+
+    def append(self, dst, src):
+        _chk(_lib.mvr_cloud_append(self._h, dst, src), self._h)
+
+    def clear(self, slot):
+        _chk(_lib.mvr_cloud_clear(self._h, slot), self._h)
+
+    def transform(self, dst, src, T):
+        """getTransformedPoints semantics (f64 pose)."""
+        t = to_cm(T, np.float64)
+        _chk(_lib.mvr_cloud_transform(self._h, dst, src, _p(t, C.c_double)), self._h)
+
+    def transform_f32(self, dst, src, T):
+        """pcl::transformPointCloud semantics (f32 pose)."""
+        t = to_cm(T, np.float32)
+        _chk(_lib.mvr_cloud_transform_f32(self._h, dst, src, _p(t, C.c_float)), self._h)
+
+    # -- hot path
+    def nn(self, q_slot, t_slot, fma=False):
+        n = self.size(q_slot)
+        idx, d2 = np.empty(n, np.uint32), np.empty(n, np.float32)
+        _chk(_lib.mvr_nn(self._h, q_slot, t_slot, int(fma), _p(idx, C.c_uint32), _p(d2, C.c_float)), self._h)
+        return idx, d2
+
+    def correspondences(self, s, t, max_dist, reciprocal=True, fma=False):
+        n = self.size(s)
+        q, m, d = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float32)
+        cnt = _sz()
+        _chk(_lib.mvr_correspondences(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
+                                      _p(q, C.c_int32), _p(m, C.c_int32), _p(d, C.c_float), n,
+                                      C.byref(cnt)), self._h)
+        k = cnt.value
+        return q[:k].copy(), m[:k].copy(), d[:k].copy()
+
+    def pair_moments(self, s, t, max_dist, reciprocal=True, fma=False) -> PairMoments:
+        out = PairMoments()
+        _chk(_lib.mvr_pair_moments(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
+                                   C.byref(out)), self._h)
+        return out
+
+    def pair_moments2(self, s, t, max_dist, origin, reciprocal=True, fma=False, q_begin=0,
+                      q_count=None) -> PairMoments2:
+        out = PairMoments2()
+        o = np.ascontiguousarray(origin, np.float64)
+        qc = (1 << 62) if q_count is None else int(q_count)
+        _chk(_lib.mvr_pair_moments2(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
+                                    int(q_begin), qc, _p(o, C.c_double), C.byref(out)), self._h)
+        return out
+
+    def pair_moments2_dev(self, s, t, max_dist, origin, dev_ptr, reciprocal=True, fma=False,
+                          q_begin=0, q_count=None):
+        o = np.ascontiguousarray(origin, np.float64)
+        qc = (1 << 62) if q_count is None else int(q_count)
+        _chk(_lib.mvr_pair_moments2_dev(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
+                                        int(q_begin), qc, _p(o, C.c_double), _vp(dev_ptr)), self._h)
+
+    def icp_align(self, src, tgt, out, params: IcpParams):
+        """Returns (T (4,4) float32, stats dict, rc); rc is OK or E_NOCORR."""
+        T, st = np.empty(16, np.float32), IcpStats()
+        rc = _chk(_lib.mvr_icp_align(self._h, src, tgt, out, C.byref(params), _p(T, C.c_float),
+                                     C.byref(st)), self._h, allow=(E_NOCORR,))
+        stats = dict(iterations=st.iterations, converged=bool(st.converged),
+                     state=CONV_STATES[st.state], n_corr=st.n_corr, mse=st.mse, evals=st.evals,
+                     fwd_queries=st.fwd_queries, ms=st.ms)
+        return from_cm(T), stats, rc
+
+    def fitness(self, inp, tgt, T, max_range=np.finfo(np.float64).max, fma=False) -> float:
+        t, s = to_cm(T, np.float32), C.c_double()
+        _chk(_lib.mvr_fitness(self._h, inp, tgt, _p(t, C.c_float), float(max_range), int(fma),
+                              C.byref(s)), self._h)
+        return s.value
+
+    # -- misc
+    def sync(self):
+        _chk(_lib.mvr_ctx_sync(self._h), self._h)
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        ncu, mhz = C.c_int(), C.c_int()
+        _chk(_lib.mvr_device_info(self._h, name, 64, C.byref(ncu), C.byref(mhz)), self._h)
+        return name.value.decode(), ncu.value, mhz.value
+
+    def prof_enable(self, on=True):
+        _chk(_lib.mvr_prof_enable(self._h, int(on)), self._h)
+
+    def prof_reset(self):
+        _chk(_lib.mvr_prof_reset(self._h), self._h)
+
+    def prof_get(self, family):
+        n, ms, w = C.c_uint64(), C.c_double(), C.c_double()
+        _chk(_lib.mvr_prof_get(self._h, family, C.byref(n), C.byref(ms), C.byref(w)), self._h)
+        return n.value, ms.value, w.value

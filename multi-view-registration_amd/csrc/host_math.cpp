@@ -1,0 +1,422 @@
+// csrc/host_math.cpp -- the O(1) host-side solves of the hot path.
+//
+// north_star keeps "the 3x3 SVD on host": the GPU reduces a scan pair to a
+// handful of f64 moments, the host turns them into poses.
+//   * Umeyama / Kabsch      : TransformationEstimationSVD inside icp.align
+//                             (mvr/src/registrator.cpp:569)
+//   * LUM edge + graph solve: pcl::registration::LUM::computeEdge / compute
+//                             (mvr/src/registrator.cpp:627-663; App. A.6), here
+//                             evaluated from raw second moments so that all 16
+//                             LUM iterations of one outer pass need no further
+//                             pass over the points.
+//   * turntable prior       : PointCloud::initRotation (point_cloud.cpp:400-413),
+//                             Registrator::getRotationMatrix (registrator.cpp:331-342)
+// Pure host C++, double precision; results are cast to float where the
+// reference's types are float (Eigen::Matrix4f).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mvr_internal.h"
+
+namespace mvr {
+
+namespace {
+
+struct M3 {
+  double a[3][3];
+  double &operator()(int r, int c) { return a[r][c]; }
+  double operator()(int r, int c) const { return a[r][c]; }
+};
+
+M3 zero3() { M3 m; std::memset(&m, 0, sizeof m); return m; }
+M3 mul(const M3 &A, const M3 &B)
+{
+  M3 C = zero3();
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) C(r, c) += A(r, k) * B(k, c);
+  return C;
+}
+M3 transpose(const M3 &A) { M3 T; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T(r, c) = A(c, r); return T; }
+M3 add(const M3 &A, const M3 &B, double sb = 1.0) { M3 C; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C(r, c) = A(r, c) + sb * B(r, c); return C; }
+M3 outer(const double u[3], const double v[3]) { M3 C; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C(r, c) = u[r] * v[c]; return C; }
+void mulv(const M3 &A, const double v[3], double out[3]) { for (int r = 0; r < 3; ++r) out[r] = A(r, 0) * v[0] + A(r, 1) * v[1] + A(r, 2) * v[2]; }
+M3 sym6(const double s[6]) { M3 m; m(0, 0) = s[0]; m(0, 1) = m(1, 0) = s[1]; m(0, 2) = m(2, 0) = s[2]; m(1, 1) = s[3]; m(1, 2) = m(2, 1) = s[4]; m(2, 2) = s[5]; return m; }
+double det(const M3 &m)
+{
+  return m(0, 0) * (m(1, 1) * m(2, 2) - m(1, 2) * m(2, 1)) - m(0, 1) * (m(1, 0) * m(2, 2) - m(1, 2) * m(2, 0)) +
+         m(0, 2) * (m(1, 0) * m(2, 1) - m(1, 1) * m(2, 0));
+}
+
+}  // namespace
+
+// Hestenes one-sided Jacobi; singular values descending (Eigen::JacobiSVD order).
+void svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+  double col[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};   // col[j] = j-th column of A*V ; v[j] = j-th column of V
+  for (int j = 0; j < 3; ++j) for (int r = 0; r < 3; ++r) col[j][r] = A[3 * r + j];
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    bool any = false;
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double app = 0, aqq = 0, apq = 0;
+        for (int r = 0; r < 3; ++r) { app += col[p][r] * col[p][r]; aqq += col[q][r] * col[q][r]; apq += col[p][r] * col[q][r]; }
+        if (apq == 0.0 || std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq)) continue;
+        any = true;
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = std::copysign(1.0, tau) / (std::fabs(tau) + std::hypot(1.0, tau));
+        const double cs = 1.0 / std::hypot(1.0, t), sn = cs * t;
+        for (int r = 0; r < 3; ++r) {
+          const double x = col[p][r], y = col[q][r];
+          col[p][r] = cs * x - sn * y; col[q][r] = sn * x + cs * y;
+          const double vx = v[p][r], vy = v[q][r];
+          v[p][r] = cs * vx - sn * vy; v[q][r] = sn * vx + cs * vy;
+        }
+      }
+    if (!any) break;
+  }
+  double nrm[3]; int ord[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) nrm[j] = std::sqrt(col[j][0] * col[j][0] + col[j][1] * col[j][1] + col[j][2] * col[j][2]);
+  std::sort(ord, ord + 3, [&](int x, int y) { return nrm[x] > nrm[y]; });
+  double u[3][3];
+  for (int j = 0; j < 3; ++j) {
+    const int o = ord[j];
+    S[j] = nrm[o];
+    for (int r = 0; r < 3; ++r) { V[3 * r + j] = v[o][r]; u[j][r] = nrm[o] > 0 ? col[o][r] / nrm[o] : 0.0; }
+  }
+  if (S[0] <= DBL_MIN) { u[0][0] = 1; u[0][1] = 0; u[0][2] = 0; u[1][0] = 0; u[1][1] = 1; u[1][2] = 0; S[1] = S[2] = 0; }
+  if (S[1] <= S[0] * 1e-15) {   // rank <= 1: any unit vector orthogonal to u0
+    int k = 0;
+    for (int r = 1; r < 3; ++r) if (std::fabs(u[0][r]) < std::fabs(u[0][k])) k = r;
+    double w[3] = {-u[0][k] * u[0][0], -u[0][k] * u[0][1], -u[0][k] * u[0][2]};
+    w[k] += 1.0;
+    const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int r = 0; r < 3; ++r) u[1][r] = w[r] / n;
+  }
+  if (S[2] <= S[0] * 1e-15) {   // rank <= 2: u2 = u0 x u1
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+  }
+  for (int j = 0; j < 3; ++j) for (int r = 0; r < 3; ++r) U[3 * r + j] = u[j][r];
+}
+
+// Eigen::umeyama(src, dst, false), Eigen >= 3.3 sign rule.
+void umeyama_from_moments(const double mean_src[3], const double mean_tgt[3], const double sigma[9], float T[16],
+                          double sv[3])
+{
+  double U[9], S[3], V[9];
+  svd3(sigma, U, S, V);
+  M3 u, v;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { u(r, c) = U[3 * r + c]; v(r, c) = V[3 * r + c]; }
+  const double flip = (det(u) * det(v) < 0.0) ? -1.0 : 1.0;
+  for (int r = 0; r < 3; ++r) u(r, 2) *= flip;
+  const M3 R = mul(u, transpose(v));
+  double Rp[3];
+  mulv(R, mean_src, Rp);
+  std::memset(T, 0, 16 * sizeof(float));
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[r + 4 * c] = (float)R(r, c);
+    T[12 + r] = (float)(mean_tgt[r] - Rp[r]);
+  }
+  T[15] = 1.0f;
+  if (sv) { sv[0] = S[0]; sv[1] = S[1]; sv[2] = S[2]; }
+}
+
+int invert6(const double A[36], double Ainv[36])
+{
+  double W[6][12];
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { W[r][c] = A[6 * r + c]; W[r][6 + c] = (r == c) ? 1.0 : 0.0; }
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < 6; ++r) if (std::fabs(W[r][k]) > std::fabs(W[piv][k])) piv = r;
+    if (W[piv][k] == 0.0) return MVR_E_SINGULAR;
+    if (piv != k) for (int c = 0; c < 12; ++c) std::swap(W[k][c], W[piv][c]);
+    const double inv = 1.0 / W[k][k];
+    for (int c = 0; c < 12; ++c) W[k][c] *= inv;
+    for (int r = 0; r < 6; ++r) {
+      if (r == k || W[r][k] == 0.0) continue;
+      const double f = W[r][k];
+      for (int c = 0; c < 12; ++c) W[r][c] -= f * W[k][c];
+    }
+  }
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Ainv[6 * r + c] = W[r][6 + c];
+  return MVR_OK;
+}
+
+int solve_dense(int n, double *A, double *b)
+{
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < n; ++r) if (std::fabs(A[(size_t)r * n + k]) > std::fabs(A[(size_t)piv * n + k])) piv = r;
+    if (A[(size_t)piv * n + k] == 0.0) return MVR_E_SINGULAR;
+    if (piv != k) { for (int c = 0; c < n; ++c) std::swap(A[(size_t)k * n + c], A[(size_t)piv * n + c]); std::swap(b[k], b[piv]); }
+    for (int r = k + 1; r < n; ++r) {
+      const double f = A[(size_t)r * n + k] / A[(size_t)k * n + k];
+      if (f == 0.0) continue;
+      for (int c = k; c < n; ++c) A[(size_t)r * n + c] -= f * A[(size_t)k * n + c];
+      b[r] -= f * b[k];
+    }
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    double s = b[k];
+    for (int c = k + 1; c < n; ++c) s -= A[(size_t)k * n + c] * b[c];
+    b[k] = s / A[(size_t)k * n + k];
+  }
+  return MVR_OK;
+}
+
+}  // namespace mvr
+
+using namespace mvr;
+
+extern "C" {
+
+#define API __attribute__((visibility("default")))
+
+API int mvr_umeyama_from_moments(const mvr_pair_moments_t *mom, float T[16], double sv[3])
+{
+  if (!mom || !T) return MVR_E_ARG;
+  if (mom->n < 3.0) return MVR_E_NOCORR;
+  umeyama_from_moments(mom->mean_src, mom->mean_tgt, mom->sigma, T, sv);
+  return MVR_OK;
+}
+
+API int mvr_moments_from_moments2(const mvr_pair_moments2_t *m2, mvr_pair_moments_t *out)
+{
+  if (!m2 || !out) return MVR_E_ARG;
+  std::memset(out, 0, sizeof *out);
+  out->n = m2->n;
+  if (m2->n <= 0) return MVR_OK;
+  const double inv = 1.0 / m2->n;
+  double mp[3], mq[3];
+  for (int k = 0; k < 3; ++k) { mp[k] = m2->sp[k] * inv; mq[k] = m2->sq[k] * inv; out->mean_src[k] = mp[k] + m2->origin[k]; out->mean_tgt[k] = mq[k] + m2->origin[k]; }
+  // sum |p-q|^2 = tr(spp) - 2 tr(spq) + tr(sqq)
+  out->mse = ((m2->spp[0] + m2->spp[3] + m2->spp[5]) - 2.0 * (m2->spq[0] + m2->spq[4] + m2->spq[8]) +
+              (m2->sqq[0] + m2->sqq[3] + m2->sqq[5])) * inv;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out->sigma[3 * r + c] = m2->spq[3 * c + r] * inv - mq[r] * mp[c];
+  return MVR_OK;
+}
+
+// pcl::getTransformation(x, y, z, roll, pitch, yaw) = Translation * Rz(yaw) Ry(pitch) Rx(roll)
+API void mvr_pose_to_mat4(const double pose[6], double T[16])
+{
+  const double cr = std::cos(pose[3]), sr = std::sin(pose[3]);
+  const double cp = std::cos(pose[4]), sp = std::sin(pose[4]);
+  const double cy = std::cos(pose[5]), sy = std::sin(pose[5]);
+  std::memset(T, 0, 16 * sizeof(double));
+  T[0] = cy * cp; T[4] = cy * sp * sr - sy * cr; T[8]  = sy * sr + cy * sp * cr; T[12] = pose[0];
+  T[1] = sy * cp; T[5] = cy * cr + sy * sp * sr; T[9]  = sy * sp * cr - cy * sr; T[13] = pose[1];
+  T[2] = -sp;     T[6] = cp * sr;                T[10] = cp * cr;                T[14] = pose[2];
+  T[15] = 1.0;
+}
+
+// LUM::computeEdge from raw moments.  With p' = p - o,
+// q' = q - o the compounded points are a' = Rs p' + cs, b' = Rt q' + ct
+// (cs = Rs o + ts - o), so every sum over aver = (a+b)/2 and diff = a-b is an
+// algebraic function of {n, sum p', sum q', sum p'p'^T, sum q'q'^T, sum p'q'^T}.
+// Work in the shifted frame (small magnitudes), shift MM/MZ back at the end.
+API int mvr_lum_edge_from_moments(const mvr_pair_moments2_t *m2, const double pose_s[6], const double pose_t[6],
+                                  double MM[36], double MZ[6], double *ss)
+{
+  if (!m2 || !pose_s || !pose_t || !MM || !MZ || !ss) return MVR_E_ARG;
+  std::memset(MM, 0, 36 * sizeof(double)); std::memset(MZ, 0, 6 * sizeof(double)); *ss = 0.0;
+  const double n = m2->n;
+  if (n < 3.0) return MVR_E_NOCORR;
+  double Ts[16], Tt[16];
+  mvr_pose_to_mat4(pose_s, Ts); mvr_pose_to_mat4(pose_t, Tt);
+  M3 Rs, Rt;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Rs(r, c) = Ts[r + 4 * c]; Rt(r, c) = Tt[r + 4 * c]; }
+  const double *o = m2->origin;
+  double cs[3], ct[3], t3[3];
+  mulv(Rs, o, t3); for (int k = 0; k < 3; ++k) cs[k] = t3[k] + Ts[12 + k] - o[k];
+  mulv(Rt, o, t3); for (int k = 0; k < 3; ++k) ct[k] = t3[k] + Tt[12 + k] - o[k];
+  double Rsp[3], Rtq[3];
+  mulv(Rs, m2->sp, Rsp); mulv(Rt, m2->sq, Rtq);
+  double sa[3], sb[3];      // sum a', sum b'
+  for (int k = 0; k < 3; ++k) { sa[k] = Rsp[k] + n * cs[k]; sb[k] = Rtq[k] + n * ct[k]; }
+  M3 spq; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) spq(r, c) = m2->spq[3 * r + c];
+  // S_aa = Rs spp Rs^T + (Rs sp) cs^T + cs (Rs sp)^T + n cs cs^T
+  M3 Saa = add(add(mul(mul(Rs, sym6(m2->spp)), transpose(Rs)), outer(Rsp, cs)), add(outer(cs, Rsp), outer(cs, cs), n));
+  M3 Sbb = add(add(mul(mul(Rt, sym6(m2->sqq)), transpose(Rt)), outer(Rtq, ct)), add(outer(ct, Rtq), outer(ct, ct), n));
+  // S_ab = Rs spq Rt^T + (Rs sp) ct^T + cs (Rt sq)^T + n cs ct^T
+  M3 Sab = add(add(mul(mul(Rs, spq), transpose(Rt)), outer(Rsp, ct)), add(outer(cs, Rtq), outer(cs, ct), n));
+  M3 Sba = transpose(Sab);
+  // shifted-frame sums
+  double sav[3], sdf[3];
+  for (int k = 0; k < 3; ++k) { sav[k] = 0.5 * (sa[k] + sb[k]); sdf[k] = sa[k] - sb[k]; }
+  M3 Savav, Savdf;   // sum av' av'^T ; sum av' diff^T
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+    Savav(r, c) = 0.25 * (Saa(r, c) + Sab(r, c) + Sba(r, c) + Sbb(r, c));
+    Savdf(r, c) = 0.5 * (Saa(r, c) - Sab(r, c) + Sba(r, c) - Sbb(r, c));
+  }
+  const double tr_dfdf = (Saa(0, 0) + Saa(1, 1) + Saa(2, 2)) - 2.0 * (Sab(0, 0) + Sab(1, 1) + Sab(2, 2)) +
+                         (Sbb(0, 0) + Sbb(1, 1) + Sbb(2, 2));
+  // absolute-frame sums: av = av' + o
+  double Sx[3]; M3 Sxx, Sxd;
+  for (int k = 0; k < 3; ++k) Sx[k] = sav[k] + n * o[k];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+    Sxx(r, c) = Savav(r, c) + o[r] * sav[c] + sav[r] * o[c] + n * o[r] * o[c];
+    Sxd(r, c) = Savdf(r, c) + o[r] * sdf[c];
+  }
+#define M(r, c) MM[6 * (r) + (c)]
+  M(0, 4) = -Sx[1]; M(0, 5) = Sx[2]; M(1, 3) = -Sx[2]; M(1, 4) = Sx[0]; M(2, 3) = Sx[1]; M(2, 5) = -Sx[0];
+  M(3, 4) = -Sxx(0, 2); M(3, 5) = -Sxx(0, 1); M(4, 5) = -Sxx(1, 2);
+  M(3, 3) = Sxx(1, 1) + Sxx(2, 2); M(4, 4) = Sxx(0, 0) + Sxx(1, 1); M(5, 5) = Sxx(0, 0) + Sxx(2, 2);
+  M(0, 0) = M(1, 1) = M(2, 2) = n;
+  for (int r = 0; r < 6; ++r) for (int c = r + 1; c < 6; ++c) M(c, r) = M(r, c);
+#undef M
+  MZ[0] = sdf[0]; MZ[1] = sdf[1]; MZ[2] = sdf[2];
+  MZ[3] = Sxd(1, 2) - Sxd(2, 1);   // sum (y dz - z dy)
+  MZ[4] = Sxd(0, 1) - Sxd(1, 0);   // sum (x dy - y dx)
+  MZ[5] = Sxd(2, 0) - Sxd(0, 2);   // sum (z dx - x dz)
+  double Minv[36], D[6] = {0, 0, 0, 0, 0, 0};
+  if (invert6(MM, Minv) != MVR_OK) { *ss = NAN; return MVR_OK; }
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) D[r] += Minv[6 * r + c] * MZ[c];
+  // residual e = diff - Dt - C av, C = [[0,-D4,D5],[D4,0,-D3],[-D5,D3,0]]; in
+  // the shifted frame e = diff - (Dt + C o) - C av'
+  M3 Cm = zero3();
+  Cm(0, 1) = -D[4]; Cm(0, 2) = D[5]; Cm(1, 0) = D[4]; Cm(1, 2) = -D[3]; Cm(2, 0) = -D[5]; Cm(2, 1) = D[3];
+  double Co[3], Dt[3];
+  mulv(Cm, o, Co);
+  for (int k = 0; k < 3; ++k) Dt[k] = D[k] + Co[k];
+  const M3 CtC = mul(transpose(Cm), Cm);
+  double tr_ctc_savav = 0, tr_c_savdf = 0;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { tr_ctc_savav += CtC(r, c) * Savav(c, r); tr_c_savdf += Cm(r, c) * Savdf(c, r); }
+  double Csav[3];
+  mulv(Cm, sav, Csav);
+  const double dt2 = Dt[0] * Dt[0] + Dt[1] * Dt[1] + Dt[2] * Dt[2];
+  const double dt_sdf = Dt[0] * sdf[0] + Dt[1] * sdf[1] + Dt[2] * sdf[2];
+  const double dt_csav = Dt[0] * Csav[0] + Dt[1] * Csav[1] + Dt[2] * Csav[2];
+  *ss = tr_dfdf + n * dt2 + tr_ctc_savav - 2.0 * dt_sdf - 2.0 * tr_c_savdf + 2.0 * dt_csav;
+  return MVR_OK;
+}
+
+static void lum_incidence(const double pose[6], double out[36])
+{
+  std::memset(out, 0, 36 * sizeof(double));
+  for (int k = 0; k < 6; ++k) out[7 * k] = 1.0;
+  const double cx = std::cos(pose[3]), sx = std::sin(pose[3]), cy = std::cos(pose[4]), sy = std::sin(pose[4]);
+  out[4] = pose[1] * sx - pose[2] * cx;
+  out[5] = pose[1] * cx * sy + pose[2] * sx * sy;
+  out[6 + 3] = pose[2];
+  out[6 + 4] = -pose[0] * sx;
+  out[6 + 5] = -pose[0] * cx * sy + pose[2] * cy;
+  out[12 + 3] = -pose[1];
+  out[12 + 4] = pose[0] * cx;
+  out[12 + 5] = -pose[0] * sx * sy - pose[1] * cy;
+  out[18 + 5] = sy;
+  out[24 + 4] = sx;
+  out[24 + 5] = cx * cy;
+  out[30 + 4] = cx;
+  out[30 + 5] = -sx * cy;
+}
+
+// LUM::compute (App. A.6) on per-edge moments.
+API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_pair_moments2_t *m2,
+                        int max_iterations, double threshold, double *poses, int *iters)
+{
+  if (iters) *iters = 0;
+  if (n < 2 || ne < 0 || !es || !et || !m2 || !poses) return MVR_E_ARG;
+  for (int e = 0; e < ne; ++e) if (es[e] < 0 || es[e] >= n || et[e] < 0 || et[e] >= n) return MVR_E_ARG;
+  const int dim = 6 * (n - 1);
+  std::vector<double> G((size_t)dim * dim), B(dim), cinv((size_t)ne * 36), cinvd((size_t)ne * 6);
+  int it = 0;
+  for (; it < max_iterations; ++it) {
+    for (int e = 0; e < ne; ++e) {
+      double MM[36], MZ[6], ss;
+      const int rc = mvr_lum_edge_from_moments(&m2[e], poses + 6 * es[e], poses + 6 * et[e], MM, MZ, &ss);
+      if (rc != MVR_OK || ss < 0.0000000000001 || !std::isfinite(ss)) {
+        std::fill(cinv.begin() + 36 * e, cinv.begin() + 36 * (e + 1), 0.0);
+        std::fill(cinvd.begin() + 6 * e, cinvd.begin() + 6 * (e + 1), 0.0);
+      } else {
+        for (int k = 0; k < 36; ++k) cinv[36 * e + k] = MM[k] * (1.0 / ss);
+        for (int k = 0; k < 6; ++k) cinvd[6 * e + k] = MZ[k] * (1.0 / ss);
+      }
+    }
+    std::fill(G.begin(), G.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
+    for (int vi = 1; vi < n; ++vi)
+      for (int vj = 0; vj < n; ++vj) {
+        int e = -1; bool fwd = false;
+        for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vi && et[k] == vj) { e = k; fwd = true; }
+        for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vj && et[k] == vi) e = k;
+        if (e < 0) continue;
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < 6; ++c) {
+            if (vj > 0) G[(size_t)(6 * (vi - 1) + r) * dim + 6 * (vj - 1) + c] = -cinv[36 * e + 6 * r + c];
+            G[(size_t)(6 * (vi - 1) + r) * dim + 6 * (vi - 1) + c] += cinv[36 * e + 6 * r + c];
+          }
+        for (int r = 0; r < 6; ++r) B[6 * (vi - 1) + r] += (fwd ? 1.0 : -1.0) * cinvd[6 * e + r];
+      }
+    if (solve_dense(dim, G.data(), B.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
+    double sum = 0.0;
+    for (int vi = 1; vi < n; ++vi) {
+      double inc[36], incinv[36], dp[6], nrm = 0.0;
+      lum_incidence(poses + 6 * vi, inc);
+      if (invert6(inc, incinv) != MVR_OK) continue;
+      for (int r = 0; r < 6; ++r) {
+        double s = 0.0;
+        for (int c = 0; c < 6; ++c) s += incinv[6 * r + c] * B[6 * (vi - 1) + c];
+        dp[r] = -s; nrm += s * s;
+      }
+      sum += std::sqrt(nrm);
+      for (int r = 0; r < 6; ++r) poses[6 * vi + r] += dp[r];
+    }
+    if (sum <= threshold * (double)(n - 1)) { ++it; break; }
+  }
+  if (iters) *iters = it;
+  return MVR_OK;
+}
+
+API double mvr_turntable_angle(int view, int n_views)
+{
+  // point_cloud.cpp:409: ((view<7)?(-view):(12-view))*M_PI/6, generalised to V views
+  const int k = (view <= n_views / 2) ? -view : (n_views - view);
+  return (double)k * (2.0 * M_PI / (double)n_views);
+}
+
+API void mvr_axis_rotation(const double pivot[3], const double axis[3], double angle, double T[16])
+{
+  const double n = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+  const double x = axis[0] / n, y = axis[1] / n, z = axis[2] / n, c = std::cos(angle), s = std::sin(angle), k = 1.0 - c;
+  const double R[3][3] = {{c + x * x * k, x * y * k - z * s, x * z * k + y * s},
+                          {y * x * k + z * s, c + y * y * k, y * z * k - x * s},
+                          {z * x * k - y * s, z * y * k + x * s, c + z * z * k}};
+  std::memset(T, 0, 16 * sizeof(double));
+  for (int r = 0; r < 3; ++r) {
+    for (int cc = 0; cc < 3; ++cc) T[r + 4 * cc] = R[r][cc];
+    T[12 + r] = pivot[r] - (R[r][0] * pivot[0] + R[r][1] * pivot[1] + R[r][2] * pivot[2]);
+  }
+  T[15] = 1.0;
+}
+
+API void mvr_mat4d_mul(const double A[16], const double B[16], double C[16])
+{
+  double R[16];
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) {
+      double s = A[i] * B[4 * j];
+      s = s + A[i + 4] * B[4 * j + 1];
+      s = s + A[i + 8] * B[4 * j + 2];
+      s = s + A[i + 12] * B[4 * j + 3];
+      R[i + 4 * j] = s;
+    }
+  std::memcpy(C, R, sizeof R);
+}
+
+API void mvr_mat4f_mul(const float A[16], const float B[16], float C[16])
+{
+  float R[16];
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) {
+      float s = A[i] * B[4 * j];
+      s = s + A[i + 4] * B[4 * j + 1];
+      s = s + A[i + 8] * B[4 * j + 2];
+      s = s + A[i + 12] * B[4 * j + 3];
+      R[i + 4 * j] = s;
+    }
+  std::memcpy(C, R, sizeof R);
+}
+
+}  // extern "C"

@@ -1,0 +1,591 @@
+// csrc/mvr_ctx.hip -- C-ABI entry points of libmvr_hip.so (include/mvr_hip.h):
+// context, device clouds, and the host side of the ICP iteration
+// (pcl::IterativeClosestPoint::align) driving the HIP
+// kernels of mvr_nn.hip / mvr_reduce.hip.  One host<->device round trip per
+// ICP iteration: the 17 f64 moments come back, the 3x3 SVD runs on the host,
+// the new 4x4 goes out as a kernel argument.
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "mvr_internal.h"
+
+namespace mvr {
+
+int set_error(Ctx *c, int status, const char *what, hipError_t e)
+{
+  if (c) {
+    c->last_error = what ? what : "";
+    if (e != hipSuccess) { c->last_error += ": "; c->last_error += hipGetErrorString(e); }
+  }
+  return status;
+}
+
+ProfScope::ProfScope(Ctx *ctx, int family, double w) : c(ctx), fam(family), work(w)
+{
+  if (!c->prof) return;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+  (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope()
+{
+  if (!c->prof || !a || !b) return;
+  (void)hipEventRecord(b, c->stream);
+  c->recs.push_back(ProfRec{fam, a, b, work});
+}
+
+namespace {
+
+int prof_drain(Ctx *c)
+{
+  if (c->recs.empty()) return MVR_OK;
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto &r : c->recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_launches[r.family] += 1; c->prof_ms[r.family] += ms; c->prof_work[r.family] += r.work;
+    }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  c->recs.clear();
+  return MVR_OK;
+}
+
+bool slot_ok(int s) { return s >= 0 && s < MVR_MAX_SLOTS; }
+
+int cloud_reserve(Ctx *c, Cloud &cl, size_t cap, bool keep)
+{
+  if (cl.cap >= cap) return MVR_OK;
+  size_t ncap = std::max(cap, cl.cap + cl.cap / 2);
+  float4 *np = nullptr;
+  MVR_HIP_TRY(c, hipMalloc(&np, ncap * sizeof(float4)));
+  if (keep && cl.n) {
+    hipError_t e = hipMemcpyAsync(np, cl.pts, cl.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(np); return set_error(c, MVR_E_HIP, "cloud grow copy", e); }
+  }
+  if (cl.pts) { (void)hipStreamSynchronize(c->stream); (void)hipFree(cl.pts); }
+  cl.pts = np; cl.cap = ncap;
+  return MVR_OK;
+}
+
+template <class T>
+int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
+{
+  if (cap >= want) return MVR_OK;
+  if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; cap = 0; }
+  size_t ncap = want + want / 4 + 64;
+  MVR_HIP_TRY(c, hipMalloc(&p, ncap * sizeof(T)));
+  cap = ncap;
+  return MVR_OK;
+}
+
+// forward NN + (optional) reciprocal pass for source queries [qb, qb+qn).
+// Leaves keys[], slot[], rkeys[] ready for pass1.  Returns evals in *evals.
+int run_search(Ctx *c, const Cloud &src, const Cloud &tgt, size_t qb, size_t qn, double max_dist, bool reciprocal,
+               bool fma, double *evals)
+{
+  const size_t ns = src.n, nt = tgt.n;
+  if (int rc = ensure(c, c->keys, c->keys_cap, ns)) return rc;
+  if (int rc = ensure(c, c->match, c->match_cap, ns)) return rc;
+  if (int rc = launch_fill_u64(c, c->keys + qb, qn, kKeyInit)) return rc;
+  if (int rc = launch_nn(c, src.pts, qb, qn, nullptr, nullptr, tgt.pts, nt, fma, c->keys)) return rc;
+  if (evals) *evals += (double)qn * (double)nt;
+  if (reciprocal && nt > 0 && qn > 0) {
+    const size_t nl = std::min(qn, nt);
+    if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
+    if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
+    if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
+    MVR_HIP_TRY(c, hipMemsetAsync(c->slot, 0xFF, nt * sizeof(uint32_t), c->stream));
+    MVR_HIP_TRY(c, hipMemsetAsync(c->count, 0, sizeof(uint32_t), c->stream));
+    if (int rc = launch_mark(c, c->keys, qb, qn, max_dist * max_dist, c->slot, c->list, c->count)) return rc;
+    if (int rc = launch_fill_u64(c, c->rkeys, nl, kKeyInit)) return rc;
+    // reverse pass: queries = distinct matched targets, searched in the WHOLE source
+    if (int rc = launch_nn(c, tgt.pts, 0, nl, c->list, c->count, src.pts, ns, fma, c->rkeys)) return rc;
+  }
+  return MVR_OK;
+}
+
+int read_moments(Ctx *c, size_t n_doubles)
+{
+  MVR_HIP_TRY(c, hipMemcpyAsync(c->h_moments, c->moments, n_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MVR_OK;
+}
+
+double now_ms()
+{
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+}  // namespace mvr
+
+using namespace mvr;
+
+#define API __attribute__((visibility("default")))
+#define CTX(p) reinterpret_cast<Ctx *>(p)
+
+extern "C" {
+
+API const char *mvr_strerror(int s)
+{
+  switch (s) {
+    case MVR_OK: return "ok";
+    case MVR_E_ARG: return "invalid argument";
+    case MVR_E_HIP: return "HIP runtime error or no usable GPU";
+    case MVR_E_NOCORR: return "not enough correspondences (< 3)";
+    case MVR_E_NOMEM: return "out of memory";
+    case MVR_E_SINGULAR: return "singular linear system";
+    default: return "unknown status";
+  }
+}
+
+API const char *mvr_last_error(const mvr_ctx *ctx) { return ctx ? reinterpret_cast<const Ctx *>(ctx)->last_error.c_str() : ""; }
+
+API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
+{
+  if (!out) return MVR_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MVR_E_HIP;   // no GPU: fail loudly, no fallback
+  if (device_id < 0 || device_id >= ndev) return MVR_E_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return MVR_E_HIP;
+  Ctx *c = new (std::nothrow) Ctx();
+  if (!c) return MVR_E_NOMEM;
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return MVR_E_HIP; }
+  c->n_cu = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; c->name = prop.gcnArchName;
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MVR_E_HIP; }
+    c->own_stream = true;
+  }
+  if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->moments, 64 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc(&c->h_moments, 64 * sizeof(double)) != hipSuccess) {
+    mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(c));
+    return MVR_E_HIP;
+  }
+  *out = reinterpret_cast<mvr_ctx *>(c);
+  return MVR_OK;
+}
+
+API int mvr_ctx_create(mvr_ctx **out, int device_id) { return mvr_ctx_create_on_stream(out, device_id, nullptr); }
+
+API int mvr_ctx_destroy(mvr_ctx *ctx)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto &s : c->slots) if (s.pts) (void)hipFree(s.pts);
+  if (c->keys) (void)hipFree(c->keys);
+  if (c->rkeys) (void)hipFree(c->rkeys);
+  if (c->slot) (void)hipFree(c->slot);
+  if (c->list) (void)hipFree(c->list);
+  if (c->match) (void)hipFree(c->match);
+  if (c->count) (void)hipFree(c->count);
+  if (c->partials) (void)hipFree(c->partials);
+  if (c->moments) (void)hipFree(c->moments);
+  if (c->h_moments) (void)hipHostFree(c->h_moments);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MVR_OK;
+}
+
+API int mvr_ctx_sync(mvr_ctx *ctx)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MVR_OK;
+}
+
+API int mvr_device_info(mvr_ctx *ctx, char *name, size_t cap, int *n_cu, int *clock_mhz)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (name && cap) { std::snprintf(name, cap, "%s", c->name.c_str()); }
+  if (n_cu) *n_cu = c->n_cu;
+  if (clock_mhz) *clock_mhz = c->clock_mhz;
+  return MVR_OK;
+}
+
+// ------------------------------------------------------------------- clouds
+
+API int mvr_cloud_reserve(mvr_ctx *ctx, int slot, size_t cap)
+{
+  if (!ctx || !slot_ok(slot)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  return cloud_reserve(c, c->slots[slot], cap, true);
+}
+
+API int mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, size_t stride)
+{
+  if (!ctx || !slot_ok(slot) || (n && !xyz) || (stride != 16 && stride != 12)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &cl = c->slots[slot];
+  cl.n = 0;
+  if (int rc = cloud_reserve(c, cl, n, false)) return rc;
+  if (n) {
+    if (stride == 16) {
+      MVR_HIP_TRY(c, hipMemcpyAsync(cl.pts, xyz, n * 16, hipMemcpyHostToDevice, c->stream));
+    } else {
+      float *tmp = nullptr;
+      MVR_HIP_TRY(c, hipMalloc(&tmp, n * 12));
+      hipError_t e = hipMemcpyAsync(tmp, xyz, n * 12, hipMemcpyHostToDevice, c->stream);
+      int rc = (e == hipSuccess) ? launch_unpack_xyz(c, tmp, cl.pts, n) : set_error(c, MVR_E_HIP, "upload", e);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(tmp);
+      if (rc) return rc;
+    }
+    // the caller keeps ownership of xyz and may change it right after return
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  cl.n = n;
+  return MVR_OK;
+}
+
+API int mvr_cloud_download(mvr_ctx *ctx, int slot, float *xyz, size_t cap, size_t stride, size_t *n)
+{
+  if (!ctx || !slot_ok(slot) || (stride != 16 && stride != 12)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const Cloud &cl = c->slots[slot];
+  if (n) *n = cl.n;
+  const size_t m = std::min(cap, cl.n);
+  if (!m || !xyz) return MVR_OK;
+  if (stride == 16) {
+    MVR_HIP_TRY(c, hipMemcpyAsync(xyz, cl.pts, m * 16, hipMemcpyDeviceToHost, c->stream));
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    float *tmp = nullptr;
+    MVR_HIP_TRY(c, hipMalloc(&tmp, m * 12));
+    int rc = launch_pack_xyz(c, cl.pts, tmp, m);
+    hipError_t e = hipMemcpyAsync(xyz, tmp, m * 12, hipMemcpyDeviceToHost, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_error(c, MVR_E_HIP, "download", e);
+  }
+  return MVR_OK;
+}
+
+API int mvr_cloud_size(mvr_ctx *ctx, int slot, size_t *n)
+{
+  if (!ctx || !slot_ok(slot) || !n) return MVR_E_ARG;
+  *n = CTX(ctx)->slots[slot].n;
+  return MVR_OK;
+}
+
+API int mvr_cloud_clear(mvr_ctx *ctx, int slot)
+{
+  if (!ctx || !slot_ok(slot)) return MVR_E_ARG;
+  CTX(ctx)->slots[slot].n = 0;
+  return MVR_OK;
+}
+
+API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
+{
+  if (!ctx || !slot_ok(dst) || !slot_ok(src)) return MVR_E_ARG;
+  if (dst == src) return MVR_OK;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &d = c->slots[dst]; const Cloud &s = c->slots[src];
+  d.n = 0;
+  if (int rc = cloud_reserve(c, d, s.n, false)) return rc;
+  if (s.n) {
+    ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)s.n);
+    MVR_HIP_TRY(c, hipMemcpyAsync(d.pts, s.pts, s.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+  }
+  d.n = s.n;
+  return MVR_OK;
+}
+
+API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
+{
+  if (!ctx || !slot_ok(dst) || !slot_ok(src)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &d = c->slots[dst];
+  const size_t add = c->slots[src].n;         // read before a self-append grows it
+  if (int rc = cloud_reserve(c, d, d.n + add, true)) return rc;
+  const Cloud &s = c->slots[src];
+  if (add) {
+    ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)add);
+    MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+  }
+  d.n += add;
+  return MVR_OK;
+}
+
+API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
+{
+  if (!ctx || !slot_ok(dst) || !slot_ok(src) || !T) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = c->slots[src].n;
+  if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
+  if (int rc = launch_transform_f64(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
+  c->slots[dst].n = n;
+  return MVR_OK;
+}
+
+API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16])
+{
+  if (!ctx || !slot_ok(dst) || !slot_ok(src) || !T) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = c->slots[src].n;
+  if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
+  if (int rc = launch_transform_f32(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
+  c->slots[dst].n = n;
+  return MVR_OK;
+}
+
+// ----------------------------------------------------------------- hot path
+
+API int mvr_nn(mvr_ctx *ctx, int qs, int ts, int fma, uint32_t *idx, float *d2)
+{
+  if (!ctx || !slot_ok(qs) || !slot_ok(ts)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const Cloud &q = c->slots[qs], &t = c->slots[ts];
+  if (q.n == 0) return MVR_OK;
+  if (int rc = ensure(c, c->keys, c->keys_cap, q.n)) return rc;
+  if (int rc = launch_fill_u64(c, c->keys, q.n, kKeyInit)) return rc;
+  if (int rc = launch_nn(c, q.pts, 0, q.n, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
+  uint32_t *didx = nullptr; float *dd2 = nullptr;
+  MVR_HIP_TRY(c, hipMalloc(&didx, q.n * 4));
+  if (hipMalloc(&dd2, q.n * 4) != hipSuccess) { (void)hipFree(didx); return set_error(c, MVR_E_HIP, "hipMalloc"); }
+  int rc = launch_decode_keys(c, c->keys, q.n, didx, dd2);
+  hipError_t e = hipSuccess;
+  if (!rc && idx) e = hipMemcpyAsync(idx, didx, q.n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (!rc && e == hipSuccess && d2) e = hipMemcpyAsync(d2, dd2, q.n * 4, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  (void)hipFree(didx); (void)hipFree(dd2);
+  if (rc) return rc;
+  if (e != hipSuccess) return set_error(c, MVR_E_HIP, "mvr_nn copy", e);
+  if (e2 != hipSuccess) return set_error(c, MVR_E_HIP, "mvr_nn sync", e2);
+  return MVR_OK;
+}
+
+static int pair_common(Ctx *c, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb, size_t qn,
+                       double *evals)
+{
+  const Cloud &s = c->slots[ss], &t = c->slots[ts];
+  if (int rc = run_search(c, s, t, qb, qn, max_dist, reciprocal != 0, fma != 0, evals)) return rc;
+  return launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, c->count, qb, qn, max_dist * max_dist,
+                      reciprocal != 0 && t.n > 0, c->match, c->moments);
+}
+
+API int mvr_correspondences(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma,
+                            int32_t *query, int32_t *match, float *dist2, size_t cap, size_t *m)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !m) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  *m = 0;
+  const size_t ns = c->slots[ss].n;
+  if (ns == 0) return MVR_OK;
+  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, 0, ns, nullptr)) return rc;
+  std::vector<int32_t> hm(ns);
+  std::vector<nnkey_t> hk(ns);
+  MVR_HIP_TRY(c, hipMemcpyAsync(hm.data(), c->match, ns * 4, hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipMemcpyAsync(hk.data(), c->keys, ns * 8, hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  size_t k = 0;
+  for (size_t i = 0; i < ns; ++i) {
+    if (hm[i] < 0) continue;
+    if (k < cap) {
+      if (query) query[k] = (int32_t)i;
+      if (match) match[k] = hm[i];
+      if (dist2) { uint32_t b = (uint32_t)(hk[i] >> 32); std::memcpy(&dist2[k], &b, 4); }
+    }
+    ++k;
+  }
+  *m = k;
+  return MVR_OK;
+}
+
+API int mvr_pair_moments(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma,
+                         mvr_pair_moments_t *out)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !out) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  std::memset(out, 0, sizeof *out);
+  const Cloud &s = c->slots[ss], &t = c->slots[ts];
+  if (s.n == 0) return MVR_OK;
+  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, 0, s.n, nullptr)) return rc;
+  if (int rc = launch_pass2(c, s.pts, t.pts, c->match, 0, s.n, c->moments)) return rc;
+  if (int rc = read_moments(c, 17)) return rc;
+  const double *h = c->h_moments;
+  out->n = h[0];
+  for (int k = 0; k < 3; ++k) { out->mean_src[k] = h[1 + k]; out->mean_tgt[k] = h[4 + k]; }
+  out->mse = h[7];
+  for (int k = 0; k < 9; ++k) out->sigma[k] = h[8 + k];
+  return MVR_OK;
+}
+
+static int moments2_impl(Ctx *c, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb, size_t qn,
+                         const double origin[3], double *dev_out)
+{
+  const Cloud &s = c->slots[ss], &t = c->slots[ts];
+  if (qb > s.n) qb = s.n;
+  if (qn > s.n - qb) qn = s.n - qb;
+  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, qb, qn, nullptr)) return rc;
+  return launch_moments2(c, s.pts, t.pts, c->match, qb, qn, origin, dev_out);
+}
+
+API int mvr_pair_moments2_dev(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb,
+                              size_t qn, const double origin[3], double *dev_out)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !origin || !dev_out) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  return moments2_impl(c, ss, ts, max_dist, reciprocal, fma, qb, qn, origin, dev_out);
+}
+
+API int mvr_pair_moments2(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb,
+                          size_t qn, const double origin[3], mvr_pair_moments2_t *out)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !origin || !out) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = moments2_impl(c, ss, ts, max_dist, reciprocal, fma, qb, qn, origin, c->moments)) return rc;
+  if (int rc = read_moments(c, 32)) return rc;
+  static_assert(sizeof(mvr_pair_moments2_t) == 31 * sizeof(double), "moments2 layout");
+  std::memcpy(out, c->h_moments, sizeof *out);
+  return MVR_OK;
+}
+
+API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params *p, float T_out[16],
+                      mvr_icp_stats *st)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || (os >= 0 && !slot_ok(os)) || !p || !T_out) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const double t0 = now_ms();
+  const size_t ns = c->slots[ss].n;
+  // App. A.1: input_transformed = *input (guess == identity), w := 1
+  Cloud &cur = c->slots[kScratchCur];
+  cur.n = 0;
+  if (int rc = cloud_reserve(c, cur, ns, false)) return rc;
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (ns) MVR_HIP_TRY(c, hipMemcpyAsync(cur.pts, c->slots[ss].pts, ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+  cur.n = ns;
+  float fin[16], tr[16];
+  std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
+  // DefaultConvergenceCriteria (App. A.4)
+  const double rot_thr = 1.0 - p->transformation_epsilon, trans_thr = p->transformation_epsilon;
+  const double rel_mse = p->euclidean_fitness_eps, abs_mse = 1e-12;
+  double prev_mse = DBL_MAX, cur_mse = 0.0, evals = 0.0, fwdq = 0.0;
+  int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
+  const Cloud &tgt = c->slots[ts];
+  do {
+    double ev = 0.0;
+    if (int rc = run_search(c, cur, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev)) return rc;
+    if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, c->slot, c->count, 0, ns,
+                              p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
+                              c->moments)) return rc;
+    if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, 0, ns, c->moments)) return rc;
+    if (int rc = read_moments(c, 18)) return rc;
+    const double *h = c->h_moments;
+    fwdq += (double)ns;
+    evals += ev + h[17] * (double)ns;   // forward Ns*Nt + reverse Nt'*Ns
+    ncorr = (int)h[0];
+    if (h[0] < 3.0) { state = MVR_CONV_NO_CORRESPONDENCES; converged = 0; status = MVR_E_NOCORR; break; }
+    umeyama_from_moments(h + 1, h + 4, h + 8, tr, nullptr);
+    cur_mse = h[7];
+    if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
+    mvr_mat4f_mul(tr, fin, fin);
+    ++iters;
+    state = MVR_CONV_NOT; converged = 0;
+    if (iters >= p->max_iterations) { state = MVR_CONV_ITERATIONS; converged = 1; }
+    else {
+      const double cos_angle = 0.5 * ((double)tr[0] + (double)tr[5] + (double)tr[10] - 1.0);
+      const double t2 = (double)tr[12] * (double)tr[12] + (double)tr[13] * (double)tr[13] + (double)tr[14] * (double)tr[14];
+      if (cos_angle >= rot_thr && t2 <= trans_thr) { state = MVR_CONV_TRANSFORM; converged = 1; }
+      else if (std::fabs(cur_mse - prev_mse) < abs_mse) { state = MVR_CONV_ABS_MSE; converged = 1; }
+      else if (std::fabs(cur_mse - prev_mse) / prev_mse < rel_mse) { state = MVR_CONV_REL_MSE; converged = 1; }
+      else prev_mse = cur_mse;
+    }
+  } while (!converged);
+  // output = final * (*input), from the ORIGINAL input: alias-safe (registrator.cpp:920)
+  if (os >= 0) {
+    if (os != ss) { c->slots[os].n = 0; if (int rc = cloud_reserve(c, c->slots[os], ns, false)) return rc; }
+    if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
+    c->slots[os].n = ns;
+  }
+  std::memcpy(T_out, fin, sizeof fin);
+  if (st) {
+    st->iterations = iters; st->converged = converged; st->state = state; st->n_corr = ncorr; st->mse = cur_mse;
+    st->evals = evals; st->fwd_queries = fwdq; st->ms = now_ms() - t0;
+  }
+  return status;
+}
+
+API int mvr_fitness(mvr_ctx *ctx, int is, int ts, const float T[16], double max_range, int fma, double *score)
+{
+  if (!ctx || !slot_ok(is) || !slot_ok(ts) || !T || !score) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  *score = DBL_MAX;
+  const size_t ns = c->slots[is].n;
+  if (ns == 0) return MVR_OK;
+  Cloud &tmp = c->slots[kScratchTmp];
+  tmp.n = 0;
+  if (int rc = cloud_reserve(c, tmp, ns, false)) return rc;
+  if (int rc = launch_transform_f32(c, c->slots[is].pts, tmp.pts, ns, T)) return rc;
+  tmp.n = ns;
+  const Cloud &t = c->slots[ts];
+  if (int rc = ensure(c, c->keys, c->keys_cap, ns)) return rc;
+  if (int rc = launch_fill_u64(c, c->keys, ns, kKeyInit)) return rc;
+  if (int rc = launch_nn(c, tmp.pts, 0, ns, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
+  if (int rc = launch_fitness(c, c->keys, ns, max_range, c->moments)) return rc;
+  if (int rc = read_moments(c, 2)) return rc;
+  if (c->h_moments[1] > 0) *score = c->h_moments[0] / c->h_moments[1];
+  return MVR_OK;
+}
+
+// ----------------------------------------------------------- instrumentation
+
+API int mvr_prof_enable(mvr_ctx *ctx, int on)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (!on) { if (int rc = prof_drain(c)) return rc; }
+  c->prof = on != 0;
+  return MVR_OK;
+}
+
+API int mvr_prof_reset(mvr_ctx *ctx)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (int rc = prof_drain(c)) return rc;
+  for (int k = 0; k < MVR_K_COUNT; ++k) { c->prof_launches[k] = 0; c->prof_ms[k] = 0; c->prof_work[k] = 0; }
+  return MVR_OK;
+}
+
+API int mvr_prof_get(mvr_ctx *ctx, int family, uint64_t *launches, double *ms, double *work)
+{
+  if (!ctx || family < 0 || family >= MVR_K_COUNT) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (int rc = prof_drain(c)) return rc;
+  if (launches) *launches = c->prof_launches[family];
+  if (ms) *ms = c->prof_ms[family];
+  if (work) *work = c->prof_work[family];
+  return MVR_OK;
+}
+
+}  // extern "C"

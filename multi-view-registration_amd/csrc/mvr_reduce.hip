@@ -1,0 +1,431 @@
+// csrc/mvr_reduce.hip -- HBM-bound kernels of the ICP hot path for gfx950:
+//   K1  transform_f32 / transform_f64  (ICP::transformCloud, getTransformedPoints)
+//   K3  mark_kernel                    (dedupe of matched targets for the reciprocal pass)
+//   K5  pass1_kernel                   (reciprocal filter + centroid sums)
+//   K6  pass2_kernel                   (3x3 covariance about the centroids)
+//   K7  fitness_kernel                 (getFitnessScore reduction)
+//   K8  moments2_kernel                (raw second moments for LUM::computeEdge)
+// All streaming/gather work: one 16-byte point per lane per access, f64
+// accumulators per lane, wave reduction with __shfl_down (64 lanes), one LDS
+// hop across the 4 waves, per-block partials to HBM and a fixed-order final
+// sum -- bitwise reproducible run to run (no float atomics).
+// Compiled with -ffp-contract=off.
+#include "mvr_internal.h"
+
+namespace mvr {
+
+namespace {
+
+constexpr int kRT = 256;          // threads per reduction block
+constexpr int kMaxBlocks = 1024;  // partial rows
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sums of K per-thread doubles -> row `blockIdx.x` of partials
+template <int K>
+__device__ __forceinline__ void block_partials(const double (&acc)[K], double *__restrict__ partials)
+{
+  __shared__ double lds[kRT / 64][K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) lds[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = lds[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kRT / 64; ++w) s += lds[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
+  }
+}
+
+// fixed-order sum of `rows` partial rows of K doubles (one block, K <= 64)
+template <int K>
+__device__ __forceinline__ void sum_rows(const double *__restrict__ partials, int rows, double (&out)[K],
+                                         double *lds /* [K] */)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < K; k += kRT / 64) {
+    double s = 0.0;
+    for (int r = lane; r < rows; r += 64) s += partials[(size_t)r * K + k];
+    s = wave_sum(s);
+    if (lane == 0) lds[k] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = lds[k];
+}
+
+// ---------------------------------------------------------------- K1 transforms
+
+struct Mat34f { float m[12]; };   // rows of the 3x4, row-major
+struct Mat44d { double m[16]; };  // column-major 4x4
+
+__global__ void transform_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n, Mat34f T)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  float4 o;
+  o.x = ((T.m[0] * p.x + T.m[1] * p.y) + T.m[2] * p.z) + T.m[3];
+  o.y = ((T.m[4] * p.x + T.m[5] * p.y) + T.m[6] * p.z) + T.m[7];
+  o.z = ((T.m[8] * p.x + T.m[9] * p.y) + T.m[10] * p.z) + T.m[11];
+  o.w = 1.0f;
+  out[i] = o;
+}
+
+__global__ void transform_f64_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n, Mat44d T)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  const double x = p.x, y = p.y, z = p.z;
+  const double d = 1.0 / (((T.m[3] * x + T.m[7] * y) + T.m[11] * z) + T.m[15]);
+  float4 o;
+  o.x = (float)((((T.m[0] * x + T.m[4] * y) + T.m[8] * z) + T.m[12]) * d);
+  o.y = (float)((((T.m[1] * x + T.m[5] * y) + T.m[9] * z) + T.m[13]) * d);
+  o.z = (float)((((T.m[2] * x + T.m[6] * y) + T.m[10] * z) + T.m[14]) * d);
+  o.w = 1.0f;
+  out[i] = o;
+}
+
+__global__ void unpack_xyz_kernel(const float *__restrict__ packed, float4 *__restrict__ out, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = make_float4(packed[3 * i], packed[3 * i + 1], packed[3 * i + 2], 1.0f);
+}
+
+__global__ void pack_xyz_kernel(const float4 *__restrict__ in, float *__restrict__ packed, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = in[i];
+  packed[3 * i] = p.x; packed[3 * i + 1] = p.y; packed[3 * i + 2] = p.z;
+}
+
+__global__ void decode_keys_kernel(const nnkey_t *__restrict__ keys, size_t n, uint32_t *__restrict__ idx,
+                                   float *__restrict__ d2)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const nnkey_t k = keys[i];
+  const uint32_t j = (uint32_t)k;
+  if (idx) idx[i] = j;
+  if (d2) d2[i] = (j == kNone) ? __builtin_inff() : __uint_as_float((uint32_t)(k >> 32));
+}
+
+// ------------------------------------------------------------------- K3 mark
+// Every source point whose NN is within max_dist marks its target; the first
+// marker (atomicCAS) appends the target to the list of distinct reverse
+// queries.  O(Ns) however large the target has grown (registrator.cpp:576).
+__global__ void mark_kernel(const nnkey_t *__restrict__ keys, size_t q_begin, size_t q_count, double max2,
+                            uint32_t *__restrict__ slot, uint32_t *__restrict__ list, uint32_t *__restrict__ count)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= q_count) return;
+  const nnkey_t key = keys[q_begin + k];
+  const uint32_t j = (uint32_t)key;
+  if (j == kNone) return;
+  const float d2 = __uint_as_float((uint32_t)(key >> 32));
+  if ((double)d2 > max2) return;
+  if (atomicCAS(&slot[j], kNone, kMarked) == kNone) {
+    const uint32_t pos = atomicAdd(count, 1u);
+    list[pos] = j;
+    slot[j] = pos;      // read only by later kernels on the same stream
+  }
+}
+
+// -------------------------------------------------------------- K5 pass 1
+// acc: 0 n, 1..3 sum p, 4..6 sum q, 7 sum d2
+__global__ void __launch_bounds__(kRT)
+pass1_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const nnkey_t *__restrict__ keys,
+             const nnkey_t *__restrict__ rkeys, const uint32_t *__restrict__ slot, size_t q_begin,
+             size_t q_count, double max2, int reciprocal, int32_t *__restrict__ match,
+             double *__restrict__ partials)
+{
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
+    const size_t i = q_begin + k;
+    const nnkey_t key = keys[i];
+    const uint32_t j = (uint32_t)key;
+    const float d2 = __uint_as_float((uint32_t)(key >> 32));
+    bool ok = (j != kNone) && !((double)d2 > max2);
+    if (ok && reciprocal) {
+      // App. A.2: NN of t_j in the source must be i itself, within max_dist
+      const nnkey_t rk = rkeys[slot[j]];
+      const float dr = __uint_as_float((uint32_t)(rk >> 32));
+      ok = ((uint32_t)rk == (uint32_t)i) && !((double)dr > max2);
+    }
+    match[i] = ok ? (int32_t)j : -1;
+    if (ok) {
+      const float4 p = src[i], q = tgt[j];
+      acc[0] += 1.0;
+      acc[1] += (double)p.x; acc[2] += (double)p.y; acc[3] += (double)p.z;
+      acc[4] += (double)q.x; acc[5] += (double)q.y; acc[6] += (double)q.z;
+      acc[7] += (double)d2;
+    }
+  }
+  block_partials<8>(acc, partials);
+}
+
+// moments: [0] n, [1..3] mean p, [4..6] mean q, [7] mse
+// (+ [17] = number of distinct reverse queries, for the evals accounting)
+__global__ void __launch_bounds__(kRT) pass1_final_kernel(const double *__restrict__ partials, int rows,
+                                                           const uint32_t *__restrict__ count,
+                                                           double *__restrict__ moments)
+{
+  __shared__ double lds[8];
+  double s[8];
+  sum_rows<8>(partials, rows, s, lds);
+  if (threadIdx.x == 0) {
+    const double n = s[0];
+    moments[0] = n;
+    for (int k = 1; k < 8; ++k) moments[k] = (n > 0) ? s[k] / n : 0.0;
+    moments[17] = count ? (double)*count : 0.0;
+  }
+}
+
+// -------------------------------------------------------------- K6 pass 2
+__global__ void __launch_bounds__(kRT)
+pass2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const int32_t *__restrict__ match,
+             size_t q_begin, size_t q_count, const double *__restrict__ moments, double *__restrict__ partials)
+{
+  const double mpx = moments[1], mpy = moments[2], mpz = moments[3];
+  const double mqx = moments[4], mqy = moments[5], mqz = moments[6];
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
+    const size_t i = q_begin + k;
+    const int32_t j = match[i];
+    if (j < 0) continue;
+    const float4 p = src[i], q = tgt[j];
+    const double px = (double)p.x - mpx, py = (double)p.y - mpy, pz = (double)p.z - mpz;
+    const double qx = (double)q.x - mqx, qy = (double)q.y - mqy, qz = (double)q.z - mqz;
+    acc[0] += qx * px; acc[1] += qx * py; acc[2] += qx * pz;
+    acc[3] += qy * px; acc[4] += qy * py; acc[5] += qy * pz;
+    acc[6] += qz * px; acc[7] += qz * py; acc[8] += qz * pz;
+  }
+  block_partials<9>(acc, partials);
+}
+
+__global__ void __launch_bounds__(kRT) pass2_final_kernel(const double *__restrict__ partials, int rows,
+                                                           double *__restrict__ moments)
+{
+  __shared__ double lds[9];
+  double s[9];
+  sum_rows<9>(partials, rows, s, lds);
+  if (threadIdx.x == 0) {
+    const double n = moments[0];
+    for (int k = 0; k < 9; ++k) moments[8 + k] = (n > 0) ? s[k] / n : 0.0;
+  }
+}
+
+// -------------------------------------------------------------- K8 moments2
+// 28 sums about `origin`: n, p(3), q(3), pp(6), qq(6), pq(9)
+struct Vec3d { double x, y, z; };
+
+__global__ void __launch_bounds__(kRT)
+moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const int32_t *__restrict__ match,
+                size_t q_begin, size_t q_count, Vec3d o, double *__restrict__ partials)
+{
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
+    const size_t i = q_begin + k;
+    const int32_t j = match[i];
+    if (j < 0) continue;
+    const float4 p4 = src[i], q4 = tgt[j];
+    const double px = (double)p4.x - o.x, py = (double)p4.y - o.y, pz = (double)p4.z - o.z;
+    const double qx = (double)q4.x - o.x, qy = (double)q4.y - o.y, qz = (double)q4.z - o.z;
+    acc[0] += 1.0;
+    acc[1] += px; acc[2] += py; acc[3] += pz;
+    acc[4] += qx; acc[5] += qy; acc[6] += qz;
+    acc[7] += px * px; acc[8] += px * py; acc[9] += px * pz; acc[10] += py * py; acc[11] += py * pz; acc[12] += pz * pz;
+    acc[13] += qx * qx; acc[14] += qx * qy; acc[15] += qx * qz; acc[16] += qy * qy; acc[17] += qy * qz; acc[18] += qz * qz;
+    acc[19] += px * qx; acc[20] += px * qy; acc[21] += px * qz;
+    acc[22] += py * qx; acc[23] += py * qy; acc[24] += py * qz;
+    acc[25] += pz * qx; acc[26] += pz * qy; acc[27] += pz * qz;
+  }
+  block_partials<28>(acc, partials);
+}
+
+// out (32 doubles): [0] n, [1..3] origin, [4..6] sp, [7..9] sq, [10..15] spp, [16..21] sqq, [22..30] spq, [31] 0
+__global__ void __launch_bounds__(kRT) moments2_final_kernel(const double *__restrict__ partials, int rows, Vec3d o,
+                                                              double *__restrict__ out)
+{
+  __shared__ double lds[28];
+  double s[28];
+  sum_rows<28>(partials, rows, s, lds);
+  if (threadIdx.x == 0) {
+    out[0] = s[0]; out[1] = o.x; out[2] = o.y; out[3] = o.z;
+    for (int k = 1; k < 28; ++k) out[3 + k] = s[k];
+    out[31] = 0.0;
+  }
+}
+
+// -------------------------------------------------------------- K7 fitness
+__global__ void __launch_bounds__(kRT)
+fitness_kernel(const nnkey_t *__restrict__ keys, size_t n, double max_range, double *__restrict__ partials)
+{
+  double acc[2] = {0, 0};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const nnkey_t key = keys[i];
+    if ((uint32_t)key == kNone) continue;
+    const float d2 = __uint_as_float((uint32_t)(key >> 32));
+    if ((double)d2 <= max_range) { acc[0] += (double)d2; acc[1] += 1.0; }
+  }
+  block_partials<2>(acc, partials);
+}
+
+__global__ void __launch_bounds__(kRT) fitness_final_kernel(const double *__restrict__ partials, int rows,
+                                                             double *__restrict__ moments)
+{
+  __shared__ double lds[2];
+  double s[2];
+  sum_rows<2>(partials, rows, s, lds);
+  if (threadIdx.x == 0) { moments[0] = s[0]; moments[1] = s[1]; }
+}
+
+inline int reduce_blocks(const Ctx *c, size_t n)
+{
+  const size_t want = (n + kRT - 1) / kRT;
+  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu * 4);
+  return (int)std::max<size_t>(1, std::min(want, cap));
+}
+
+inline int ensure_partials(Ctx *c, size_t doubles)
+{
+  if (c->partials_cap >= doubles) return MVR_OK;
+  if (c->partials) (void)hipFree(c->partials);
+  c->partials = nullptr; c->partials_cap = 0;
+  MVR_HIP_TRY(c, hipMalloc(&c->partials, doubles * sizeof(double)));
+  c->partials_cap = doubles;
+  return MVR_OK;
+}
+
+}  // namespace
+
+int launch_transform_f32(Ctx *c, const float4 *in, float4 *out, size_t n, const float T[16])
+{
+  if (n == 0) return MVR_OK;
+  Mat34f M;
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) M.m[4 * r + k] = T[r + 4 * k];
+  ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)n);
+  hipLaunchKernelGGL(transform_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, out, n, M);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_transform_f64(Ctx *c, const float4 *in, float4 *out, size_t n, const double T[16])
+{
+  if (n == 0) return MVR_OK;
+  Mat44d M;
+  for (int k = 0; k < 16; ++k) M.m[k] = T[k];
+  ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)n);
+  hipLaunchKernelGGL(transform_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, out, n, M);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_unpack_xyz(Ctx *c, const float *packed, float4 *out, size_t n)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(unpack_xyz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, packed, out, n);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_pack_xyz(Ctx *c, const float4 *in, float *packed, size_t n)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(pack_xyz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, packed, n);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_decode_keys(Ctx *c, const nnkey_t *keys, size_t n, uint32_t *idx, float *d2)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(decode_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, keys, n, idx, d2);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_mark(Ctx *c, const nnkey_t *keys, size_t q_begin, size_t q_count, double max2, uint32_t *slot,
+                uint32_t *list, uint32_t *count)
+{
+  if (q_count == 0) return MVR_OK;
+  ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count);
+  hipLaunchKernelGGL(mark_kernel, dim3((unsigned)((q_count + 255) / 256)), dim3(256), 0, c->stream, keys, q_begin,
+                     q_count, max2, slot, list, count);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys, const nnkey_t *rkeys,
+                 const uint32_t *slot, const uint32_t *count, size_t q_begin, size_t q_count, double max2,
+                 bool reciprocal, int32_t *match, double *moments)
+{
+  const int blocks = reduce_blocks(c, q_count);
+  if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
+  // K5 touches Ns*(12+4+4) + 12*M algorithmic bytes (M <= Ns)
+  ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
+  hipLaunchKernelGGL(pass1_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, keys, rkeys, slot, q_begin,
+                     q_count, max2, reciprocal ? 1 : 0, match, c->partials);
+  hipLaunchKernelGGL(pass1_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks,
+                     reciprocal ? count : nullptr, moments);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, size_t q_begin,
+                 size_t q_count, double *moments)
+{
+  const int blocks = reduce_blocks(c, q_count);
+  if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
+  ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
+  hipLaunchKernelGGL(pass2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, q_begin, q_count,
+                     moments, c->partials);
+  hipLaunchKernelGGL(pass2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, size_t q_begin,
+                    size_t q_count, const double origin[3], double *out)
+{
+  const int blocks = reduce_blocks(c, q_count);
+  if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
+  Vec3d o{origin[0], origin[1], origin[2]};
+  ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
+  hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, q_begin, q_count, o,
+                     c->partials);
+  hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_fitness(Ctx *c, const nnkey_t *keys, size_t n, double max_range, double *moments)
+{
+  const int blocks = reduce_blocks(c, n);
+  if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
+  ProfScope ps(c, MVR_K_REDUCE, 8.0 * (double)n);
+  hipLaunchKernelGGL(fitness_kernel, dim3(blocks), dim3(kRT), 0, c->stream, keys, n, max_range, c->partials);
+  hipLaunchKernelGGL(fitness_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+}  // namespace mvr
