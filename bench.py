@@ -91,7 +91,12 @@ def main():
     if rank == 0:
         log("[bench] synth %dx%d in %.2fs; rank0 segments %s" % (V, N, time.time() - t0, segs))
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit (non-default) HIP stream carries everything in order: the
+    # library's kernels, torch's zero_/D2H copies and the RCCL all-reduce
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream, "need a non-default stream handle"
     ctx = mvr.Context(local_rank, stream=stream)
     table = torch.zeros((V, 32), dtype=torch.float64, device="cuda")
     # raw scans live in slots V..2V-1, their posed copies (what LUM sees) in 0..V-1
@@ -217,17 +222,20 @@ def main():
         import oracle as orc    # checker only: the CPU restatement timed beside the GPU path
         t0 = time.perf_counter()
         clouds = [orc.transform_f64(poses0[v], scans[v]) for v in range(V)]
-        nq = 0
-        for s, t in edges:
-            c = orc.correspondences(clouds[s], clouds[t], args.max_dist, reciprocal=True, fma=bool(args.fma), kdtree=True)
-            orc.umeyama(clouds[s], clouds[t], c)
-            nq += len(clouds[s])
-            if time.perf_counter() - t0 > 45:
-                break
+        nq, passes = 0, 0
+        while time.perf_counter() - t0 < 10.0:            # bounded sample: >= 10 s, whole ring passes
+            for s, t in edges:
+                c = orc.correspondences(clouds[s], clouds[t], args.max_dist, reciprocal=True, fma=bool(args.fma), kdtree=True)
+                orc.umeyama(clouds[s], clouds[t], c)
+                nq += len(clouds[s])
+                if time.perf_counter() - t0 > 45:
+                    break
+            passes += 1
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": nq / dt, "unit": "correspondences/s", "cores": 1, "kind": "port",
-                               "sample": "%d of %d ring pairs of the same workload (kd-tree exact NN, reciprocal, "
-                                         "Umeyama), oracle/mvr_oracle.c single thread, %.1f s" % (nq // N, V, dt),
+                               "sample": "%d ring pairs (%d pass(es) over the %d pairs of the same workload; kd-tree "
+                                         "exact NN built per pair, reciprocal filter, Umeyama), oracle/mvr_oracle.c, "
+                                         "1 thread, %.1f s" % (nq // N, passes, V, dt),
                                "host_cpus": os.cpu_count()}
     if rank == 0:
         print(json.dumps(out), flush=True)

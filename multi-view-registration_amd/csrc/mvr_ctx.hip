@@ -30,11 +30,23 @@ ProfScope::ProfScope(Ctx *ctx, int family, double w) : c(ctx), fam(family), work
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
   (void)hipEventRecord(a, c->stream);
 }
+ProfScope::ProfScope(Ctx *ctx, int family, const uint32_t *dev_count, double per_cnt, double upper_bound)
+    : ProfScope(ctx, family, upper_bound)
+{
+  d_count = dev_count; per_count = per_cnt;
+}
 ProfScope::~ProfScope()
 {
   if (!c->prof || !a || !b) return;
   (void)hipEventRecord(b, c->stream);
-  c->recs.push_back(ProfRec{fam, a, b, work});
+  const uint32_t *hc = nullptr;
+  if (d_count && c->h_counts && c->h_counts_used < kProfCounts) {
+    uint32_t *slot = c->h_counts + c->h_counts_used;
+    if (hipMemcpyAsync(slot, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess) {
+      hc = slot; ++c->h_counts_used;
+    }
+  }
+  c->recs.push_back(ProfRec{fam, a, b, work, hc, per_count});
 }
 
 namespace {
@@ -46,11 +58,13 @@ int prof_drain(Ctx *c)
   for (auto &r : c->recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-      c->prof_launches[r.family] += 1; c->prof_ms[r.family] += ms; c->prof_work[r.family] += r.work;
+      c->prof_launches[r.family] += 1; c->prof_ms[r.family] += ms;
+      c->prof_work[r.family] += r.h_count ? (double)*r.h_count * r.per_count : r.work;
     }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   c->recs.clear();
+  c->h_counts_used = 0;
   return MVR_OK;
 }
 
@@ -167,7 +181,8 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
     c->own_stream = true;
   }
   if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->moments, 64 * sizeof(double)) != hipSuccess ||
-      hipHostMalloc(&c->h_moments, 64 * sizeof(double)) != hipSuccess) {
+      hipHostMalloc(&c->h_moments, 64 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc(&c->h_counts, kProfCounts * sizeof(uint32_t)) != hipSuccess) {
     mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(c));
     return MVR_E_HIP;
   }
@@ -194,6 +209,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   if (c->partials) (void)hipFree(c->partials);
   if (c->moments) (void)hipFree(c->moments);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
+  if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return MVR_OK;

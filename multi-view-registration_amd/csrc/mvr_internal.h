@@ -38,7 +38,9 @@ constexpr int kNNTile = 1024;     // target points per LDS tile (16 KB)
 constexpr int kNNSub = 32;        // sub-tile over which only min(d2) is tracked
 constexpr int kNNQB = kNNThreads * kNNQ;
 
-struct ProfRec { int family; hipEvent_t a, b; double work; };
+// work = `work` unless `h_count` is set: then work = *h_count * per_count (the
+// reverse NN pass, whose query count is only known on the device)
+struct ProfRec { int family; hipEvent_t a, b; double work; const uint32_t *h_count; double per_count; };
 
 struct Ctx {
   int device = 0;
@@ -62,6 +64,8 @@ struct Ctx {
   // instrumentation
   bool prof = false;
   std::vector<ProfRec> recs;
+  uint32_t *h_counts = nullptr;                       // pinned: device counters copied per profiled launch
+  size_t h_counts_used = 0;
   uint64_t prof_launches[MVR_K_COUNT] = {0};
   double prof_ms[MVR_K_COUNT] = {0};
   double prof_work[MVR_K_COUNT] = {0};
@@ -78,9 +82,16 @@ int set_error(Ctx *c, int status, const char *what, hipError_t e = hipSuccess);
     if (_e != hipSuccess) return ::mvr::set_error((ctx), MVR_E_HIP, #expr, _e); \
   } while (0)
 
+constexpr size_t kProfCounts = 1 << 16;
+
 struct ProfScope {
   Ctx *c; int fam; hipEvent_t a = nullptr, b = nullptr; double work;
+  const uint32_t *d_count = nullptr; double per_count = 0.0;
   ProfScope(Ctx *ctx, int family, double w);
+  // work is (*d_count) * per_count, read back asynchronously after the launch
+  ProfScope(Ctx *ctx, int family, const uint32_t *dev_count, double per_cnt, double upper_bound);
+  ProfScope(const ProfScope &) = delete;
+  ProfScope &operator=(const ProfScope &) = delete;
   ~ProfScope();
 };
 

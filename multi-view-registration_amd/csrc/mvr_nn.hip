@@ -188,7 +188,8 @@ int launch_nn(Ctx *c, const float4 *q, size_t q_begin, size_t q_count, const uin
   // 4 per CU keeps the SIMDs busy across barriers.  Never more blocks than units.
   const uint64_t resident = (uint64_t)c->n_cu * 4;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>(units, resident);
-  ProfScope ps(c, MVR_K_NN, (double)q_count * (double)nt);
+  // evaluations: queries x targets; for the reverse pass the query count lives on the device
+  ProfScope ps(c, MVR_K_NN, qlist ? qcount : nullptr, (double)nt, (double)q_count * (double)nt);
   if (fma)
     hipLaunchKernelGGL(nn_kernel<true>, dim3(blocks), dim3(kNNThreads), 0, c->stream, q,
                        (uint32_t)q_begin, (uint32_t)q_count, qlist, qcount, t, (uint32_t)nt, keys);
