@@ -162,6 +162,12 @@ int  mvr_pair_moments2_dev(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_
                            int reciprocal, int fma_dist, size_t q_begin, size_t q_count,
                            const double origin[3], double *dev_out);
 
+/* raw second moments of caller-supplied correspondences (lum.setCorrespondences,
+ * registrator.cpp:650): query[k] indexes src_slot, match[k] indexes tgt_slot. */
+int  mvr_pair_moments2_from_corr(mvr_ctx *ctx, int src_slot, int tgt_slot, const int32_t *query,
+                                 const int32_t *match, size_t m, const double origin[3],
+                                 mvr_pair_moments2_t *out);
+
 /* host-side solves on the moments (3x3 SVD stays on the host) */
 /* TransformationEstimationSVD / Eigen::umeyama (App. A.3). */
 int  mvr_umeyama_from_moments(const mvr_pair_moments_t *mom, float T[16], double sv[3]);

@@ -101,6 +101,8 @@ SIGNATURES = {
                                     _dp, C.POINTER(PairMoments2)]),
     "mvr_pair_moments2_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _sz,
                                         _sz, _dp, _vp]),
+    "mvr_pair_moments2_from_corr": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _sz, _dp,
+                                              C.POINTER(PairMoments2)]),
     "mvr_umeyama_from_moments": (C.c_int, [C.POINTER(PairMoments), _fp, _dp]),
     "mvr_moments_from_moments2": (C.c_int, [C.POINTER(PairMoments2), C.POINTER(PairMoments)]),
     "mvr_icp_align": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), _fp,
@@ -361,6 +363,15 @@ class Context:
         qc = (1 << 62) if q_count is None else int(q_count)
         _chk(_lib.mvr_pair_moments2_dev(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
                                         int(q_begin), qc, _p(o, C.c_double), _vp(dev_ptr)), self._h)
+
+    def pair_moments2_from_corr(self, s, t, query, match, origin) -> PairMoments2:
+        q = np.ascontiguousarray(query, np.int32)
+        m = np.ascontiguousarray(match, np.int32)
+        o = np.ascontiguousarray(origin, np.float64)
+        out = PairMoments2()
+        _chk(_lib.mvr_pair_moments2_from_corr(self._h, s, t, _p(q, C.c_int32), _p(m, C.c_int32), len(q),
+                                              _p(o, C.c_double), C.byref(out)), self._h)
+        return out
 
     def icp_align(self, src, tgt, out, params: IcpParams):
         """Returns (T (4,4) float32, stats dict, rc); rc is OK or E_NOCORR."""

@@ -484,6 +484,31 @@ API int mvr_pair_moments2(mvr_ctx *ctx, int ss, int ts, double max_dist, int rec
   return MVR_OK;
 }
 
+API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t *query, const int32_t *match,
+                                    size_t m, const double origin[3], mvr_pair_moments2_t *out)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !origin || !out || (m && (!query || !match))) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const Cloud &s = c->slots[ss], &t = c->slots[ts];
+  std::memset(out, 0, sizeof *out);
+  for (int k = 0; k < 3; ++k) out->origin[k] = origin[k];
+  if (s.n == 0) return MVR_OK;
+  std::vector<int32_t> hm(s.n, -1);
+  for (size_t k = 0; k < m; ++k) {
+    if (query[k] < 0 || (size_t)query[k] >= s.n || match[k] < 0 || (size_t)match[k] >= t.n)
+      return set_error(c, MVR_E_ARG, "correspondence index out of range");
+    hm[query[k]] = match[k];
+  }
+  if (int rc = ensure(c, c->match, c->match_cap, s.n)) return rc;
+  MVR_HIP_TRY(c, hipMemcpyAsync(c->match, hm.data(), s.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));     // hm goes out of scope
+  if (int rc = launch_moments2(c, s.pts, t.pts, c->match, 0, s.n, origin, c->moments)) return rc;
+  if (int rc = read_moments(c, 32)) return rc;
+  std::memcpy(out, c->h_moments, sizeof *out);
+  return MVR_OK;
+}
+
 API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params *p, float T_out[16],
                       mvr_icp_stats *st)
 {

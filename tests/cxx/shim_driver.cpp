@@ -1,0 +1,135 @@
+// tests/cxx/shim_driver.cpp -- drives the C++ drop-in shim (include/mvr/*.hpp)
+// exactly the way the reference's Registrator drives PCL, on synthetic
+// turntable scans, and prints the results as JSON for tests/test_gpu_shim.py
+// to compare with the oracle-based restatement of the same driver loops.
+//
+// usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
+//   mode: seq | lum | auto | err | api
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#define MVR_ALIAS_PCL
+#include "mvr/registrator.hpp"
+
+using namespace mvr;
+
+static void print_pose(const RowMatrixd &m, bool last)
+{
+  // column-vector 4x4, row by row (T(r,c) = m(c,r)) -- the transformation.txt order (point_cloud.cpp:336-343)
+  std::printf("[");
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) std::printf("%.17g%s", m(c, r), (r == 3 && c == 3) ? "" : ",");
+  std::printf("]%s", last ? "" : ",");
+}
+
+static void print_mat4f(const Matrix4f &T)
+{
+  std::printf("[");
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) std::printf("%.9g%s", T(r, c), (r == 3 && c == 3) ? "" : ",");
+  std::printf("]");
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 7) { std::fprintf(stderr, "usage: %s mode views points max_dist repeat config\n", argv[0]); return 2; }
+  const std::string mode = argv[1];
+  const int V = std::atoi(argv[2]);
+  const size_t N = (size_t)std::atol(argv[3]);
+  const double max_d = std::atof(argv[4]);
+  const int repeat = std::atoi(argv[5]);
+  const int config = std::atoi(argv[6]);
+  try {
+    mvr_synth_params sp;
+    mvr_synth_default(&sp, V, config);
+    TurntableModel model;
+    model.views.resize(V);
+    for (int v = 0; v < V; ++v) {
+      model.views[v].view = v;
+      model.views[v].points.resize(N);
+      if (mvr_synth_view(&sp, v, N, model.views[v].points.points[0].data, nullptr) != MVR_OK) return 3;
+    }
+    Registrator reg(&model);
+    double piv[3], ax[3];
+    mvr_synth_prior(&sp, piv, ax);
+    reg.setPivotPoint(piv[0], piv[1], piv[2]);
+    reg.setAxisNormal(ax[0], ax[1], ax[2]);
+
+    std::printf("{\"mode\":\"%s\",", mode.c_str());
+    if (mode == "seq") {
+      reg.registrationICP(1000, max_d, 0, repeat);
+    } else if (mode == "lum") {
+      reg.registrationLUM(10, 16 * repeat, max_d, 0);
+      std::printf("\"lum_ncorr\":[");
+      for (size_t i = 0; i < reg.lum_ncorr.size(); ++i) std::printf("%d%s", reg.lum_ncorr[i], i + 1 < reg.lum_ncorr.size() ? "," : "");
+      std::printf("],");
+    } else if (mode == "auto") {
+      reg.automaticRegistration(0, 1000, repeat, max_d, 50.0);
+    } else if (mode == "err") {
+      auto pairs = reg.computeError(0, max_d);
+      std::printf("\"pairs\":[");
+      for (size_t i = 0; i < pairs.size(); ++i) {
+        double s = 0; for (const Correspondence &c : *pairs[i].second) s += c.distance;
+        std::printf("[%d,%d,%zu,%.17g]%s", pairs[i].first.first, pairs[i].first.second, pairs[i].second->size(), s, i + 1 < pairs.size() ? "," : "");
+      }
+      std::printf("],");
+    } else if (mode == "api") {
+      // the PCL-named API surface, through the pcl:: alias, incl. the error paths
+      pcl::PointCloud<pcl::PointXYZ>::Ptr a(new pcl::PointCloud<pcl::PointXYZ>), b(new pcl::PointCloud<pcl::PointXYZ>);
+      model.views[0].getTransformedPoints(*a);
+      model.views[1].initRotation(reg);
+      model.views[1].getTransformedPoints(*b);
+      pcl::IterativeClosestPoint<pcl::PointXYZ, pcl::PointXYZ> icp;
+      icp.setUseReciprocalCorrespondences(true);
+      icp.setMaxCorrespondenceDistance(max_d);
+      icp.setMaximumIterations(7);
+      icp.setTransformationEpsilon(0);
+      icp.setEuclideanFitnessEpsilon(-1e300);
+      icp.setInputSource(b);
+      icp.setInputTarget(a);
+      icp.align(*b);                                   // aliased output (registrator.cpp:920)
+      std::printf("\"iters\":%d,\"converged\":%d,\"T\":", icp.getStats().iterations, (int)icp.hasConverged());
+      print_mat4f(icp.getFinalTransformation());
+      std::printf(",\"fitness_after_alias\":%.17g,", icp.getFitnessScore());
+      // far-away target: not enough correspondences -> no throw, hasConverged() false
+      pcl::PointCloud<pcl::PointXYZ>::Ptr far(new pcl::PointCloud<pcl::PointXYZ>(*a));
+      for (auto &p : far->points) p.x += 1e4f;
+      icp.setMaxCorrespondenceDistance(1.0);
+      icp.setInputTarget(far);
+      pcl::PointCloud<pcl::PointXYZ> out;
+      icp.align(out);
+      std::printf("\"nocorr_converged\":%d,\"nocorr_identity\":%d,", (int)icp.hasConverged(), (int)icp.getFinalTransformation().isIdentity());
+      pcl::registration::CorrespondenceEstimation<pcl::PointXYZ, pcl::PointXYZ, float> ce;
+      ce.setInputSource(b); ce.setInputTarget(a);
+      pcl::Correspondences one, rec;
+      ce.determineCorrespondences(one, max_d);
+      ce.determineReciprocalCorrespondences(rec, max_d);
+      std::printf("\"n_oneway\":%zu,\"n_recip\":%zu,", one.size(), rec.size());
+    } else {
+      std::fprintf(stderr, "unknown mode\n");
+      return 2;
+    }
+    std::printf("\"log\":[");
+    for (size_t i = 0; i < reg.log.size(); ++i) {
+      const AlignLog &e = reg.log[i];
+      std::printf("{\"view\":%d,\"n_corr\":%d,\"mse\":%.17g,\"iterations\":%d,\"fitness\":%s,\"T\":", e.view, e.n_corr, e.mse, e.iterations,
+                  e.has_fitness ? std::to_string(e.fitness).c_str() : "null");
+      print_mat4f(e.T);
+      std::printf("}%s", i + 1 < reg.log.size() ? "," : "");
+    }
+    std::printf("],");
+    if (mode == "seq" || mode == "auto" || mode == "lum") {
+      for (int v = 0; v < V; ++v) model.views[v].setRegisterState(true);
+      reg.refineAxis(0);
+      std::printf("\"refined_pivot\":[%.9g,%.9g,%.9g],\"refined_axis\":[%.9g,%.9g,%.9g],", reg.getPivotPoint()[0], reg.getPivotPoint()[1],
+                  reg.getPivotPoint()[2], reg.getAxisNormal()[0], reg.getAxisNormal()[1], reg.getAxisNormal()[2]);
+    }
+    std::printf("\"poses\":[");
+    for (int v = 0; v < V; ++v) print_pose(model.views[v].getMatrix(), v == V - 1);
+    std::printf("]}\n");
+  } catch (const mvr::Error &e) {
+    std::fprintf(stderr, "mvr::Error %d: %s\n", e.status, e.what());
+    return 1;
+  }
+  return 0;
+}

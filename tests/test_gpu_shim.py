@@ -1,0 +1,126 @@
+"""GPU tests of the C++ drop-in shim (include/mvr/*.hpp): the reference's own
+driver loops (Registrator::registrationICP / registrationLUM / computeError /
+automaticRegistration, mvr/src/registrator.cpp) compiled against the PCL-named
+shim classes, run on the GPU, and compared with the same loops restated on the
+CPU oracle (tests/ref_driver.py) on identical synthetic scans."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ref_driver
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, TRANS_TOL = 1e-5, 1e-4
+
+
+@pytest.fixture(scope="module")
+def driver(built):
+    exe = built.build_cxx_tests()
+    assert exe and os.path.exists(exe)
+    return exe
+
+
+def run(exe, mode, V, N, max_d, repeat, config):
+    r = subprocess.run([exe, mode, str(V), str(N), str(max_d), str(repeat), str(config)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout), r.stderr
+
+
+def scene(mvr, orc, V, N, config):
+    sp = mvr.synth_params(V, config)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    # the driver stores pivot/axis as osg::Vec3 (float)
+    piv, ax = piv.astype(np.float32).astype(np.float64), ax.astype(np.float32).astype(np.float64)
+    return sp, scans, ref_driver.init_poses(orc, V, piv, ax)
+
+
+def assert_poses(got, exp, rot=ROT_TOL, trans=TRANS_TOL):
+    for v, (g, e) in enumerate(zip(got, exp)):
+        g = np.array(g).reshape(4, 4)
+        assert np.abs(g[:3, :3] - e[:3, :3]).max() <= rot, (v, np.abs(g[:3, :3] - e[:3, :3]).max())
+        assert np.abs(g[:3, 3] - e[:3, 3]).max() <= trans, (v, np.abs(g[:3, 3] - e[:3, 3]).max())
+
+
+def test_registration_icp_driver(driver, mvr, orc):
+    """registrator.cpp:517-588 through the shim == the oracle-driven restatement."""
+    V, N, max_d, repeat = 12, 3000, 8.0, 2
+    out, _ = run(driver, "seq", V, N, max_d, repeat, 3)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 3)
+    poses, log = ref_driver.sequential_icp(orc, scans, poses0, orc.make_params(max_dist=max_d, max_iter=1000), V, repeat=repeat)
+    assert [e["view"] for e in out["log"]] == [e["view"] for e in log] == ref_driver.view_order(V) * repeat
+    for g, e in zip(out["log"], log):
+        assert g["iterations"] == e["iterations"] == 1
+        assert abs(g["n_corr"] - e["n_corr"]) <= 2 and abs(g["mse"] - e["mse"]) < 1e-4
+        T = np.array(g["T"]).reshape(4, 4)
+        assert np.abs(T[:3, :3] - e["T"][:3, :3]).max() <= ROT_TOL and np.abs(T[:3, 3] - e["T"][:3, 3]).max() <= TRANS_TOL
+    fit = [e for e in log if "fitness" in e]
+    gfit = [g["fitness"] for g in out["log"] if g["fitness"] is not None]
+    assert len(gfit) == len(fit) == repeat and np.allclose(gfit, [e["fitness"] for e in fit], atol=1e-4)
+    assert_poses(out["poses"], poses, rot=5e-5, trans=5e-4)     # 22 chained aligns
+    # refineAxis (registrator.cpp:402-455) moves the mis-calibrated prior towards the true axis
+    true_ax = np.array(sp.axis) / np.linalg.norm(sp.axis)
+    prior_ax = mvr.synth_prior(sp)[1]
+    ref_ax = np.array(out["refined_axis"])
+    ang = lambda a: np.degrees(np.arccos(min(1.0, abs(a @ true_ax))))
+    assert ang(ref_ax) < ang(prior_ax)
+
+
+def test_registration_lum_driver(driver, mvr, orc):
+    """registrator.cpp:611-664 through the shim == oracle LUM pass."""
+    V, N, max_d = 12, 3000, 8.0
+    out, _ = run(driver, "lum", V, N, max_d, 1, 3)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 3)
+    new, P, corrs, its = ref_driver.lum_pass(orc, scans, poses0, max_d, 16)
+    assert out["lum_ncorr"] == [len(c) for c in corrs]
+    assert_poses(out["poses"], new, rot=2e-5, trans=2e-3)
+
+
+def test_compute_error_pairs(driver, mvr, orc):
+    """registrator.cpp:466-515: ring pairs + (0, V-1), reciprocal correspondences."""
+    V, N, max_d = 12, 2500, 6.0
+    out, _ = run(driver, "err", V, N, max_d, 1, 5)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 5)
+    clouds = [orc.transform_f64(poses0[v], scans[v]) for v in range(V)]
+    exp_pairs = [(i, i + 1) for i in range(V - 1)] + [(0, V - 1)]
+    assert [(p[0], p[1]) for p in out["pairs"]] == exp_pairs
+    for (s, t), p in zip(exp_pairs, out["pairs"]):
+        c = orc.correspondences(clouds[s], clouds[t], max_d)
+        assert p[2] == len(c) and abs(p[3] - float(c["dist2"].astype(np.float64).sum())) < 1e-6 * max(1.0, p[3])
+
+
+def test_automatic_registration_driver(driver, mvr, orc):
+    """The intent of automaticRegistration (:746-842): incremental add-a-view
+    with `repeat` aliased in-place aligns per view."""
+    V, N, max_d, repeat = 6, 3000, 8.0, 3
+    out, _ = run(driver, "auto", V, N, max_d, repeat, 6)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 6)
+    poses = [p.copy() for p in poses0]
+    target = orc.transform_f64(poses[0], scans[0])
+    params = orc.make_params(max_dist=max_d, max_iter=1000, teps=0.0, feps=50.0)    # transformation eps never set (App. C.3)
+    k = 0
+    for v in range(1, V):
+        source = orc.transform_f64(poses[v], scans[v])
+        for _ in range(repeat):
+            source, T, st, rc = orc.icp_align(source, target, params)              # aliased: source advances in place
+            poses[v] = orc.mat4d_mul(T.astype(np.float64), poses[v])
+            g = out["log"][k]; k += 1
+            assert g["view"] == v and abs(g["n_corr"] - st["n_corr"]) <= 2
+        target = np.concatenate([target, source])
+    assert k == len(out["log"])
+    assert_poses(out["poses"], poses, rot=5e-5, trans=5e-4)
+
+
+def test_pcl_named_api_surface(driver):
+    out, err = run(driver, "api", 12, 3000, 8.0, 1, 3)
+    assert out["iters"] == 7 and out["converged"] == 1
+    assert out["nocorr_converged"] == 0 and out["nocorr_identity"] == 1
+    assert "Not enough correspondences" in err
+    assert out["n_oneway"] > out["n_recip"] > 100
+    assert np.isfinite(out["fitness_after_alias"])
