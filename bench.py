@@ -37,18 +37,6 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def split_queries(n_edges, ns, world, rank):
-    """Contiguous, even split of the n_edges*ns source queries -> [(edge, q_begin, q_count)]."""
-    total = n_edges * ns
-    lo, hi = total * rank // world, total * (rank + 1) // world
-    segs = []
-    for e in range(n_edges):
-        a, b = max(lo, e * ns), min(hi, (e + 1) * ns)
-        if b > a:
-            segs.append((e, a - e * ns, b - a))
-    return segs
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,10 +74,7 @@ def main():
     piv, ax = mvr.synth_prior(sp)
     poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
     origin = np.array(sp.pivot)
-    edges = [(i, (i + 1) % V) for i in range(V)]
-    segs = split_queries(V, N, world, rank)
-    if rank == 0:
-        log("[bench] synth %dx%d in %.2fs; rank0 segments %s" % (V, N, time.time() - t0, segs))
+    ring = importlib.import_module(g.PKG + ".ring")
 
     # one explicit (non-default) HIP stream carries everything in order: the
     # library's kernels, torch's zero_/D2H copies and the RCCL all-reduce
@@ -97,52 +82,24 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream, "need a non-default stream handle"
-    ctx = mvr.Context(local_rank, stream=stream)
-    table = torch.zeros((V, 32), dtype=torch.float64, device="cuda")
-    # raw scans live in slots V..2V-1, their posed copies (what LUM sees) in 0..V-1
     h2d0 = time.time()
-    for v in range(V):
-        ctx.upload(V + v, scans[v])
+    backend = ring.HipBackend(scans, device=local_rank, stream=stream, fma=bool(args.fma))
+    ctx = backend.ctx
     ctx.sync()
     h2d = time.time() - h2d0
-    poses = [p.copy() for p in poses0]
+    reg = ring.RingLUM(backend, V, [N] * V, args.max_dist, origin, rank=rank, world=world,
+                       all_reduce=(dist.all_reduce if world > 1 else None))
+    if rank == 0:
+        log("[bench] synth %dx%d in %.2fs; rank0 segments %s" % (V, N, time.time() - t0, reg.segments))
+    state = {"poses": [p.copy() for p in poses0]}
 
     def reset():
-        for v in range(V):
-            poses[v] = poses0[v].copy()
-            ctx.transform(v, V + v, poses[v])   # getTransformedPoints with the turntable prior
+        state["poses"] = [p.copy() for p in poses0]
         ctx.sync()
 
-    stats = dict(ncorr=0.0, mse=0.0)
-
     def step():
-        table.zero_()
-        for e, qb, qn in segs:
-            s, t = edges[e]
-            ctx.pair_moments2_dev(s, t, args.max_dist, origin, table[e].data_ptr(), reciprocal=True,
-                                  fma=bool(args.fma), q_begin=qb, q_count=qn)
-        if world > 1:
-            dist.all_reduce(table)                     # RCCL: per-pair sums/residuals -> every rank
-        rows = table.cpu().numpy()                      # sync point: 3 KB D2H
-        m2s = []
-        for e in range(V):
-            r = rows[e].copy(); r[1:4] = origin         # origin column is a constant, not a sum
-            m2s.append(mvr.moments2_from_row(r))
-        # per-pair rigid solve (host 3x3 SVD) + residual, then the global LUM step
-        ncorr, wmse = 0.0, 0.0
-        for m2 in m2s:
-            pm = mvr.moments_from_moments2(m2)
-            mvr.umeyama_from_moments(pm)
-            ncorr += pm.n; wmse += pm.n * pm.mse
-        rc, P, its = mvr.lum_compute(V, edges, m2s, max_iterations=16)
-        if rc != 0:
-            raise RuntimeError("LUM solve failed: %d" % rc)
-        for v in range(1, V):
-            # registrator.cpp:656-662: pose_v <- LUM_v (an Eigen::Affine3f) * pose_v, then re-pose the raw scan
-            L = mvr.pose_to_mat4(P[v]).astype(np.float32).astype(np.float64)
-            poses[v] = mvr.mat4d_mul(L, poses[v])
-            ctx.transform(v, V + v, poses[v])
-        stats["ncorr"], stats["mse"] = ncorr, (wmse / ncorr if ncorr else 0.0)
+        # one registrationLUM outer pass over all scan pairs (ring.RingLUM.step)
+        state["poses"] = reg.step(state["poses"])
 
     def barrier():
         if world > 1:
@@ -185,7 +142,7 @@ def main():
                    "views": V, "points_per_scan": N, "max_distance": args.max_dist, "pairs": V,
                    "dist_mode": "fma" if args.fma else "rounded-per-op (spec)",
                    "sharding": "source queries of the %d ring pairs split evenly over %d rank(s)" % (V, world)},
-        "accepted_correspondences_per_step": stats["ncorr"], "mse": stats["mse"],
+        "accepted_correspondences_per_step": reg.last["n_corr"], "mse": reg.last["mse"],
         "device": name, "n_cu": n_cu,
     }
     if nn_launches:

@@ -26,6 +26,29 @@ if not os.path.exists(LIB_PATH):
         "libmvr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
 
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, the name libmvr_hip.so needs) but
+    ask for it as "libamdhip64.so"; if libmvr_hip.so were loaded first against
+    /opt/rocm, a later `import torch` would bring a SECOND runtime into the
+    process and find no GPU.  Loading torch's copy first makes both import
+    orders resolve to the same runtime.  MVR_HIP_RUNTIME=system skips this."""
+    if os.environ.get("MVR_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+_share_hip_runtime_with_torch()
 _lib = C.CDLL(LIB_PATH)
 
 MAX_SLOTS = 64

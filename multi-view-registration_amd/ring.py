@@ -1,0 +1,144 @@
+"""ring.py -- the global multi-view step over all scan pairs of the view graph,
+sharded over one process per GPU.
+
+One step = one outer pass of Registrator::registrationLUM
+(mvr/src/registrator.cpp:625-664):
+    posed clouds  <- getTransformedPoints(pose_v)              (K1, GPU)
+    per ring edge (i -> i+1): reciprocal correspondences        (K2/K3, GPU)
+                  + raw second moments of the accepted pairs    (K8, GPU)
+    [world > 1]   one all-reduce (SUM) of the V x 32 f64 edge table (RCCL over xGMI)
+    host          per-pair Umeyama + residual, LUM::compute from the moments
+    pose_v        <- LUM_v * pose_v                              (:656-662)
+
+Sharding: the V*Ns source queries of all edges are split into
+`world` contiguous, equal ranges; every rank holds all scans, so no point ever
+crosses the fabric -- only the 3 KB table does.  Each rank then solves the same
+small system redundantly (no broadcast needed).
+
+The compute backend is injected: `HipBackend` (the product; fails loudly without
+a GPU) or any object with the same three methods -- the world_size-2 gloo tests
+plug the CPU oracle in from tests/, the product never does.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import (Context, lum_compute, mat4d_mul, moments2_from_row, moments_from_moments2,
+               pose_to_mat4, umeyama_from_moments)
+
+ROW = 32   # doubles per edge row: {n, origin[3], sp[3], sq[3], spp[6], sqq[6], spq[9], 0}
+
+
+def ring_edges(n_views):
+    """registrator.cpp:640-643: source i, target (i+1) mod V."""
+    return [(i, (i + 1) % n_views) for i in range(n_views)]
+
+
+def split_queries(sizes, world, rank):
+    """Even, contiguous split of the concatenated source queries of all edges.
+    sizes[e] = number of source points of edge e.  -> [(edge, q_begin, q_count)]"""
+    total = int(sum(sizes))
+    lo, hi = total * rank // world, total * (rank + 1) // world
+    segs, base = [], 0
+    for e, n in enumerate(sizes):
+        a, b = max(lo, base), min(hi, base + n)
+        if b > a:
+            segs.append((e, a - base, b - a))
+        base += n
+    return segs
+
+
+class HipBackend:
+    """Raw scans in slots V..2V-1, posed clouds in slots 0..V-1 of one mvr_ctx;
+    the edge table is a torch CUDA tensor so that torch.distributed (RCCL) can
+    all-reduce it in place."""
+
+    def __init__(self, scans, device=0, stream=None, fma=False):
+        import torch
+        self.torch = torch
+        self.V = len(scans)
+        # ONE explicit HIP stream orders the library's kernels, torch's fills /
+        # copies and the collective.  `stream` = raw hipStream_t of a torch
+        # stream that is current in the caller; otherwise a private torch stream.
+        self._tstream = None
+        if not stream:
+            self._tstream = torch.cuda.Stream(device=device)
+            stream = self._tstream.cuda_stream
+        self.ctx = Context(device, stream=stream)
+        for v, s in enumerate(scans):
+            self.ctx.upload(self.V + v, s)
+        self.sizes = [len(s) for s in scans]
+        with self._on_stream():
+            self.table = torch.zeros((self.V, ROW), dtype=torch.float64, device=torch.device("cuda", device))
+        self.fma = fma
+
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self._tstream) if self._tstream is not None else contextlib.nullcontext()
+
+    def pose_clouds(self, poses, views=None):
+        for v in (range(self.V) if views is None else views):
+            self.ctx.transform(v, self.V + v, poses[v])
+
+    def edge_rows(self, segments, edges, max_dist, origin):
+        """Fill this rank's rows (partial sums for split edges); returns the table."""
+        with self._on_stream():
+            self.table.zero_()
+        for e, qb, qn in segments:
+            s, t = edges[e]
+            self.ctx.pair_moments2_dev(s, t, max_dist, origin, self.table[e].data_ptr(), reciprocal=True,
+                                       fma=self.fma, q_begin=qb, q_count=qn)
+        return self.table
+
+    def to_host(self, table):
+        with self._on_stream():
+            return table.cpu().numpy()
+
+    def close(self):
+        self.ctx.close()
+
+
+class RingLUM:
+    def __init__(self, backend, n_views, sizes, max_dist, origin, rank=0, world=1, all_reduce=None,
+                 lum_iterations=16):
+        self.b, self.V = backend, n_views
+        self.edges = ring_edges(n_views)
+        self.max_dist, self.origin = float(max_dist), np.asarray(origin, np.float64)
+        self.rank, self.world, self.all_reduce = rank, world, all_reduce
+        if world > 1 and all_reduce is None:
+            raise ValueError("world > 1 needs an all_reduce callable")
+        self.lum_iterations = lum_iterations
+        # edge e's queries are the points of its SOURCE view
+        self.segments = split_queries([sizes[s] for s, _ in self.edges], world, rank)
+        self.last = {}
+
+    def step(self, poses):
+        """poses: list of V (4,4) float64 column-vector poses -> new list."""
+        b = self.b
+        b.pose_clouds(poses)
+        table = b.edge_rows(self.segments, self.edges, self.max_dist, self.origin)
+        if self.world > 1:
+            self.all_reduce(table)            # per-pair sums/residuals of all ranks -> every rank
+        rows = b.to_host(table)
+        m2s = []
+        for e in range(len(self.edges)):
+            r = np.array(rows[e], np.float64)
+            r[1:4] = self.origin              # a constant, not a sum
+            m2s.append(moments2_from_row(r))
+        pair_T, pair_n, pair_mse = [], [], []
+        for m2 in m2s:                        # per-pair rigid solve: host 3x3 SVD on the moments
+            pm = moments_from_moments2(m2)
+            T, _ = umeyama_from_moments(pm)
+            pair_T.append(T); pair_n.append(pm.n); pair_mse.append(pm.mse)
+        rc, P, its = lum_compute(self.V, self.edges, m2s, max_iterations=self.lum_iterations)
+        if rc != 0:
+            raise RuntimeError("LUM solve failed with status %d" % rc)
+        new = [poses[0].copy()]
+        for v in range(1, self.V):
+            # lum.getTransformation(i) is an Eigen::Affine3f before it meets the f64 pose
+            L = pose_to_mat4(P[v]).astype(np.float32).astype(np.float64)
+            new.append(mat4d_mul(L, poses[v]))
+        n = float(sum(pair_n))
+        self.last = dict(pair_T=pair_T, pair_n=pair_n, pair_mse=pair_mse, lum_pose=P, lum_iterations=its,
+                         n_corr=n, mse=(sum(a * b for a, b in zip(pair_n, pair_mse)) / n) if n else 0.0)
+        return new
