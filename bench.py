@@ -181,7 +181,7 @@ def main():
         clouds = [orc.transform_f64(poses0[v], scans[v]) for v in range(V)]
         nq, passes = 0, 0
         while time.perf_counter() - t0 < 10.0:            # bounded sample: >= 10 s, whole ring passes
-            for s, t in edges:
+            for s, t in reg.edges:
                 c = orc.correspondences(clouds[s], clouds[t], args.max_dist, reciprocal=True, fma=bool(args.fma), kdtree=True)
                 orc.umeyama(clouds[s], clouds[t], c)
                 nq += len(clouds[s])

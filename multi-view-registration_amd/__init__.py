@@ -140,6 +140,7 @@ SIGNATURES = {
     "mvr_axis_rotation": (None, [_dp, _dp, C.c_double, _dp]),
     "mvr_mat4d_mul": (None, [_dp, _dp, _dp]),
     "mvr_mat4f_mul": (None, [_fp, _fp, _fp]),
+    "mvr_ctx_tune": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mvr_prof_enable": (C.c_int, [_vp, C.c_int]),
     "mvr_prof_reset": (C.c_int, [_vp]),
     "mvr_prof_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), _dp, _dp]),
@@ -421,6 +422,11 @@ class Context:
         ncu, mhz = C.c_int(), C.c_int()
         _chk(_lib.mvr_device_info(self._h, name, 64, C.byref(ncu), C.byref(mhz)), self._h)
         return name.value.decode(), ncu.value, mhz.value
+
+    def tune(self, **kw):
+        """NN launch knobs (nn_q, nn_sub, nn_blocks_per_cu); results do not depend on them."""
+        for k, v in kw.items():
+            _chk(_lib.mvr_ctx_tune(self._h, k.encode(), int(v)), self._h)
 
     def prof_enable(self, on=True):
         _chk(_lib.mvr_prof_enable(self._h, int(on)), self._h)

@@ -600,6 +600,17 @@ API int mvr_fitness(mvr_ctx *ctx, int is, int ts, const float T[16], double max_
 
 // ----------------------------------------------------------- instrumentation
 
+API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
+{
+  if (!ctx || !key) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (!std::strcmp(key, "nn_q")) c->nn_q = value;
+  else if (!std::strcmp(key, "nn_sub")) c->nn_sub = value;
+  else if (!std::strcmp(key, "nn_blocks_per_cu")) c->nn_blocks_per_cu = value;
+  else return MVR_E_ARG;
+  return MVR_OK;
+}
+
 API int mvr_prof_enable(mvr_ctx *ctx, int on)
 {
   if (!ctx) return MVR_E_ARG;

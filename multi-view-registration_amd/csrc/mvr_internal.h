@@ -33,10 +33,9 @@ constexpr nnkey_t kKeyInit = ~0ull;
 
 // brute-force NN tiling (see mvr_nn.hip)
 constexpr int kNNThreads = 256;   // 4 waves
-constexpr int kNNQ = 4;           // queries held in registers per lane
 constexpr int kNNTile = 1024;     // target points per LDS tile (16 KB)
-constexpr int kNNSub = 32;        // sub-tile over which only min(d2) is tracked
-constexpr int kNNQB = kNNThreads * kNNQ;
+// Q (queries held in registers per lane) and SUB (sub-tile over which only
+// min(d2) is tracked) are template parameters, chosen per ctx (nn_q, nn_sub).
 
 // work = `work` unless `h_count` is set: then work = *h_count * per_count (the
 // reverse NN pass, whose query count is only known on the device)
@@ -61,6 +60,8 @@ struct Ctx {
   double *partials = nullptr; size_t partials_cap = 0;
   double *moments = nullptr;                          // device: 64 doubles
   double *h_moments = nullptr;                        // pinned host: 64 doubles
+  // launch configuration of the NN kernel (mvr_ctx_tune)
+  int nn_q = 8, nn_sub = 32, nn_blocks_per_cu = 2;
   // instrumentation
   bool prof = false;
   std::vector<ProfRec> recs;

@@ -46,21 +46,32 @@ __device__ __forceinline__ void block_partials(const double (&acc)[K], double *_
   }
 }
 
-// fixed-order sum of `rows` partial rows of K doubles (one block, K <= 64)
+// fixed-order sum of `rows` partial rows of K doubles (one block, K <= 32).
+// Thread (g, k) = (tid / 32, tid % 32) adds rows g, g+8, ... of column k, so a
+// row is read as one contiguous run of K doubles; the 8 row groups are then
+// added in a fixed order -> bitwise reproducible.
 template <int K>
 __device__ __forceinline__ void sum_rows(const double *__restrict__ partials, int rows, double (&out)[K],
-                                         double *lds /* [K] */)
+                                         double * /*unused*/)
 {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = wave; k < K; k += kRT / 64) {
-    double s = 0.0;
-    for (int r = lane; r < rows; r += 64) s += partials[(size_t)r * K + k];
-    s = wave_sum(s);
-    if (lane == 0) lds[k] = s;
+  static_assert(K <= 32, "sum_rows: K <= 32");
+  __shared__ double grp[kRT / 32][32];
+  __shared__ double tot[32];
+  const int g = threadIdx.x >> 5, k = threadIdx.x & 31;
+  double s = 0.0;
+  if (k < K)
+    for (int r = g; r < rows; r += kRT / 32) s += partials[(size_t)r * K + k];
+  grp[g][k] = s;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t = grp[0][threadIdx.x];
+#pragma unroll
+    for (int gg = 1; gg < kRT / 32; ++gg) t += grp[gg][threadIdx.x];
+    tot[threadIdx.x] = t;
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < K; ++k) out[k] = lds[k];
+  for (int kk = 0; kk < K; ++kk) out[kk] = tot[kk];
 }
 
 // ---------------------------------------------------------------- K1 transforms
@@ -130,14 +141,23 @@ __global__ void mark_kernel(const nnkey_t *__restrict__ keys, size_t q_begin, si
                             uint32_t *__restrict__ slot, uint32_t *__restrict__ list, uint32_t *__restrict__ count)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= q_count) return;
-  const nnkey_t key = keys[q_begin + k];
-  const uint32_t j = (uint32_t)key;
-  if (j == kNone) return;
-  const float d2 = __uint_as_float((uint32_t)(key >> 32));
-  if ((double)d2 > max2) return;
-  if (atomicCAS(&slot[j], kNone, kMarked) == kNone) {
-    const uint32_t pos = atomicAdd(count, 1u);
+  uint32_t j = kNone;
+  bool win = false;
+  if (k < q_count) {
+    const nnkey_t key = keys[q_begin + k];
+    j = (uint32_t)key;
+    const float d2 = __uint_as_float((uint32_t)(key >> 32));
+    if (j != kNone && !((double)d2 > max2)) win = (atomicCAS(&slot[j], kNone, kMarked) == kNone);
+  }
+  // one counter add per wave: winners take consecutive list positions
+  const unsigned long long mask = __ballot(win);
+  if (mask == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(count, (uint32_t)__popcll(mask));
+  base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+  if (win) {
+    const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     list[pos] = j;
     slot[j] = pos;      // read only by later kernels on the same stream
   }
@@ -301,7 +321,9 @@ __global__ void __launch_bounds__(kRT) fitness_final_kernel(const double *__rest
 inline int reduce_blocks(const Ctx *c, size_t n)
 {
   const size_t want = (n + kRT - 1) / kRT;
-  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu * 4);
+  // few partial rows keep the single-block final sum short; 2 blocks per CU
+  // already put > 8 MB of 16-byte loads in flight
+  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu * 2);
   return (int)std::max<size_t>(1, std::min(want, cap));
 }
 
