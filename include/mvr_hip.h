@@ -215,10 +215,15 @@ void   mvr_mat4f_mul(const float A[16], const float B[16], float C[16]);
  * family: 0 = nn (brute-force NN, fwd + reciprocal), 1 = reductions (K5/K6/K8),
  * 2 = transform/copy, 3 = glue (mark/compact/weights). */
 enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_COUNT = 4 };
-/* launch-configuration knobs of the NN kernel, for tuning runs: "nn_q" (queries
- * per lane: 2,4,6,8), "nn_sub" (min-tracking sub-tile: 16,32,64),
- * "nn_blocks_per_cu" (1..5).  Results do not depend on them. */
+/* knobs of the exact NN search.  "nn_mode": 1 (default) = spatially culled
+ * kernel, 0 = brute-force kernel (also MVR_NN_MODE in the environment);
+ * brute-force launch shape: "nn_q" (queries per lane: 2,4,6,8), "nn_sub"
+ * (min-tracking sub-tile: 16,32,64), "nn_blocks_per_cu" (1..5); culled kernel:
+ * "cull_q" (queries per lane: 1,2,4; 0 = auto).  Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
+/* diagnostics of the culled kernel: {pair evaluations of the last launch,
+ * running total, max tiles processed by one wave, max tiles tested by one wave} */
+int  mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset);
 int  mvr_prof_enable(mvr_ctx *ctx, int on);
 int  mvr_prof_reset(mvr_ctx *ctx);
 /* launches, total ms, point-pair evals (nn family) / bytes (others) */

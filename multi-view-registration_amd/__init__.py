@@ -141,6 +141,7 @@ SIGNATURES = {
     "mvr_mat4d_mul": (None, [_dp, _dp, _dp]),
     "mvr_mat4f_mul": (None, [_fp, _fp, _fp]),
     "mvr_ctx_tune": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "mvr_debug_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
     "mvr_prof_enable": (C.c_int, [_vp, C.c_int]),
     "mvr_prof_reset": (C.c_int, [_vp]),
     "mvr_prof_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), _dp, _dp]),
@@ -427,6 +428,11 @@ class Context:
         """NN launch knobs (nn_q, nn_sub, nn_blocks_per_cu); results do not depend on them."""
         for k, v in kw.items():
             _chk(_lib.mvr_ctx_tune(self._h, k.encode(), int(v)), self._h)
+
+    def debug_counters(self, reset=False):
+        out = (C.c_uint64 * 4)()
+        _chk(_lib.mvr_debug_counters(self._h, out, int(reset)), self._h)
+        return list(out)
 
     def prof_enable(self, on=True):
         _chk(_lib.mvr_prof_enable(self._h, int(on)), self._h)

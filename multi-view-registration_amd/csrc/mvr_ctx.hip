@@ -1,9 +1,9 @@
 // csrc/mvr_ctx.hip -- C-ABI entry points of libmvr_hip.so (include/mvr_hip.h):
 // context, device clouds, and the host side of the ICP iteration
 // (pcl::IterativeClosestPoint::align) driving the HIP
-// kernels of mvr_nn.hip / mvr_reduce.hip.  One host<->device round trip per
-// ICP iteration: the 17 f64 moments come back, the 3x3 SVD runs on the host,
-// the new 4x4 goes out as a kernel argument.
+// kernels of mvr_nn.hip / mvr_index.hip / mvr_reduce.hip.  One host<->device
+// round trip per ICP iteration: the 18 f64 moments come back, the 3x3 SVD runs
+// on the host, the new 4x4 goes out as a kernel argument.
 #include <algorithm>
 #include <chrono>
 #include <cfloat>
@@ -30,23 +30,25 @@ ProfScope::ProfScope(Ctx *ctx, int family, double w) : c(ctx), fam(family), work
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
   (void)hipEventRecord(a, c->stream);
 }
-ProfScope::ProfScope(Ctx *ctx, int family, const uint32_t *dev_count, double per_cnt, double upper_bound)
+ProfScope::ProfScope(Ctx *ctx, int family, const void *dev_count, int bytes, double per_cnt, double upper_bound, int shards)
     : ProfScope(ctx, family, upper_bound)
 {
-  d_count = dev_count; per_count = per_cnt;
+  d_count = dev_count; d_bytes = bytes; per_count = per_cnt; n_shards = shards;
 }
 ProfScope::~ProfScope()
 {
   if (!c->prof || !a || !b) return;
   (void)hipEventRecord(b, c->stream);
-  const uint32_t *hc = nullptr;
-  if (d_count && c->h_counts && c->h_counts_used < kProfCounts) {
-    uint32_t *slot = c->h_counts + c->h_counts_used;
-    if (hipMemcpyAsync(slot, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) == hipSuccess) {
-      hc = slot; ++c->h_counts_used;
+  const uint64_t *hc = nullptr;
+  const size_t need = n_shards > 0 ? kEvalRegion : 1;
+  if (d_count && c->h_counts && c->h_counts_used + need <= kProfCounts) {
+    uint64_t *slot = c->h_counts + c->h_counts_used;
+    *slot = 0;
+    if (hipMemcpyAsync(slot, d_count, (size_t)d_bytes, hipMemcpyDeviceToHost, c->stream) == hipSuccess) {
+      hc = slot; c->h_counts_used += need;
     }
   }
-  c->recs.push_back(ProfRec{fam, a, b, work, hc, per_count});
+  c->recs.push_back(ProfRec{fam, a, b, work, hc, n_shards, per_count});
 }
 
 namespace {
@@ -59,7 +61,13 @@ int prof_drain(Ctx *c)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       c->prof_launches[r.family] += 1; c->prof_ms[r.family] += ms;
-      c->prof_work[r.family] += r.h_count ? (double)*r.h_count * r.per_count : r.work;
+      if (r.h_count && r.n_shards > 0) {
+        double s = 0.0;
+        for (int k = 0; k < r.n_shards; ++k) s += (double)r.h_count[(size_t)k * kEvalStride];
+        c->prof_work[r.family] += s * r.per_count;
+      } else {
+        c->prof_work[r.family] += r.h_count ? (double)*r.h_count * r.per_count : r.work;
+      }
     }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
@@ -86,25 +94,62 @@ int cloud_reserve(Ctx *c, Cloud &cl, size_t cap, bool keep)
   return MVR_OK;
 }
 
-template <class T>
-int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
+void cloud_free(Cloud &cl)
 {
-  if (cap >= want) return MVR_OK;
-  if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; cap = 0; }
-  size_t ncap = want + want / 4 + 64;
-  MVR_HIP_TRY(c, hipMalloc(&p, ncap * sizeof(T)));
-  cap = ncap;
-  return MVR_OK;
+  if (cl.pts) (void)hipFree(cl.pts);
+  if (cl.sorted) (void)hipFree(cl.sorted);
+  if (cl.tlo) (void)hipFree(cl.tlo);
+  if (cl.thi) (void)hipFree(cl.thi);
+  cl.order.reset();
+  cl = Cloud();
 }
 
-// forward NN + (optional) reciprocal pass for source queries [qb, qb+qn).
-// Leaves keys[], slot[], rkeys[] ready for pass1.  Returns evals in *evals.
-int run_search(Ctx *c, const Cloud &src, const Cloud &tgt, size_t qb, size_t qn, double max_dist, bool reciprocal,
-               bool fma, double *evals)
+float cap_from_max2(double max2)
+{
+  // smallest float bound that still admits every float d2 with (double)d2 <= max2
+  if (!(max2 < (double)FLT_MAX)) return INFINITY;
+  float f = (float)max2;
+  if ((double)f < max2) f = std::nextafterf(f, INFINITY);
+  return f;
+}
+
+// forward NN + (optional) reciprocal pass for the source queries at positions
+// [qb, qb+qn) (positions in the source's Morton order in culled mode, original
+// indices in brute-force mode: either way the ranges [0,n) partition the
+// queries, and every per-pair sum is additive over such a partition).
+// Leaves keys[], slot[], rkeys[] ready for pass1.
+struct SearchPlan { const uint32_t *qperm = nullptr; const uint32_t *tinv = nullptr; };
+
+int run_search(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool reciprocal, bool fma,
+               double *evals, SearchPlan *plan)
 {
   const size_t ns = src.n, nt = tgt.n;
+  const double max2 = max_dist * max_dist;
+  const bool cull = c->nn_mode != 0;
+  *plan = SearchPlan();
   if (int rc = ensure(c, c->keys, c->keys_cap, ns)) return rc;
   if (int rc = ensure(c, c->match, c->match_cap, ns)) return rc;
+  if (cull && ns > 0 && nt > 0) {
+    if (int rc = ensure_index(c, src)) return rc;
+    if (int rc = ensure_index(c, tgt)) return rc;
+    plan->qperm = src.order->perm;
+    plan->tinv = tgt.order->inv;
+    // keys are written (not min-combined) by exactly one wave per query
+    if (int rc = launch_nn_cull(c, src, qb, qn, nullptr, nullptr, tgt, cap_from_max2(max2), fma, c->keys)) return rc;
+    if (reciprocal && qn > 0) {
+      const size_t nl = std::min(qn, nt);
+      if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
+      if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
+      if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
+      if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
+      if (int rc = launch_mark_sorted(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags, c->list, c->count,
+                                      c->slot)) return rc;
+      // reverse pass: queries = distinct matched targets (Morton order), searched in the WHOLE source
+      if (int rc = launch_nn_cull(c, tgt, 0, nl, c->list, c->count, src, cap_from_max2(max2), fma, c->rkeys)) return rc;
+    }
+    (void)evals;
+    return MVR_OK;
+  }
   if (int rc = launch_fill_u64(c, c->keys + qb, qn, kKeyInit)) return rc;
   if (int rc = launch_nn(c, src.pts, qb, qn, nullptr, nullptr, tgt.pts, nt, fma, c->keys)) return rc;
   if (evals) *evals += (double)qn * (double)nt;
@@ -115,7 +160,7 @@ int run_search(Ctx *c, const Cloud &src, const Cloud &tgt, size_t qb, size_t qn,
     if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
     MVR_HIP_TRY(c, hipMemsetAsync(c->slot, 0xFF, nt * sizeof(uint32_t), c->stream));
     MVR_HIP_TRY(c, hipMemsetAsync(c->count, 0, sizeof(uint32_t), c->stream));
-    if (int rc = launch_mark(c, c->keys, qb, qn, max_dist * max_dist, c->slot, c->list, c->count)) return rc;
+    if (int rc = launch_mark(c, c->keys, qb, qn, max2, c->slot, c->list, c->count)) return rc;
     if (int rc = launch_fill_u64(c, c->rkeys, nl, kKeyInit)) return rc;
     // reverse pass: queries = distinct matched targets, searched in the WHOLE source
     if (int rc = launch_nn(c, tgt.pts, 0, nl, c->list, c->count, src.pts, ns, fma, c->rkeys)) return rc;
@@ -175,17 +220,20 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return MVR_E_HIP; }
   c->n_cu = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; c->name = prop.gcnArchName;
+  if (const char *m = std::getenv("MVR_NN_MODE")) c->nn_mode = std::atoi(m);   // 0 brute force, 1 culled (default)
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MVR_E_HIP; }
     c->own_stream = true;
   }
-  if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->moments, 64 * sizeof(double)) != hipSuccess ||
+  if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->evals, 2 * kEvalRegion * sizeof(uint64_t)) != hipSuccess ||
+      hipMalloc(&c->bbox, 64) != hipSuccess || hipMalloc(&c->moments, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&c->h_moments, 64 * sizeof(double)) != hipSuccess ||
-      hipHostMalloc(&c->h_counts, kProfCounts * sizeof(uint32_t)) != hipSuccess) {
+      hipHostMalloc(&c->h_counts, kProfCounts * sizeof(uint64_t)) != hipSuccess) {
     mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(c));
     return MVR_E_HIP;
   }
+  (void)hipMemset(c->evals, 0, 2 * kEvalRegion * sizeof(uint64_t));
   *out = reinterpret_cast<mvr_ctx *>(c);
   return MVR_OK;
 }
@@ -199,15 +247,11 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-  for (auto &s : c->slots) if (s.pts) (void)hipFree(s.pts);
-  if (c->keys) (void)hipFree(c->keys);
-  if (c->rkeys) (void)hipFree(c->rkeys);
-  if (c->slot) (void)hipFree(c->slot);
-  if (c->list) (void)hipFree(c->list);
-  if (c->match) (void)hipFree(c->match);
-  if (c->count) (void)hipFree(c->count);
-  if (c->partials) (void)hipFree(c->partials);
-  if (c->moments) (void)hipFree(c->moments);
+  for (auto &s : c->slots) cloud_free(s);
+  c->orders.clear();
+  void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox};
+  for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -250,6 +294,7 @@ API int mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, siz
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   Cloud &cl = c->slots[slot];
   cl.n = 0;
+  new_point_set(c, cl);
   if (int rc = cloud_reserve(c, cl, n, false)) return rc;
   if (n) {
     if (stride == 16) {
@@ -305,7 +350,9 @@ API int mvr_cloud_size(mvr_ctx *ctx, int slot, size_t *n)
 API int mvr_cloud_clear(mvr_ctx *ctx, int slot)
 {
   if (!ctx || !slot_ok(slot)) return MVR_E_ARG;
-  CTX(ctx)->slots[slot].n = 0;
+  Ctx *c = CTX(ctx);
+  c->slots[slot].n = 0;
+  new_point_set(c, c->slots[slot]);
   return MVR_OK;
 }
 
@@ -323,6 +370,7 @@ API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
     MVR_HIP_TRY(c, hipMemcpyAsync(d.pts, s.pts, s.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
   }
   d.n = s.n;
+  inherit_point_set(d, s);
   return MVR_OK;
 }
 
@@ -338,6 +386,7 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
   if (add) {
     ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)add);
     MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    new_point_set(c, d);                      // a different point set: its order is rebuilt on next use
   }
   d.n += add;
   return MVR_OK;
@@ -352,6 +401,8 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
   if (int rc = launch_transform_f64(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
+  if (dst != src) inherit_point_set(c->slots[dst], c->slots[src]);
+  c->slots[dst].coords_valid = false;
   return MVR_OK;
 }
 
@@ -364,6 +415,8 @@ API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16
   if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
   if (int rc = launch_transform_f32(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
+  if (dst != src) inherit_point_set(c->slots[dst], c->slots[src]);
+  c->slots[dst].coords_valid = false;
   return MVR_OK;
 }
 
@@ -374,11 +427,17 @@ API int mvr_nn(mvr_ctx *ctx, int qs, int ts, int fma, uint32_t *idx, float *d2)
   if (!ctx || !slot_ok(qs) || !slot_ok(ts)) return MVR_E_ARG;
   Ctx *c = CTX(ctx);
   MVR_HIP_TRY(c, hipSetDevice(c->device));
-  const Cloud &q = c->slots[qs], &t = c->slots[ts];
+  Cloud &q = c->slots[qs], &t = c->slots[ts];
   if (q.n == 0) return MVR_OK;
   if (int rc = ensure(c, c->keys, c->keys_cap, q.n)) return rc;
   if (int rc = launch_fill_u64(c, c->keys, q.n, kKeyInit)) return rc;
-  if (int rc = launch_nn(c, q.pts, 0, q.n, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
+  if (c->nn_mode != 0 && t.n > 0) {
+    if (int rc = ensure_index(c, q)) return rc;
+    if (int rc = ensure_index(c, t)) return rc;
+    if (int rc = launch_nn_cull(c, q, 0, q.n, nullptr, nullptr, t, INFINITY, fma != 0, c->keys)) return rc;
+  } else {
+    if (int rc = launch_nn(c, q.pts, 0, q.n, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
+  }
   uint32_t *didx = nullptr; float *dd2 = nullptr;
   MVR_HIP_TRY(c, hipMalloc(&didx, q.n * 4));
   if (hipMalloc(&dd2, q.n * 4) != hipSuccess) { (void)hipFree(didx); return set_error(c, MVR_E_HIP, "hipMalloc"); }
@@ -395,12 +454,12 @@ API int mvr_nn(mvr_ctx *ctx, int qs, int ts, int fma, uint32_t *idx, float *d2)
 }
 
 static int pair_common(Ctx *c, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb, size_t qn,
-                       double *evals)
+                       double *evals, SearchPlan *plan)
 {
-  const Cloud &s = c->slots[ss], &t = c->slots[ts];
-  if (int rc = run_search(c, s, t, qb, qn, max_dist, reciprocal != 0, fma != 0, evals)) return rc;
-  return launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, c->count, qb, qn, max_dist * max_dist,
-                      reciprocal != 0 && t.n > 0, c->match, c->moments);
+  Cloud &s = c->slots[ss], &t = c->slots[ts];
+  if (int rc = run_search(c, s, t, qb, qn, max_dist, reciprocal != 0, fma != 0, evals, plan)) return rc;
+  return launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, c->count, plan->qperm, plan->tinv, qb, qn,
+                      max_dist * max_dist, reciprocal != 0 && t.n > 0, c->match, c->moments);
 }
 
 API int mvr_correspondences(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma,
@@ -412,7 +471,8 @@ API int mvr_correspondences(mvr_ctx *ctx, int ss, int ts, double max_dist, int r
   *m = 0;
   const size_t ns = c->slots[ss].n;
   if (ns == 0) return MVR_OK;
-  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, 0, ns, nullptr)) return rc;
+  SearchPlan plan;
+  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, 0, ns, nullptr, &plan)) return rc;
   std::vector<int32_t> hm(ns);
   std::vector<nnkey_t> hk(ns);
   MVR_HIP_TRY(c, hipMemcpyAsync(hm.data(), c->match, ns * 4, hipMemcpyDeviceToHost, c->stream));
@@ -441,8 +501,9 @@ API int mvr_pair_moments(mvr_ctx *ctx, int ss, int ts, double max_dist, int reci
   std::memset(out, 0, sizeof *out);
   const Cloud &s = c->slots[ss], &t = c->slots[ts];
   if (s.n == 0) return MVR_OK;
-  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, 0, s.n, nullptr)) return rc;
-  if (int rc = launch_pass2(c, s.pts, t.pts, c->match, 0, s.n, c->moments)) return rc;
+  SearchPlan plan;
+  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, 0, s.n, nullptr, &plan)) return rc;
+  if (int rc = launch_pass2(c, s.pts, t.pts, c->match, plan.qperm, 0, s.n, c->moments)) return rc;
   if (int rc = read_moments(c, 17)) return rc;
   const double *h = c->h_moments;
   out->n = h[0];
@@ -458,8 +519,9 @@ static int moments2_impl(Ctx *c, int ss, int ts, double max_dist, int reciprocal
   const Cloud &s = c->slots[ss], &t = c->slots[ts];
   if (qb > s.n) qb = s.n;
   if (qn > s.n - qb) qn = s.n - qb;
-  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, qb, qn, nullptr)) return rc;
-  return launch_moments2(c, s.pts, t.pts, c->match, qb, qn, origin, dev_out);
+  SearchPlan plan;
+  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, qb, qn, nullptr, &plan)) return rc;
+  return launch_moments2(c, s.pts, t.pts, c->match, plan.qperm, qb, qn, origin, dev_out);
 }
 
 API int mvr_pair_moments2_dev(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb,
@@ -503,7 +565,7 @@ API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t 
   if (int rc = ensure(c, c->match, c->match_cap, s.n)) return rc;
   MVR_HIP_TRY(c, hipMemcpyAsync(c->match, hm.data(), s.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));     // hm goes out of scope
-  if (int rc = launch_moments2(c, s.pts, t.pts, c->match, 0, s.n, origin, c->moments)) return rc;
+  if (int rc = launch_moments2(c, s.pts, t.pts, c->match, nullptr, 0, s.n, origin, c->moments)) return rc;
   if (int rc = read_moments(c, 32)) return rc;
   std::memcpy(out, c->h_moments, sizeof *out);
   return MVR_OK;
@@ -517,13 +579,16 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_ms();
   const size_t ns = c->slots[ss].n;
-  // App. A.1: input_transformed = *input (guess == identity), w := 1
+  // App. A.1: input_transformed = *input (guess == identity)
   Cloud &cur = c->slots[kScratchCur];
   cur.n = 0;
   if (int rc = cloud_reserve(c, cur, ns, false)) return rc;
   const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   if (ns) MVR_HIP_TRY(c, hipMemcpyAsync(cur.pts, c->slots[ss].pts, ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
   cur.n = ns;
+  if (c->nn_mode != 0 && ns) { if (int rc = ensure_index(c, c->slots[ss])) return rc; }   // sort the source once, share it
+  inherit_point_set(cur, c->slots[ss]);
+  MVR_HIP_TRY(c, hipMemsetAsync(c->evals + kEvalRegion, 0, kEvalRegion * sizeof(uint64_t), c->stream));   // running totals of the culled kernel
   float fin[16], tr[16];
   std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
   // DefaultConvergenceCriteria (App. A.4)
@@ -531,23 +596,25 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   const double rel_mse = p->euclidean_fitness_eps, abs_mse = 1e-12;
   double prev_mse = DBL_MAX, cur_mse = 0.0, evals = 0.0, fwdq = 0.0;
   int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
-  const Cloud &tgt = c->slots[ts];
+  Cloud &tgt = c->slots[ts];
   do {
     double ev = 0.0;
-    if (int rc = run_search(c, cur, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev)) return rc;
-    if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, c->slot, c->count, 0, ns,
+    SearchPlan plan;
+    if (int rc = run_search(c, cur, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev, &plan)) return rc;
+    if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, c->slot, c->count, plan.qperm, plan.tinv, 0, ns,
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
-    if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, 0, ns, c->moments)) return rc;
+    if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
     if (int rc = read_moments(c, 18)) return rc;
     const double *h = c->h_moments;
     fwdq += (double)ns;
-    evals += ev + h[17] * (double)ns;   // forward Ns*Nt + reverse Nt'*Ns
+    evals += (c->nn_mode != 0) ? 0.0 : ev + h[17] * (double)ns;   // forward Ns*Nt + reverse Nt'*Ns (brute force)
     ncorr = (int)h[0];
     if (h[0] < 3.0) { state = MVR_CONV_NO_CORRESPONDENCES; converged = 0; status = MVR_E_NOCORR; break; }
     umeyama_from_moments(h + 1, h + 4, h + 8, tr, nullptr);
     cur_mse = h[7];
     if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
+    cur.coords_valid = false;
     mvr_mat4f_mul(tr, fin, fin);
     ++iters;
     state = MVR_CONV_NOT; converged = 0;
@@ -566,8 +633,17 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     if (os != ss) { c->slots[os].n = 0; if (int rc = cloud_reserve(c, c->slots[os], ns, false)) return rc; }
     if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
     c->slots[os].n = ns;
+    if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
+    c->slots[os].coords_valid = false;
   }
   std::memcpy(T_out, fin, sizeof fin);
+  if (st && c->nn_mode != 0) {
+    std::vector<uint64_t> h(kEvalRegion);
+    MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), c->evals + kEvalRegion, kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    evals = 0.0;
+    for (int k = 0; k < kEvalShards; ++k) evals += (double)h[(size_t)k * kEvalStride];
+  }
   if (st) {
     st->iterations = iters; st->converged = converged; st->state = state; st->n_corr = ncorr; st->mse = cur_mse;
     st->evals = evals; st->fwd_queries = fwdq; st->ms = now_ms() - t0;
@@ -588,10 +664,18 @@ API int mvr_fitness(mvr_ctx *ctx, int is, int ts, const float T[16], double max_
   if (int rc = cloud_reserve(c, tmp, ns, false)) return rc;
   if (int rc = launch_transform_f32(c, c->slots[is].pts, tmp.pts, ns, T)) return rc;
   tmp.n = ns;
-  const Cloud &t = c->slots[ts];
+  inherit_point_set(tmp, c->slots[is]);
+  Cloud &t = c->slots[ts];
   if (int rc = ensure(c, c->keys, c->keys_cap, ns)) return rc;
   if (int rc = launch_fill_u64(c, c->keys, ns, kKeyInit)) return rc;
-  if (int rc = launch_nn(c, tmp.pts, 0, ns, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
+  if (c->nn_mode != 0 && t.n > 0) {
+    if (int rc = ensure_index(c, tmp)) return rc;
+    if (int rc = ensure_index(c, t)) return rc;
+    if (!c->slots[is].order) c->slots[is].order = tmp.order;     // keep the sort for the next call
+    if (int rc = launch_nn_cull(c, tmp, 0, ns, nullptr, nullptr, t, cap_from_max2(max_range), fma != 0, c->keys)) return rc;
+  } else {
+    if (int rc = launch_nn(c, tmp.pts, 0, ns, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
+  }
   if (int rc = launch_fitness(c, c->keys, ns, max_range, c->moments)) return rc;
   if (int rc = read_moments(c, 2)) return rc;
   if (c->h_moments[1] > 0) *score = c->h_moments[0] / c->h_moments[1];
@@ -607,7 +691,27 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   if (!std::strcmp(key, "nn_q")) c->nn_q = value;
   else if (!std::strcmp(key, "nn_sub")) c->nn_sub = value;
   else if (!std::strcmp(key, "nn_blocks_per_cu")) c->nn_blocks_per_cu = value;
+  else if (!std::strcmp(key, "nn_mode")) c->nn_mode = value;
+  else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
   else return MVR_E_ARG;
+  return MVR_OK;
+}
+
+API int mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset)
+{
+  if (!ctx || !out) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  std::vector<uint64_t> h(2 * kEvalRegion);
+  MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), c->evals, 2 * kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out[0] = out[1] = out[2] = out[3] = 0;
+  for (int k = 0; k < kEvalShards; ++k) {
+    out[0] += h[(size_t)k * kEvalStride];
+    out[1] += h[kEvalRegion + (size_t)k * kEvalStride];
+    out[2] = std::max<uint64_t>(out[2], h[kEvalRegion + (size_t)k * kEvalStride + 1]);
+    out[3] = std::max<uint64_t>(out[3], h[kEvalRegion + (size_t)k * kEvalStride + 2]);
+  }
+  if (reset) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, 2 * kEvalRegion * sizeof(uint64_t), c->stream));
   return MVR_OK;
 }
 

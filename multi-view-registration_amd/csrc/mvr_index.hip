@@ -1,0 +1,566 @@
+// csrc/mvr_index.hip -- exact nearest neighbours with spatial culling (gfx950).
+//
+// Same results as the brute-force kernel of mvr_nn.hip (bit-identical d2,
+// lowest ORIGINAL index on ties) with O(N * k) instead of O(N^2) distance
+// evaluations -- the GPU-native counterpart of the kd-tree the reference gets
+// from PCL/FLANN (tree_->nearestKSearch inside icp.align, registrator.cpp:569,
+// and inside determineReciprocalCorrespondences, :502/:649):
+//  * every cloud keeps a Morton-ordered copy of its points (w = bits of the
+//    original index) and one AABB per 256-point tile of that copy.  The order
+//    belongs to the point SET and is shared by all posed copies of a scan, so
+//    it is sorted once (hipCUB radix sort on 30-bit codes); after a rigid
+//    motion only coordinates and AABBs are refreshed.  The order affects speed
+//    only: AABBs are always computed from the current coordinates.
+//  * one WAVE is one worker: 64*Q Morton-consecutive queries in registers, a
+//    wave-private LDS buffer for the target tile, no workgroup barrier
+//    anywhere.  The wave first visits the tiles whose box overlaps its own
+//    query box, then every remaining tile whose box distance does not exceed
+//    the wave's current worst best-distance U (a __shfl wave max-reduction
+//    after every tile).  A tile is skipped only if lb*(1-1e-5) > U, so any
+//    point that could win or tie is still evaluated: results stay exact.
+//  * inside a tile the inner loop is the brute-force one (min3 tracking per
+//    32-target sub-tile, index recovered by one re-scan at the end).
+// Compiled with -ffp-contract=off.
+#include <hipcub/hipcub.hpp>
+
+#include "mvr_internal.h"
+
+namespace mvr {
+
+Order::~Order()
+{
+  if (perm) (void)hipFree(perm);
+  if (inv) (void)hipFree(inv);
+}
+
+namespace {
+
+constexpr int kSub = 32;   // min-tracking sub-tile
+
+// ------------------------------------------------------------------ index build
+
+__global__ void bbox_partial_kernel(const float4 *__restrict__ p, size_t n, float *__restrict__ part /* [blocks][6] */)
+{
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
+    hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
+  }
+  __shared__ float s[6][256];
+  for (int k = 0; k < 3; ++k) { s[k][threadIdx.x] = lo[k]; s[3 + k][threadIdx.x] = hi[k]; }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 3; ++k) {
+        s[k][threadIdx.x] = fminf(s[k][threadIdx.x], s[k][threadIdx.x + o]);
+        s[3 + k][threadIdx.x] = fmaxf(s[3 + k][threadIdx.x], s[3 + k][threadIdx.x + o]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+
+// one wave: lane l folds partial rows l, l+64, ...; then a 64-lane shuffle reduction
+__global__ void bbox_final_kernel(const float *__restrict__ part, int blocks, float *__restrict__ bbox)
+{
+  const int lane = threadIdx.x;
+  float v[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+  for (int b = lane; b < blocks; b += 64)
+    for (int k = 0; k < 6; ++k) v[k] = (k < 3) ? fminf(v[k], part[b * 6 + k]) : fmaxf(v[k], part[b * 6 + k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 6; ++k) {
+      const float w = __shfl_xor(v[k], o, 64);
+      v[k] = (k < 3) ? fminf(v[k], w) : fmaxf(v[k], w);
+    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) if (lane == k) bbox[k] = v[k];
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ void morton_kernel(const float4 *__restrict__ p, size_t n, const float *__restrict__ bbox,
+                              uint32_t *__restrict__ code, uint32_t *__restrict__ idx)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = p[i];
+  const float c[3] = {v.x, v.y, v.z};
+  uint32_t q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float ext = bbox[3 + k] - bbox[k];
+    float f = ext > 0.f ? (c[k] - bbox[k]) / ext : 0.f;
+    f = fminf(fmaxf(f, 0.f), 1.f);                   // also maps NaN to 0
+    q[k] = (uint32_t)(f * 1023.0f);
+  }
+  // 30-bit Hilbert index (Skilling's transpose algorithm): unlike the Morton
+  // curve it has no jumps, so 256 consecutive points form a compact patch
+  // (measured on the 200k turntable pair: worst wave 24 overlapping tiles
+  // instead of 142, mean 5.4 instead of 8.8).
+  uint32_t X[3] = {q[0], q[1], q[2]};
+  for (uint32_t Qb = 1u << 9; Qb > 1; Qb >>= 1) {
+    const uint32_t P = Qb - 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (X[k] & Qb) X[0] ^= P;
+      else { const uint32_t t = (X[0] ^ X[k]) & P; X[0] ^= t; X[k] ^= t; }
+    }
+  }
+  X[1] ^= X[0]; X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Qb = 1u << 9; Qb > 1; Qb >>= 1) if (X[2] & Qb) t ^= Qb - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  code[i] = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+  idx[i] = (uint32_t)i;
+}
+
+__global__ void finish_order_kernel(const uint32_t *__restrict__ perm, size_t n, uint32_t *__restrict__ inv)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) inv[perm[k]] = (uint32_t)k;
+}
+
+// sorted[k] = {pts[perm[k]].xyz, bits(perm[k])}; one wave per 256-point tile also reduces its AABB
+__global__ void __launch_bounds__(256) refresh_sorted_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ perm,
+                                                              size_t n, float4 *__restrict__ sorted,
+                                                              float4 *__restrict__ tlo, float4 *__restrict__ thi)
+{
+  const int lane = threadIdx.x & 63;
+  const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t base = tile * kCullTile;
+  if (base >= n) return;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int r = 0; r < kCullTile / 64; ++r) {
+    const size_t k = base + r * 64 + lane;
+    if (k < n) {
+      const uint32_t o = perm[k];
+      float4 v = pts[o];
+      v.w = __uint_as_float(o);
+      sorted[k] = v;
+      lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
+      hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
+    }
+  if (lane == 0) {
+    tlo[tile] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    thi[tile] = make_float4(hi[0], hi[1], hi[2], 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ culled NN
+
+template <bool FMA>
+__device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float qz)
+{
+  const float dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+  if (FMA) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+__device__ __forceinline__ float box_dist2(const float qlo[3], const float qhi[3], const float4 lo, const float4 hi)
+{
+  const float dx = fmaxf(0.f, fmaxf(lo.x - qhi[0], qlo[0] - hi.x));
+  const float dy = fmaxf(0.f, fmaxf(lo.y - qhi[1], qlo[1] - hi.y));
+  const float dz = fmaxf(0.f, fmaxf(lo.z - qhi[2], qlo[2] - hi.z));
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  // LDS hand-off between lanes of ONE wave: DS ops of a wave complete in order;
+  // the fences keep the compiler from moving accesses across this point.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lowest original index among the points of sub-tile `sub` at distance exactly `d`
+template <bool FMA>
+__device__ __forceinline__ uint32_t sub_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t sub, float d,
+                                               float qx, float qy, float qz)
+{
+  uint32_t best = kNone;
+  const uint32_t base = sub * kSub;
+  for (int k = 0; k < kSub; ++k) {
+    const uint32_t j = base + k;
+    if (j < nt) {
+      const float4 p = ts[j];
+      if (dist2<FMA>(p, qx, qy, qz) == d) best = min(best, __float_as_uint(p.w));
+    }
+  }
+  return best;
+}
+
+// One BLOCK = one set of 64*Q Hilbert-consecutive queries, held by all 4 waves;
+// wave w owns the target tiles with (tile & 3) == w, so the serial chain of
+// tiles a query set has to visit is cut four ways.  The waves share nothing
+// but a per-query "best so far" in LDS (ds_min_u32 on the float bits, read
+// without a barrier: it only ever decreases, a stale value merely prunes less)
+// and meet once, at the end, to combine their keys.
+template <bool FMA, int Q>
+__global__ void __launch_bounds__(256)
+nn_cull_kernel(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,
+               const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
+               const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n_tiles, float cap2,
+               nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals)
+{
+  __shared__ float4 lds[4][kCullTile];
+  __shared__ unsigned sbest[64 * Q];
+  __shared__ nnkey_t skey[4][64 * Q];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float4 *__restrict__ T = lds[wv];
+  const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
+  const uint32_t b_begin = blockIdx.x * 64 * Q;
+  if (b_begin >= nq) return;                      // block-uniform
+
+  float qx[Q], qy[Q], qz[Q], best[Q];
+  uint32_t bsub[Q], ord[Q];
+  float qlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, qhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const uint32_t pos = b_begin + q * 64 + lane;
+    best[q] = __builtin_inff(); bsub[q] = kNone; ord[q] = kNone;
+    qx[q] = qy[q] = qz[q] = 0.f;
+    if (pos < nq) {
+      const float4 p = qs[qlist ? qlist[pos] : (q_begin + pos)];
+      qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
+      ord[q] = qlist ? pos : __float_as_uint(p.w);     // key slot: list position / original index
+      qlo[0] = fminf(qlo[0], p.x); qlo[1] = fminf(qlo[1], p.y); qlo[2] = fminf(qlo[2], p.z);
+      qhi[0] = fmaxf(qhi[0], p.x); qhi[1] = fmaxf(qhi[1], p.y); qhi[2] = fmaxf(qhi[2], p.z);
+    }
+    if (wv == 0) sbest[q * 64 + lane] = 0x7F800000u;   // +inf
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 3; ++k) {
+      qlo[k] = fminf(qlo[k], __shfl_xor(qlo[k], o, 64));
+      qhi[k] = fmaxf(qhi[k], __shfl_xor(qhi[k], o, 64));
+    }
+  __syncthreads();
+
+  float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
+  uint32_t tiles_done = 0, tiles_tested = 0;
+
+  auto shared_bound = [&](int q) {
+    return fminf(__uint_as_float(__atomic_load_n(&sbest[q * 64 + lane], __ATOMIC_RELAXED)), cap2);
+  };
+
+  auto process = [&](uint32_t tile) {
+    // stage the tile into this wave's LDS buffer (coalesced 16-byte loads)
+#pragma unroll
+    for (int r = 0; r < kCullTile / 64; ++r) {
+      const uint32_t j = tile * kCullTile + r * 64 + lane;
+      T[r * 64 + lane] = (j < nt) ? ts[j] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+    }
+    wave_lds_sync();
+#pragma unroll 1
+    for (int s = 0; s < kCullTile; s += kSub) {
+      float m[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) m[q] = __builtin_inff();
+#pragma unroll
+      for (int k = 0; k < kSub; k += 2) {
+        const float4 a = T[s + k], b = T[s + k + 1];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const float da = dist2<FMA>(a, qx[q], qy[q], qz[q]);
+          const float db = dist2<FMA>(b, qx[q], qy[q], qz[q]);
+          m[q] = __builtin_fminf(__builtin_fminf(m[q], da), db);
+        }
+      }
+      const uint32_t sub = tile * (kCullTile / kSub) + (uint32_t)s / kSub;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (m[q] < best[q]) { best[q] = m[q]; bsub[q] = sub; }
+        else if (m[q] == best[q] && bsub[q] != kNone && m[q] < 3.0e38f) {
+          // exact tie between two sub-tiles (visited in any order): keep the one
+          // holding the lowest original index.  Rare; only duplicates / symmetric data.
+          const uint32_t o1 = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
+          const uint32_t o2 = sub_argmin<FMA>(ts, nt, sub, best[q], qx[q], qy[q], qz[q]);
+          if (o2 < o1) bsub[q] = sub;
+        }
+      }
+    }
+    wave_lds_sync();     // all lanes done reading before the buffer is overwritten
+    ++tiles_done;
+    // publish this wave's bests, then a wave max-reduction of the set-wide bounds -> new U
+    float w = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (ord[q] != kNone) {
+        atomicMin(&sbest[q * 64 + lane], __float_as_uint(best[q]));
+        w = fmaxf(w, shared_bound(q));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
+    U = fminf(cap2, w);
+  };
+
+  // round 0: own tiles whose box overlaps the query box; round 1: the rest within U
+  for (int round = 0; round < 2; ++round) {
+    for (uint32_t base = 0; base < n_tiles; base += 64) {
+      const uint32_t t = base + lane;
+      float lb = __builtin_inff();
+      const bool mine = (t < n_tiles) && ((t & 3u) == (uint32_t)wv);
+      if (mine) lb = box_dist2(qlo, qhi, tlo[t], thi[t]);
+      const bool pred = mine && ((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
+      unsigned long long mask = __ballot(pred);
+      while (mask) {
+        const int b = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        if (round == 1) {
+          const float lbt = __shfl(lb, b, 64);
+          if (lbt * 0.99999f > U) continue;          // U shrank since the ballot
+        }
+        // exact per-query test: the tile is needed iff SOME query of this set
+        // can still find an equal-or-closer point inside the tile's box
+        const uint32_t tile = base + (uint32_t)b;
+        const float4 lo = tlo[tile], hi = thi[tile];
+        bool need = false;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const float dx = fmaxf(0.f, fmaxf(lo.x - qx[q], qx[q] - hi.x));
+          const float dy = fmaxf(0.f, fmaxf(lo.y - qy[q], qy[q] - hi.y));
+          const float dz = fmaxf(0.f, fmaxf(lo.z - qz[q], qz[q] - hi.z));
+          const float pb = dx * dx + dy * dy + dz * dz;
+          need |= (ord[q] != kNone) && (pb * 0.99999f <= shared_bound(q));
+        }
+        ++tiles_tested;
+        if (!__any(need)) continue;
+        process(tile);
+      }
+    }
+  }
+
+  // recover indices (lowest original index at distance == best); combine the 4 waves
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    nnkey_t key = kKeyInit;
+    if (ord[q] != kNone && bsub[q] != kNone && best[q] <= cap2) {
+      const uint32_t o = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
+      key = ((nnkey_t)__float_as_uint(best[q]) << 32) | o;
+    }
+    skey[wv][q * 64 + lane] = key;
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (ord[q] == kNone) continue;
+      const int i = q * 64 + lane;
+      keys[ord[q]] = min(min(skey[0][i], skey[1][i]), min(skey[2][i], skey[3][i]));
+    }
+  }
+  if (evals && lane == 0) {
+    const uint32_t nvalid = min(nq - b_begin, (uint32_t)(64 * Q));
+    const unsigned long long e = (unsigned long long)tiles_done * kCullTile * nvalid;
+    // sharded counters: one 128-byte line per shard, or thousands of waves serialise on one address
+    unsigned long long *a = evals + (size_t)(blockIdx.x & (kEvalShards - 1)) * kEvalStride;
+    unsigned long long *b = a + kEvalRegion;
+    atomicAdd(a, e);              // this launch (profiling)
+    atomicAdd(b, e);              // running total (mvr_icp_stats.evals)
+    atomicMax(b + 1, (unsigned long long)tiles_done);     // diagnostics: heaviest wave
+    atomicMax(b + 2, (unsigned long long)tiles_tested);
+  }
+}
+
+// ------------------------------------------------------ reciprocal glue (sorted space)
+
+__global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ qperm,
+                                    size_t q_begin, size_t q_count, double max2, const uint32_t *__restrict__ tinv,
+                                    uint8_t *__restrict__ flags)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= q_count) return;
+  const size_t i = qperm ? qperm[q_begin + k] : (q_begin + k);
+  const nnkey_t key = keys[i];
+  const uint32_t j = (uint32_t)key;
+  if (j == kNone) return;
+  const float d2 = __uint_as_float((uint32_t)(key >> 32));
+  if ((double)d2 > max2) return;
+  flags[tinv[j]] = 1;          // same value from every writer
+}
+
+__global__ void scatter_slot_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, size_t cap,
+                                    uint32_t *__restrict__ slot)
+{
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < cap && p < *count) slot[list[p]] = (uint32_t)p;
+}
+
+int ensure_cub(Ctx *c, size_t bytes)
+{
+  if (c->cub_cap >= bytes) return MVR_OK;
+  if (c->cub_tmp) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->cub_tmp); c->cub_tmp = nullptr; c->cub_cap = 0; }
+  MVR_HIP_TRY(c, hipMalloc(&c->cub_tmp, bytes + 4096));
+  c->cub_cap = bytes + 4096;
+  return MVR_OK;
+}
+
+}  // namespace
+
+void new_point_set(Ctx *c, Cloud &cl)
+{
+  cl.set_id = c->next_set_id++;
+  cl.order.reset();
+  cl.coords_valid = false;
+}
+
+void inherit_point_set(Cloud &dst, const Cloud &src)
+{
+  // same point set, same indexing: the ordering stays valid.  Keep an order
+  // the destination already holds for this very set (a scan re-posed every
+  // step from its never-searched raw copy), otherwise take the source's.
+  const bool same = (dst.set_id == src.set_id) && dst.order && dst.order->n == src.n;
+  dst.set_id = src.set_id;
+  if (src.order) dst.order = src.order;
+  else if (!same) dst.order.reset();
+  dst.coords_valid = false;
+}
+
+int ensure_index(Ctx *c, Cloud &cl)
+{
+  const size_t n = cl.n;
+  if (n == 0) return MVR_OK;
+  const size_t tiles = (n + kCullTile - 1) / kCullTile;
+  if (!cl.order || cl.order->n != n) {
+    cl.order.reset();
+    auto it = c->orders.find(cl.set_id);
+    if (it != c->orders.end()) {
+      cl.order = it->second.lock();
+      if (cl.order && cl.order->n != n) cl.order.reset();
+    }
+    cl.coords_valid = false;
+  }
+  if (!cl.order) {
+    // sort once per point set: bbox -> 30-bit Morton codes -> radix sort -> perm / inv
+    if (c->sort_cap < n) {
+      (void)hipStreamSynchronize(c->stream);
+      if (c->codes_a) (void)hipFree(c->codes_a);
+      if (c->codes_b) (void)hipFree(c->codes_b);
+      if (c->idx_a) (void)hipFree(c->idx_a);
+      c->codes_a = c->codes_b = c->idx_a = nullptr; c->sort_cap = 0;
+      const size_t cap = n + n / 4 + 1024;
+      MVR_HIP_TRY(c, hipMalloc(&c->codes_a, cap * 4));
+      MVR_HIP_TRY(c, hipMalloc(&c->codes_b, cap * 4));
+      MVR_HIP_TRY(c, hipMalloc(&c->idx_a, cap * 4));
+      c->sort_cap = cap;
+    }
+    if (int rc = ensure(c, c->partials, c->partials_cap, (size_t)1024 * 32)) return rc;
+    auto ord = std::make_shared<Order>();
+    MVR_HIP_TRY(c, hipMalloc(&ord->perm, n * 4));
+    MVR_HIP_TRY(c, hipMalloc(&ord->inv, n * 4));
+    ord->n = n;
+    ProfScope ps(c, MVR_K_GLUE, 40.0 * (double)n);
+    const int bb = (int)std::min<size_t>(256, (n + 255) / 256);
+    float *part = reinterpret_cast<float *>(c->partials);
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(bb), dim3(256), 0, c->stream, cl.pts, n, part);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, c->stream, part, bb, c->bbox);
+    hipLaunchKernelGGL(morton_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, cl.pts, n, c->bbox,
+                       c->codes_a, c->idx_a);
+    size_t bytes = 0;
+    MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->codes_a, c->codes_b, c->idx_a, ord->perm, (int)n, 0, 30,
+                                                      c->stream));
+    if (int rc = ensure_cub(c, bytes)) return rc;
+    MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->cub_tmp, bytes, c->codes_a, c->codes_b, c->idx_a, ord->perm, (int)n, 0,
+                                                      30, c->stream));
+    hipLaunchKernelGGL(finish_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ord->perm, n,
+                       ord->inv);
+    MVR_HIP_TRY(c, hipGetLastError());
+    cl.order = ord;
+    // drop dead cache entries, remember this one
+    for (auto it = c->orders.begin(); it != c->orders.end();) it = it->second.expired() ? c->orders.erase(it) : std::next(it);
+    c->orders[cl.set_id] = ord;
+    // every resident copy of this point set shares the new ordering
+    for (Cloud &o : c->slots) if (&o != &cl && o.set_id == cl.set_id && o.n == n && !o.order) o.order = ord;
+    cl.coords_valid = false;
+  }
+  if (!cl.coords_valid) {
+    if (int rc = ensure(c, cl.sorted, cl.sorted_cap, n)) return rc;
+    if (cl.tiles_cap < tiles) {
+      (void)hipStreamSynchronize(c->stream);
+      if (cl.tlo) (void)hipFree(cl.tlo);
+      if (cl.thi) (void)hipFree(cl.thi);
+      cl.tlo = cl.thi = nullptr; cl.tiles_cap = 0;
+      const size_t cap = tiles + tiles / 4 + 16;
+      MVR_HIP_TRY(c, hipMalloc(&cl.tlo, cap * sizeof(float4)));
+      MVR_HIP_TRY(c, hipMalloc(&cl.thi, cap * sizeof(float4)));
+      cl.tiles_cap = cap;
+    }
+    ProfScope ps(c, MVR_K_GLUE, 36.0 * (double)n);
+    hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, cl.pts,
+                       cl.order->perm, n, cl.sorted, cl.tlo, cl.thi);
+    MVR_HIP_TRY(c, hipGetLastError());
+    cl.coords_valid = true;
+  }
+  return MVR_OK;
+}
+
+int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint32_t *qlist,
+                   const uint32_t *qcount, const Cloud &t, float cap2, bool fma, nnkey_t *keys)
+{
+  if (q_count == 0 || t.n == 0) return MVR_OK;
+  if (q.n > 0xFFFFFFF0ull || t.n > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+  const uint32_t n_tiles = (uint32_t)((t.n + kCullTile - 1) / kCullTile);
+  // enough waves to fill the chip: fewer queries per lane for small problems
+  // (Q = 1 would make the wave-uniform LDS reads the bottleneck: one ds_read per 8.5 VALU)
+  // measured (tools/cull_sweep.sh): the kernel is bound by its longest serial tile chain, so small query sets win
+  int Q = (q_count <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
+  if (c->cull_q == 1 || c->cull_q == 2 || c->cull_q == 4) Q = c->cull_q;      // tuning override
+  const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (4 cooperating waves) per query set
+  MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+  ProfScope ps(c, MVR_K_NN, c->evals, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, (double)q_count * (double)t.n,
+               kEvalShards);
+#define MVR_LAUNCH_CULL(F, QQ)                                                                                       \
+  hipLaunchKernelGGL((nn_cull_kernel<F, QQ>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q_begin,     \
+                     (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, n_tiles, cap2, keys,    \
+                     c->evals)
+  if (fma) { if (Q == 4) MVR_LAUNCH_CULL(true, 4); else if (Q == 2) MVR_LAUNCH_CULL(true, 2); else MVR_LAUNCH_CULL(true, 1); }
+  else     { if (Q == 4) MVR_LAUNCH_CULL(false, 4); else if (Q == 2) MVR_LAUNCH_CULL(false, 2); else MVR_LAUNCH_CULL(false, 1); }
+#undef MVR_LAUNCH_CULL
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
+                       const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *slot)
+{
+  if (q_count == 0 || nt == 0) return MVR_OK;
+  ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count + 2.0 * (double)nt);
+  MVR_HIP_TRY(c, hipMemsetAsync(flags, 0, nt, c->stream));
+  hipLaunchKernelGGL(flag_matched_kernel, dim3((unsigned)((q_count + 255) / 256)), dim3(256), 0, c->stream, keys, qperm,
+                     q_begin, q_count, max2, tinv, flags);
+  // ordered compaction: list = sorted positions of the matched targets, in Morton order
+  hipcub::CountingInputIterator<uint32_t> it(0);
+  size_t bytes = 0;
+  MVR_HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, it, flags, list, count, (int)nt, c->stream));
+  if (int rc = ensure_cub(c, bytes)) return rc;
+  MVR_HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->cub_tmp, bytes, it, flags, list, count, (int)nt, c->stream));
+  const size_t cap = std::min(q_count, nt);
+  hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream, list, count, cap,
+                     slot);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+}  // namespace mvr

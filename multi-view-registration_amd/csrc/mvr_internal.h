@@ -5,6 +5,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -13,13 +15,30 @@
 namespace mvr {
 
 // ---- device data layout ------------------------------------------------------
+// Morton ordering of one point SET, shared by every cloud that holds that set
+// (a posed copy of a scan keeps the scan's ordering: rigid motion does not
+// change which points are neighbours).
+struct Order {
+  uint32_t *perm = nullptr;   // sorted position -> original index
+  uint32_t *inv = nullptr;    // original index  -> sorted position
+  size_t n = 0;
+  ~Order();
+};
+
 // A cloud is an array of float4 {x,y,z,1}: the same 16-byte record as
 // pcl::PointXYZ (mvr/include/types.h:14), so a host upload is one memcpy and
 // every lane moves one point with a single 16-byte access (dwordx4).
+// For the culled search it also carries a Morton-ordered copy (w = bits of the
+// original index) and one AABB per 256-point tile of that copy.
 struct Cloud {
   float4 *pts = nullptr;
   size_t n = 0;
   size_t cap = 0;
+  uint64_t set_id = 0;                 // identity of the point set + its indexing
+  std::shared_ptr<Order> order;        // null until first needed
+  float4 *sorted = nullptr; size_t sorted_cap = 0;
+  float4 *tlo = nullptr, *thi = nullptr; size_t tiles_cap = 0;
+  bool coords_valid = false;           // sorted[] / tlo / thi match pts[]
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;      // "no neighbour" index
@@ -37,9 +56,17 @@ constexpr int kNNTile = 1024;     // target points per LDS tile (16 KB)
 // Q (queries held in registers per lane) and SUB (sub-tile over which only
 // min(d2) is tracked) are template parameters, chosen per ctx (nn_q, nn_sub).
 
+// culled NN (see mvr_index.hip): tile of the Hilbert-ordered target cloud
+constexpr int kCullTile = 256;
+// its evaluation counters are sharded (one 128-byte line per shard) so that
+// thousands of waves do not serialise on one address; region A = this launch,
+// region B = {running total, max tiles per wave, max tiles tested} per shard
+constexpr int kEvalShards = 64, kEvalStride = 16;
+constexpr size_t kEvalRegion = (size_t)kEvalShards * kEvalStride;     // u64 per region
+
 // work = `work` unless `h_count` is set: then work = *h_count * per_count (the
-// reverse NN pass, whose query count is only known on the device)
-struct ProfRec { int family; hipEvent_t a, b; double work; const uint32_t *h_count; double per_count; };
+// query count / evaluation count is only known on the device)
+struct ProfRec { int family; hipEvent_t a, b; double work; const uint64_t *h_count; int n_shards; double per_count; };
 
 struct Ctx {
   int device = 0;
@@ -50,22 +77,32 @@ struct Ctx {
   std::string name;
   std::string last_error;
   Cloud slots[MVR_MAX_SLOTS + 2];          // +2 internal scratch clouds
+  uint64_t next_set_id = 1;
+  std::map<uint64_t, std::weak_ptr<Order> > orders;   // set_id -> ordering (shared between posed copies)
   // per-pair work buffers (grown on demand)
-  nnkey_t *keys = nullptr;   size_t keys_cap = 0;     // [Ns] forward NN keys
+  nnkey_t *keys = nullptr;   size_t keys_cap = 0;     // [Ns] forward NN keys (by original source index)
   nnkey_t *rkeys = nullptr;  size_t rkeys_cap = 0;    // [Nt'] reverse NN keys (by list position)
   uint32_t *slot = nullptr;  size_t slot_cap = 0;     // [Nt] target -> list position
   uint32_t *list = nullptr;  size_t list_cap = 0;     // [Nt'] distinct matched targets
   int32_t *match = nullptr;  size_t match_cap = 0;    // [Ns] accepted match or -1
+  uint8_t *flags = nullptr;  size_t flags_cap = 0;    // [Nt] matched-target flags (culled mode, sorted space)
   uint32_t *count = nullptr;                          // device counter (list length)
+  unsigned long long *evals = nullptr;                // device counter: pair evaluations of the culled kernel
   double *partials = nullptr; size_t partials_cap = 0;
   double *moments = nullptr;                          // device: 64 doubles
   double *h_moments = nullptr;                        // pinned host: 64 doubles
-  // launch configuration of the NN kernel (mvr_ctx_tune)
+  // index-build scratch
+  uint32_t *codes_a = nullptr, *codes_b = nullptr, *idx_a = nullptr; size_t sort_cap = 0;
+  void *cub_tmp = nullptr; size_t cub_cap = 0;
+  float *bbox = nullptr;                              // device: 8 floats (lo xyz, hi xyz)
+  // launch configuration (mvr_ctx_tune)
   int nn_q = 8, nn_sub = 32, nn_blocks_per_cu = 2;
+  int nn_mode = 1;                                    // 0: brute force, 1: culled (exact, identical results)
+  int cull_q = 0;                                     // culled kernel: queries per lane (0 = auto)
   // instrumentation
   bool prof = false;
   std::vector<ProfRec> recs;
-  uint32_t *h_counts = nullptr;                       // pinned: device counters copied per profiled launch
+  uint64_t *h_counts = nullptr;                       // pinned: device counters copied per profiled launch
   size_t h_counts_used = 0;
   uint64_t prof_launches[MVR_K_COUNT] = {0};
   double prof_ms[MVR_K_COUNT] = {0};
@@ -83,20 +120,33 @@ int set_error(Ctx *c, int status, const char *what, hipError_t e = hipSuccess);
     if (_e != hipSuccess) return ::mvr::set_error((ctx), MVR_E_HIP, #expr, _e); \
   } while (0)
 
-constexpr size_t kProfCounts = 1 << 16;
+constexpr size_t kProfCounts = 1 << 20;   // pinned u64 slots (a culled launch takes kEvalRegion of them)
 
 struct ProfScope {
   Ctx *c; int fam; hipEvent_t a = nullptr, b = nullptr; double work;
-  const uint32_t *d_count = nullptr; double per_count = 0.0;
+  const void *d_count = nullptr; int d_bytes = 0; int n_shards = 0; double per_count = 0.0;
   ProfScope(Ctx *ctx, int family, double w);
-  // work is (*d_count) * per_count, read back asynchronously after the launch
-  ProfScope(Ctx *ctx, int family, const uint32_t *dev_count, double per_cnt, double upper_bound);
+  // work is (*dev_count) * per_cnt, read back asynchronously after the launch;
+  // dev_count points to a device uint32 (bytes = 4), a uint64 (bytes = 8), or,
+  // with shards > 0, to `shards` u64 counters kEvalStride apart that are summed
+  ProfScope(Ctx *ctx, int family, const void *dev_count, int bytes, double per_cnt, double upper_bound, int shards = 0);
   ProfScope(const ProfScope &) = delete;
   ProfScope &operator=(const ProfScope &) = delete;
   ~ProfScope();
 };
 
-// ---- kernel launchers (mvr_nn.hip / mvr_reduce.hip) -------------------------
+template <class T>
+int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
+{
+  if (cap >= want) return MVR_OK;
+  if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; cap = 0; }
+  size_t ncap = want + want / 4 + 64;
+  MVR_HIP_TRY(c, hipMalloc(&p, ncap * sizeof(T)));
+  cap = ncap;
+  return MVR_OK;
+}
+
+// ---- kernel launchers (mvr_nn.hip / mvr_reduce.hip / mvr_index.hip) -----------
 // forward / reverse brute-force NN.  Queries: points [q_begin, q_begin+q_count)
 // of `q` (direct; key ordinal = point index), or, when `qlist` != null, the
 // points q[qlist[k]] for k < *qcount (device counter; q_count is then the upper
@@ -104,18 +154,36 @@ struct ProfScope {
 int launch_nn(Ctx *c, const float4 *q, size_t q_begin, size_t q_count, const uint32_t *qlist,
               const uint32_t *qcount, const float4 *t, size_t nt, bool fma, nnkey_t *keys);
 
+// Morton order + tile AABBs of a cloud, (re)built or refreshed as needed
+int ensure_index(Ctx *c, Cloud &cl);
+void new_point_set(Ctx *c, Cloud &cl);                 // after upload / append / clear
+void inherit_point_set(Cloud &dst, const Cloud &src);  // after copy / transform
+// culled exact NN.  Queries: sorted positions [q_begin, q_begin+q_count) of the
+// query cloud (key ordinal = ORIGINAL index of the query), or sorted positions
+// qlist[p] for p < *qcount (key ordinal = p).  cap2: distances above it are not
+// needed (+inf = unbounded).
+int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint32_t *qlist,
+                   const uint32_t *qcount, const Cloud &t, float cap2, bool fma, nnkey_t *keys);
+// culled-mode reciprocal glue: flag matched targets (sorted space), ordered list, slot positions
+int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count,
+                       double max2, const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list,
+                       uint32_t *count, uint32_t *slot);
+
 int launch_fill_u64(Ctx *c, nnkey_t *p, size_t n, nnkey_t v);
 int launch_mark(Ctx *c, const nnkey_t *keys, size_t q_begin, size_t q_count, double max2,
                 uint32_t *slot, uint32_t *list, uint32_t *count);
+// The per-query kernels walk positions [q_begin, q_begin+q_count) and take the
+// query index i = qperm ? qperm[pos] : pos.  slot is indexed by tinv ? tinv[j] : j.
 // pass 1: match[] + {n, sum p, sum q, sum d2}; then means into moments[0..7]
 int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys,
-                 const nnkey_t *rkeys, const uint32_t *slot, const uint32_t *count, size_t q_begin,
-                 size_t q_count, double max2, bool reciprocal, int32_t *match, double *moments);
+                 const nnkey_t *rkeys, const uint32_t *slot, const uint32_t *count, const uint32_t *qperm,
+                 const uint32_t *tinv, size_t q_begin, size_t q_count, double max2, bool reciprocal,
+                 int32_t *match, double *moments);
 // pass 2: sigma = (1/n) sum (q-mean_q)(p-mean_p)^T into moments[8..16]
-int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match,
+int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
                  size_t q_begin, size_t q_count, double *moments);
 // raw second moments about `origin` into out[0..31] (device pointer)
-int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match,
+int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
                     size_t q_begin, size_t q_count, const double origin[3], double *out);
 int launch_fitness(Ctx *c, const nnkey_t *keys, size_t n, double max_range, double *moments);
 int launch_transform_f32(Ctx *c, const float4 *in, float4 *out, size_t n, const float T[16]);

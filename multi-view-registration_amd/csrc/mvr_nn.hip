@@ -213,7 +213,7 @@ int launch_nn(Ctx *c, const float4 *q, size_t q_begin, size_t q_count, const uin
   const uint64_t units = n_units(Q);
   const uint32_t blocks = (uint32_t)std::min<uint64_t>(units, resident);
   // evaluations: queries x targets; for the reverse pass the query count lives on the device
-  ProfScope ps(c, MVR_K_NN, qlist ? qcount : nullptr, (double)nt, (double)q_count * (double)nt);
+  ProfScope ps(c, MVR_K_NN, qlist ? qcount : nullptr, 4, (double)nt, (double)q_count * (double)nt);
   const nn_fn fn = fma ? pick<true>(Q, SUB) : pick<false>(Q, SUB);
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(kNNThreads), 0, c->stream, q, (uint32_t)q_begin, (uint32_t)q_count,
                      qlist, qcount, t, (uint32_t)nt, keys);

@@ -55,18 +55,22 @@ __device__ __forceinline__ void sum_rows(const double *__restrict__ partials, in
                                          double * /*unused*/)
 {
   static_assert(K <= 32, "sum_rows: K <= 32");
-  __shared__ double grp[kRT / 32][32];
+  constexpr int KP = (K <= 8) ? 8 : ((K <= 16) ? 16 : 32);   // columns padded to a power of two
+  constexpr int G = kRT / KP;                                 // row groups
+  __shared__ double grp[G][KP];
   __shared__ double tot[32];
-  const int g = threadIdx.x >> 5, k = threadIdx.x & 31;
+  const int g = threadIdx.x / KP, k = threadIdx.x % KP;
   double s = 0.0;
-  if (k < K)
-    for (int r = g; r < rows; r += kRT / 32) s += partials[(size_t)r * K + k];
+  if (k < K) {
+#pragma unroll 8
+    for (int r = g; r < rows; r += G) s += partials[(size_t)r * K + k];
+  }
   grp[g][k] = s;
   __syncthreads();
   if (threadIdx.x < K) {
     double t = grp[0][threadIdx.x];
 #pragma unroll
-    for (int gg = 1; gg < kRT / 32; ++gg) t += grp[gg][threadIdx.x];
+    for (int gg = 1; gg < G; ++gg) t += grp[gg][threadIdx.x];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
@@ -167,21 +171,22 @@ __global__ void mark_kernel(const nnkey_t *__restrict__ keys, size_t q_begin, si
 // acc: 0 n, 1..3 sum p, 4..6 sum q, 7 sum d2
 __global__ void __launch_bounds__(kRT)
 pass1_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const nnkey_t *__restrict__ keys,
-             const nnkey_t *__restrict__ rkeys, const uint32_t *__restrict__ slot, size_t q_begin,
+             const nnkey_t *__restrict__ rkeys, const uint32_t *__restrict__ slot,
+             const uint32_t *__restrict__ qperm, const uint32_t *__restrict__ tinv, size_t q_begin,
              size_t q_count, double max2, int reciprocal, int32_t *__restrict__ match,
              double *__restrict__ partials)
 {
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
-    const size_t i = q_begin + k;
+    const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
     const nnkey_t key = keys[i];
     const uint32_t j = (uint32_t)key;
     const float d2 = __uint_as_float((uint32_t)(key >> 32));
     bool ok = (j != kNone) && !((double)d2 > max2);
     if (ok && reciprocal) {
       // App. A.2: NN of t_j in the source must be i itself, within max_dist
-      const nnkey_t rk = rkeys[slot[j]];
+      const nnkey_t rk = rkeys[slot[tinv ? tinv[j] : j]];
       const float dr = __uint_as_float((uint32_t)(rk >> 32));
       ok = ((uint32_t)rk == (uint32_t)i) && !((double)dr > max2);
     }
@@ -217,14 +222,15 @@ __global__ void __launch_bounds__(kRT) pass1_final_kernel(const double *__restri
 // -------------------------------------------------------------- K6 pass 2
 __global__ void __launch_bounds__(kRT)
 pass2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const int32_t *__restrict__ match,
-             size_t q_begin, size_t q_count, const double *__restrict__ moments, double *__restrict__ partials)
+             const uint32_t *__restrict__ qperm, size_t q_begin, size_t q_count, const double *__restrict__ moments,
+             double *__restrict__ partials)
 {
   const double mpx = moments[1], mpy = moments[2], mpz = moments[3];
   const double mqx = moments[4], mqy = moments[5], mqz = moments[6];
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
-    const size_t i = q_begin + k;
+    const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
     const int32_t j = match[i];
     if (j < 0) continue;
     const float4 p = src[i], q = tgt[j];
@@ -255,14 +261,15 @@ struct Vec3d { double x, y, z; };
 
 __global__ void __launch_bounds__(kRT)
 moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const int32_t *__restrict__ match,
-                size_t q_begin, size_t q_count, Vec3d o, double *__restrict__ partials)
+                const uint32_t *__restrict__ qperm, size_t q_begin, size_t q_count, Vec3d o,
+                double *__restrict__ partials)
 {
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
-    const size_t i = q_begin + k;
+    const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
     const int32_t j = match[i];
     if (j < 0) continue;
     const float4 p4 = src[i], q4 = tgt[j];
@@ -323,19 +330,11 @@ inline int reduce_blocks(const Ctx *c, size_t n)
   const size_t want = (n + kRT - 1) / kRT;
   // few partial rows keep the single-block final sum short; 2 blocks per CU
   // already put > 8 MB of 16-byte loads in flight
-  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu * 2);
+  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu);
   return (int)std::max<size_t>(1, std::min(want, cap));
 }
 
-inline int ensure_partials(Ctx *c, size_t doubles)
-{
-  if (c->partials_cap >= doubles) return MVR_OK;
-  if (c->partials) (void)hipFree(c->partials);
-  c->partials = nullptr; c->partials_cap = 0;
-  MVR_HIP_TRY(c, hipMalloc(&c->partials, doubles * sizeof(double)));
-  c->partials_cap = doubles;
-  return MVR_OK;
-}
+inline int ensure_partials(Ctx *c, size_t doubles) { return ensure(c, c->partials, c->partials_cap, doubles); }
 
 }  // namespace
 
@@ -397,43 +396,43 @@ int launch_mark(Ctx *c, const nnkey_t *keys, size_t q_begin, size_t q_count, dou
 }
 
 int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys, const nnkey_t *rkeys,
-                 const uint32_t *slot, const uint32_t *count, size_t q_begin, size_t q_count, double max2,
-                 bool reciprocal, int32_t *match, double *moments)
+                 const uint32_t *slot, const uint32_t *count, const uint32_t *qperm, const uint32_t *tinv,
+                 size_t q_begin, size_t q_count, double max2, bool reciprocal, int32_t *match, double *moments)
 {
   const int blocks = reduce_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   // K5 touches Ns*(12+4+4) + 12*M algorithmic bytes (M <= Ns)
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
-  hipLaunchKernelGGL(pass1_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, keys, rkeys, slot, q_begin,
-                     q_count, max2, reciprocal ? 1 : 0, match, c->partials);
+  hipLaunchKernelGGL(pass1_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, keys, rkeys, slot, qperm,
+                     tinv, q_begin, q_count, max2, reciprocal ? 1 : 0, match, c->partials);
   hipLaunchKernelGGL(pass1_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks,
                      reciprocal ? count : nullptr, moments);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
 
-int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, size_t q_begin,
-                 size_t q_count, double *moments)
+int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
+                 size_t q_begin, size_t q_count, double *moments)
 {
   const int blocks = reduce_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
-  hipLaunchKernelGGL(pass2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, q_begin, q_count,
-                     moments, c->partials);
+  hipLaunchKernelGGL(pass2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, qperm, q_begin,
+                     q_count, moments, c->partials);
   hipLaunchKernelGGL(pass2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
 
-int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, size_t q_begin,
-                    size_t q_count, const double origin[3], double *out)
+int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
+                    size_t q_begin, size_t q_count, const double origin[3], double *out)
 {
   const int blocks = reduce_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   Vec3d o{origin[0], origin[1], origin[2]};
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
-  hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, q_begin, q_count, o,
-                     c->partials);
+  hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, qperm, q_begin, q_count,
+                     o, c->partials);
   hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;

@@ -37,10 +37,14 @@ def orc():
     return oracle
 
 
-@pytest.fixture(scope="session")
-def gpu(mvr):
-    """A GPU context; -m gpu tests fail loudly (no skip, no fallback) without one."""
+@pytest.fixture(scope="session", params=["culled", "brute"])
+def gpu(mvr, request):
+    """A GPU context; -m gpu tests fail loudly (no skip, no fallback) without one.
+    Every parity test runs against both exact search kernels: the spatially
+    culled one (default) and the brute-force one."""
     ctx = mvr.Context(0)
+    ctx.tune(nn_mode=1 if request.param == "culled" else 0)
+    ctx.mode = request.param
     yield ctx
     ctx.close()
 

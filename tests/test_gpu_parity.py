@@ -257,4 +257,7 @@ def test_full_size_200k_pair(gpu, orc, mvr):
     out, To, sto, _ = orc.icp_align(src, tgt, orc.make_params())
     assert st["n_corr"] == sto["n_corr"] == len(c)
     assert_pose_close(T, To)
-    assert st["evals"] >= 200000.0 * 200000.0
+    if gpu.mode == "brute":
+        assert st["evals"] >= 200000.0 * 200000.0
+    else:       # the culled kernel evaluates a small fraction of the pairs, with identical results
+        assert 200000.0 * 256 <= st["evals"] < 0.2 * 200000.0 * 200000.0

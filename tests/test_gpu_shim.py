@@ -25,9 +25,21 @@ def driver(built):
     return exe
 
 
+@pytest.fixture(scope="module", params=["1", "0"], ids=["culled", "brute"], autouse=True)
+def nn_mode_env(request):
+    """Every driver test runs on both exact search kernels (MVR_NN_MODE)."""
+    old = os.environ.get("MVR_NN_MODE")
+    os.environ["MVR_NN_MODE"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("MVR_NN_MODE", None)
+    else:
+        os.environ["MVR_NN_MODE"] = old
+
+
 def run(exe, mode, V, N, max_d, repeat, config):
     r = subprocess.run([exe, mode, str(V), str(N), str(max_d), str(repeat), str(config)], stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=600)
+                       stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ))
     assert r.returncode == 0, r.stderr
     return json.loads(r.stdout), r.stderr
 

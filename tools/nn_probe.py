@@ -36,9 +36,10 @@ def main():
             m2 = ctx.pair_moments2(1, 0, 4.0, np.array(sp.pivot), fma=bool(fma))
         ctx.prof_enable(False)
         launches, ms, evals = ctx.prof_get(mvr.K_NN)
+        dbg = ctx.debug_counters()
         print(json.dumps(dict(n=n, reps=reps, fma=fma, knobs=knobs, nn_launches=launches, nn_ms=ms, nn_evals=evals,
                               evals_per_s=evals / (ms * 1e-3), tflops_canonical=8 * evals / (ms * 1e-3) / 1e12,
-                              n_corr=m2.n)))
+                              n_corr=m2.n, max_tiles_per_wave=dbg[2], max_tested_per_wave=dbg[3])))
 
 
 if __name__ == "__main__":
