@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--max-dist", type=float, default=4.0)
     ap.add_argument("--fma", type=int, default=0, help="1: fma distance chain instead of the spec's rounded-per-op form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nn-mode", type=int, default=1, help="1: exact culled search (default); 0: exact brute force")
+    ap.add_argument("--no-bruteforce-pass", action="store_true",
+                    help="skip the extra untimed brute-force ring pass that feeds roofline_bruteforce")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +109,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ctx.tune(nn_mode=args.nn_mode)
     reset()
     for _ in range(args.warmup):
         step()
@@ -125,8 +129,11 @@ def main():
 
     nn_launches, nn_ms, nn_evals = ctx.prof_get(mvr.K_NN)
     rd_launches, rd_ms, rd_bytes = ctx.prof_get(mvr.K_REDUCE)
-    xf_launches, xf_ms, xf_bytes = ctx.prof_get(mvr.K_XFORM)
+    gl_launches, gl_ms, gl_bytes = ctx.prof_get(mvr.K_GLUE)
     name, n_cu, mhz = ctx.device_info()
+    culled = args.nn_mode != 0
+    # evaluations a brute-force search of the same step performs (Ns*Nt + Nt'*Ns per pair)
+    brute_equiv = None
 
     out = {
         "metric": "ICP correspondences/sec + ms/iteration, 12-view x 200k pts",
@@ -141,37 +148,70 @@ def main():
                                % (V, N, V),
                    "views": V, "points_per_scan": N, "max_distance": args.max_dist, "pairs": V,
                    "dist_mode": "fma" if args.fma else "rounded-per-op (spec)",
+                   "nn_search": "exact, spatially culled (Hilbert tiles)" if culled else "exact, brute force",
                    "sharding": "source queries of the %d ring pairs split evenly over %d rank(s)" % (V, world)},
         "accepted_correspondences_per_step": reg.last["n_corr"], "mse": reg.last["mse"],
         "device": name, "n_cu": n_cu,
+        "step_breakdown_ms": {"enqueue": reg.last["ms_enqueue"], "gpu_drain": reg.last["ms_drain"],
+                              "host_solve": reg.last["ms_host_solve"]},
     }
+
+    def traffic_of(fname):
+        tp = os.path.join(ROOT, "profiles", fname)
+        try:
+            return json.load(open(tp)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+
+    def nn_roofline(kernel, launches, ms, evals, traffic, extra=None):
+        avg_s = ms * 1e-3 / launches
+        achieved = FLOP_PER_EVAL * (evals / launches) / avg_s / 1e12
+        r = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+             "note": "compute-bound on the FP32 vector ALUs: gfx950's dense FP32 matrix peak equals its FP32 vector "
+                     "peak (157.3 TFLOP/s) and no MFMA is issued (no dense contraction in a 3-D distance); achieved = "
+                     "8 flop x point-pair evaluations EXECUTED per launch / mean launch time from HIP events",
+             "launches": launches, "avg_launch_ms": ms / launches, "evals_per_launch": evals / launches,
+             "evals_per_s": evals / (ms * 1e-3)}
+        if extra:
+            r.update(extra)
+        return r
+
+    # the brute-force kernel (the plain VALU-roofline kernel) on the same pairs: one extra, untimed ring pass
+    bf = None
+    if world == 1 and not args.no_bruteforce_pass:
+        ctx.tune(nn_mode=0)
+        reset()
+        step()
+        ctx.prof_reset(); ctx.prof_enable(True)
+        reset()
+        step()
+        ctx.prof_enable(False)
+        bl, bms, bev = ctx.prof_get(mvr.K_NN)
+        ctx.tune(nn_mode=args.nn_mode)
+        if bl:
+            brute_equiv = bev
+            bf = nn_roofline("nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal; one untimed ring pass)", bl, bms, bev,
+                             traffic_of("nn_traffic.json"))
     if nn_launches:
-        avg_s = nn_ms * 1e-3 / nn_launches
-        achieved = FLOP_PER_EVAL * (nn_evals / nn_launches) / avg_s / 1e12
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "nn_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {
-            "kernel": "nn_kernel (brute-force 1-NN, fwd + reciprocal)",
-            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-            "note": "compute-bound on the FP32 vector ALUs: gfx950's dense FP32 matrix peak equals its FP32 "
-                    "vector peak (157.3 TFLOP/s) and no MFMA is issued (no dense contraction in a 3-D distance); "
-                    "achieved = 8 flop x point-pair evaluations per launch / mean launch time from HIP events",
-            "launches": nn_launches, "avg_launch_ms": nn_ms / nn_launches,
-            "evals_per_launch": nn_evals / nn_launches, "evals_per_s": nn_evals / (nn_ms * 1e-3),
-            "nn_share_of_step": nn_ms * 1e-3 / elapsed,
-        }
+        extra = {"nn_share_of_step": nn_ms * 1e-3 / elapsed}
+        if culled:
+            extra["evals_bruteforce_equivalent_per_step"] = brute_equiv
+            if brute_equiv:
+                extra["culling_factor"] = brute_equiv / (nn_evals / args.steps)
+                extra["bruteforce_equivalent_tflops"] = FLOP_PER_EVAL * brute_equiv / (nn_ms * 1e-3 / args.steps) / 1e12
+        out["roofline"] = nn_roofline("nn_cull_kernel (exact culled 1-NN, fwd + reciprocal)" if culled else
+                                      "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)", nn_launches, nn_ms,
+                                      nn_evals, traffic_of("nn_cull_traffic.json" if culled else "nn_traffic.json"), extra)
+    if bf:
+        out["roofline_bruteforce"] = bf
     if rd_launches:
         out["roofline_hbm"] = {
             "kernel": "pass1 + moments2 reductions (K5/K8)", "bound": "hbm",
             "achieved": rd_bytes / (rd_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": rd_bytes / (rd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "launches": rd_launches,
             "avg_launch_ms": rd_ms / rd_launches,
+            "note": "launch-latency bound at 200k points per scan (4 MB per launch)",
         }
     out["pcie"] = {"h2d_s": h2d, "h2d_bytes": V * N * 16}
 

@@ -264,14 +264,24 @@ nn_cull_kernel(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count
     return fminf(__uint_as_float(__atomic_load_n(&sbest[q * 64 + lane], __ATOMIC_RELAXED)), cap2);
   };
 
-  auto process = [&](uint32_t tile) {
-    // stage the tile into this wave's LDS buffer (coalesced 16-byte loads)
+  // register prefetch buffer: the NEXT tile's points travel from L2 while the
+  // current tile is being evaluated out of LDS
+  float4 pre[kCullTile / 64];
+  auto fetch = [&](uint32_t tile) {
 #pragma unroll
     for (int r = 0; r < kCullTile / 64; ++r) {
       const uint32_t j = tile * kCullTile + r * 64 + lane;
-      T[r * 64 + lane] = (j < nt) ? ts[j] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+      pre[r] = (j < nt) ? ts[j] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < kCullTile / 64; ++r) T[r * 64 + lane] = pre[r];
     wave_lds_sync();
+  };
+
+  // evaluates the tile currently staged in this wave's LDS buffer
+  auto process = [&](uint32_t tile) {
 #pragma unroll 1
     for (int s = 0; s < kCullTile; s += kSub) {
       float m[Q];
@@ -316,40 +326,69 @@ nn_cull_kernel(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count
     U = fminf(cap2, w);
   };
 
-  // round 0: own tiles whose box overlaps the query box; round 1: the rest within U
-  for (int round = 0; round < 2; ++round) {
-    for (uint32_t base = 0; base < n_tiles; base += 64) {
-      const uint32_t t = base + lane;
-      float lb = __builtin_inff();
-      const bool mine = (t < n_tiles) && ((t & 3u) == (uint32_t)wv);
-      if (mine) lb = box_dist2(qlo, qhi, tlo[t], thi[t]);
-      const bool pred = mine && ((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
-      unsigned long long mask = __ballot(pred);
-      while (mask) {
-        const int b = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        if (round == 1) {
-          const float lbt = __shfl(lb, b, 64);
-          if (lbt * 0.99999f > U) continue;          // U shrank since the ballot
-        }
-        // exact per-query test: the tile is needed iff SOME query of this set
-        // can still find an equal-or-closer point inside the tile's box
-        const uint32_t tile = base + (uint32_t)b;
-        const float4 lo = tlo[tile], hi = thi[tile];
-        bool need = false;
+  // exact per-query test: the tile is needed iff SOME query of this set can
+  // still find an equal-or-closer point inside the tile's box
+  auto needed = [&](uint32_t tile) {
+    const float4 lo = tlo[tile], hi = thi[tile];
+    bool need = false;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          const float dx = fmaxf(0.f, fmaxf(lo.x - qx[q], qx[q] - hi.x));
-          const float dy = fmaxf(0.f, fmaxf(lo.y - qy[q], qy[q] - hi.y));
-          const float dz = fmaxf(0.f, fmaxf(lo.z - qz[q], qz[q] - hi.z));
-          const float pb = dx * dx + dy * dy + dz * dz;
-          need |= (ord[q] != kNone) && (pb * 0.99999f <= shared_bound(q));
-        }
-        ++tiles_tested;
-        if (!__any(need)) continue;
-        process(tile);
-      }
+    for (int q = 0; q < Q; ++q) {
+      const float dx = fmaxf(0.f, fmaxf(lo.x - qx[q], qx[q] - hi.x));
+      const float dy = fmaxf(0.f, fmaxf(lo.y - qy[q], qy[q] - hi.y));
+      const float dz = fmaxf(0.f, fmaxf(lo.z - qz[q], qz[q] - hi.z));
+      const float pb = dx * dx + dy * dy + dz * dz;
+      need |= (ord[q] != kNone) && (pb * 0.99999f <= shared_bound(q));
     }
+    ++tiles_tested;
+    return __any(need) != 0;
+  };
+
+  // candidate stream over this wave's own tiles (tile = 4*i + wv, lane <-> i):
+  // round 0 = tiles whose box overlaps the query box, round 1 = the rest within U.
+  const uint32_t n_own = (n_tiles > (uint32_t)wv) ? (n_tiles - (uint32_t)wv + 3u) / 4u : 0u;
+  int round = 0;
+  uint32_t ibase = 0;                 // next block of 64 own tiles to ballot
+  uint32_t cbase = 0;                 // block the current mask belongs to
+  unsigned long long mask = 0ull;
+  float lb = __builtin_inff();
+  auto advance = [&]() -> uint32_t {
+    for (;;) {
+      while (mask == 0ull) {
+        if (ibase >= n_own) {
+          if (round == 1) return kNone;
+          round = 1; ibase = 0;
+          if (n_own == 0) return kNone;
+        }
+        const uint32_t i = ibase + lane;
+        const uint32_t t = 4u * i + (uint32_t)wv;
+        lb = __builtin_inff();
+        if (i < n_own) lb = box_dist2(qlo, qhi, tlo[t], thi[t]);
+        const bool pred = (i < n_own) && ((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
+        mask = __ballot(pred);
+        cbase = ibase;
+        ibase += 64;
+      }
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if (round == 1 && __shfl(lb, b, 64) * 0.99999f > U) continue;     // U shrank since the ballot
+      const uint32_t tile = 4u * (cbase + (uint32_t)b) + (uint32_t)wv;
+      if (needed(tile)) return tile;
+    }
+  };
+
+  uint32_t cur = advance();
+  if (cur != kNone) fetch(cur);
+  while (cur != kNone) {
+    stage();                                  // registers -> LDS (waits for the prefetch)
+    uint32_t nxt = advance();                 // chosen with the bounds as they are NOW
+    if (nxt != kNone) fetch(nxt);             // in flight during the evaluation below
+    process(cur);
+    // the bounds have shrunk: re-validate the prefetched tile (its data is dropped if it is no longer needed)
+    while (nxt != kNone && !needed(nxt)) {
+      nxt = advance();
+      if (nxt != kNone) fetch(nxt);
+    }
+    cur = nxt;
   }
 
   // recover indices (lowest original index at distance == best); combine the 4 waves

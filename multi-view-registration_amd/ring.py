@@ -114,12 +114,16 @@ class RingLUM:
 
     def step(self, poses):
         """poses: list of V (4,4) float64 column-vector poses -> new list."""
+        import time
         b = self.b
+        t0 = time.perf_counter()
         b.pose_clouds(poses)
         table = b.edge_rows(self.segments, self.edges, self.max_dist, self.origin)
+        t1 = time.perf_counter()              # everything enqueued (asynchronous)
         if self.world > 1:
             self.all_reduce(table)            # per-pair sums/residuals of all ranks -> every rank
         rows = b.to_host(table)
+        t2 = time.perf_counter()              # GPU drained, table on the host
         m2s = []
         for e in range(len(self.edges)):
             r = np.array(rows[e], np.float64)
@@ -139,6 +143,8 @@ class RingLUM:
             L = pose_to_mat4(P[v]).astype(np.float32).astype(np.float64)
             new.append(mat4d_mul(L, poses[v]))
         n = float(sum(pair_n))
+        t3 = time.perf_counter()
         self.last = dict(pair_T=pair_T, pair_n=pair_n, pair_mse=pair_mse, lum_pose=P, lum_iterations=its,
-                         n_corr=n, mse=(sum(a * b for a, b in zip(pair_n, pair_mse)) / n) if n else 0.0)
+                         n_corr=n, mse=(sum(a * b for a, b in zip(pair_n, pair_mse)) / n) if n else 0.0,
+                         ms_enqueue=1e3 * (t1 - t0), ms_drain=1e3 * (t2 - t1), ms_host_solve=1e3 * (t3 - t2))
         return new
