@@ -38,6 +38,11 @@ def log(*a):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to
+    # fd 1 (RCCL prints its version there) are diverted to stderr until the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -61,8 +66,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is taken even with one rank,
+    # so that the collective code can be rehearsed on a 1-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("MVR_BENCH_FORCE_DIST", "0") == "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as g
@@ -91,7 +100,7 @@ def main():
     ctx.sync()
     h2d = time.time() - h2d0
     reg = ring.RingLUM(backend, V, [N] * V, args.max_dist, origin, rank=rank, world=world,
-                       all_reduce=(dist.all_reduce if world > 1 else None))
+                       all_reduce=(dist.all_reduce if use_dist else None))
     if rank == 0:
         log("[bench] synth %dx%d in %.2fs; rank0 segments %s" % (V, N, time.time() - t0, reg.segments))
     state = {"poses": [p.copy() for p in poses0]}
@@ -105,7 +114,7 @@ def main():
         state["poses"] = reg.step(state["poses"])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,7 +131,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -235,9 +244,10 @@ def main():
                                          "1 thread, %.1f s" % (nq // N, passes, V, dt),
                                "host_cpus": os.cpu_count()}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

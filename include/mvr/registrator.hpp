@@ -59,6 +59,37 @@ class ScanCloud {
   }
   void initRotation(const Registrator &r);        // point_cloud.cpp:400-413
 
+  // point_cloud.cpp:305-326 / :328-347 -- `transformation.txt`: the column-vector
+  // 4x4 printed row by row (matrix(j,i), i outer), "%lf " per element, one row per
+  // line.  6 decimals: poses round-trip to 1e-6 only.
+  bool loadTransformation(const std::string &filename)
+  {
+    FILE *file = std::fopen(filename.c_str(), "r");
+    if (file == NULL) return false;
+    RowMatrixd matrix;
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; ++i)
+      for (int j = 0; j < 4 && ok; ++j) {
+        double element;
+        ok = std::fscanf(file, "%lf", &element) == 1;
+        if (ok) matrix(j, i) = element;
+      }
+    std::fclose(file);
+    if (ok) setMatrix(matrix);
+    return ok;
+  }
+  bool saveTransformation(const std::string &filename) const
+  {
+    FILE *file = std::fopen(filename.c_str(), "w");
+    if (file == NULL) return false;
+    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 4; ++j) std::fprintf(file, "%lf ", matrix_(j, i));
+      std::fprintf(file, "\n");
+    }
+    std::fclose(file);
+    return true;
+  }
+
  private:
   RowMatrixd matrix_;
 };
@@ -81,6 +112,27 @@ class Registrator {
   void setAxisNormal(double x, double y, double z) { axis_[0] = (float)x; axis_[1] = (float)y; axis_[2] = (float)z; }
   const float *getPivotPoint() const { return pivot_; }
   const float *getAxisNormal() const { return axis_; }
+
+  // registrator.cpp:258-274 / :294-308 -- `axis.txt`: pivot "x y z" then axis "nx ny nz", "%f"
+  bool load(const std::string &filename)
+  {
+    FILE *file = std::fopen(filename.c_str(), "r");
+    if (file == NULL) return false;
+    double x, y, z, nx, ny, nz;
+    const bool ok = std::fscanf(file, "%lf %lf %lf", &x, &y, &z) == 3 && std::fscanf(file, "%lf %lf %lf", &nx, &ny, &nz) == 3;
+    std::fclose(file);
+    if (ok) { setPivotPoint(x, y, z); setAxisNormal(nx, ny, nz); }
+    return ok;
+  }
+  bool save(const std::string &filename) const
+  {
+    FILE *file = std::fopen(filename.c_str(), "w");
+    if (file == NULL) return false;
+    std::fprintf(file, "%f %f %f\n", pivot_[0], pivot_[1], pivot_[2]);
+    std::fprintf(file, "%f %f %f\n", axis_[0], axis_[1], axis_[2]);
+    std::fclose(file);
+    return true;
+  }
 
   // registrator.cpp:331-342
   RowMatrixd getRotationMatrix(double angle) const

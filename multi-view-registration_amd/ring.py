@@ -120,7 +120,7 @@ class RingLUM:
         b.pose_clouds(poses)
         table = b.edge_rows(self.segments, self.edges, self.max_dist, self.origin)
         t1 = time.perf_counter()              # everything enqueued (asynchronous)
-        if self.world > 1:
+        if self.all_reduce is not None:
             self.all_reduce(table)            # per-pair sums/residuals of all ranks -> every rank
         rows = b.to_host(table)
         t2 = time.perf_counter()              # GPU drained, table on the host

@@ -1,0 +1,83 @@
+"""CPU tests of the host-only parts of the C++ shim (tests/cxx/host_driver.cpp):
+the reference's on-disk text formats -- transformation.txt
+(mvr/src/point_cloud.cpp:305-347) and axis.txt (mvr/src/registrator.cpp:258-308)
+--, the OSG<->Eigen matrix bridge (mvr/include/types.h:20-50), the turntable
+prior (point_cloud.cpp:400-413) and Registrator::refineAxis (:402-455)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+PIV = np.array([-13.382786, 50.223461, 917.4776])
+AX = np.array([-0.054323, -0.814921, -0.577020])
+
+
+@pytest.fixture(scope="module")
+def host(built, tmp_path_factory):
+    built.build_cxx_tests()
+    exe = os.path.join(ROOT, "tests", "cxx", "host_driver")
+    d = tmp_path_factory.mktemp("mvrfiles")
+    r = subprocess.run([exe, str(d)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout), d
+
+
+def colvec(m16):
+    """row-vector (OSG) 4x4 printed row-major -> column-vector matrix."""
+    return np.array(m16).reshape(4, 4).T
+
+
+def test_turntable_prior(host, orc):
+    out, _ = host
+    assert np.array_equal(np.array(out["prior_view0"]).reshape(4, 4), np.eye(4))
+    pf, af = PIV.astype(np.float32).astype(np.float64), AX.astype(np.float32).astype(np.float64)
+    for v, key in ((1, "prior_view1"), (7, "prior_view7")):
+        exp = orc.axis_rotation(pf, af, orc.turntable_angle(v, 12))       # registrator.cpp:331-342
+        assert np.abs(colvec(out[key]) - exp).max() < 1e-9
+    assert out["init_keeps_pose"] == 1          # initRotation only touches identity poses (point_cloud.cpp:402)
+
+
+def test_transformation_txt_format(host):
+    out, d = host
+    assert out["save_tf"] == 1 and out["load_tf"] == 1 and out["load_missing"] == 0
+    txt = open(os.path.join(d, "transformation.txt")).read()
+    rows = txt.strip("\n").split("\n")
+    assert len(rows) == 4 and all(len(r.split()) == 4 for r in rows) and all(r.endswith(" ") for r in rows)
+    # the file holds the COLUMN-vector matrix row by row (matrix(j,i), i outer), %lf = 6 decimals
+    T = colvec(out["prior_view1"])
+    file_T = np.array([[float(x) for x in r.split()] for r in rows])
+    assert np.abs(file_T - T).max() <= 5.01e-7
+    assert all(len(x.split(".")[1]) == 6 for r in rows for x in r.split())
+    assert np.abs(colvec(out["loaded_view1"]) - file_T).max() == 0          # what was written is what is read back
+    assert np.allclose(file_T[3], [0, 0, 0, 1])
+
+
+def test_axis_txt_format(host):
+    out, d = host
+    assert out["save_axis"] == 1 and out["load_axis"] == 1
+    lines = open(os.path.join(d, "axis.txt")).read().strip().split("\n")
+    assert len(lines) == 2
+    got = np.array([[float(x) for x in ln.split()] for ln in lines])
+    assert np.abs(got[0] - PIV).max() < 1e-4 and np.abs(got[1] - AX).max() < 1e-6
+    assert np.allclose(out["axis_loaded"], np.concatenate([got[0], got[1]]), atol=1e-4)
+
+
+def test_pcl_matrix_caster_is_a_transpose(host):
+    out, _ = host
+    osg = np.array(out["prior_view1"]).reshape(4, 4)
+    e = np.array(out["caster_e"]).reshape(4, 4)             # Matrix4f printed as (r,c)
+    assert np.array_equal(e.astype(np.float32), osg.T.astype(np.float32))
+    assert np.array_equal(np.array(out["caster_back"]).reshape(4, 4).astype(np.float32), osg.astype(np.float32))
+
+
+def test_refine_axis_recovers_the_turntable(host):
+    out, _ = host
+    piv, ax = np.array(out["refined"][:3]), np.array(out["refined"][3:])
+    a = AX / np.linalg.norm(AX)
+    assert abs(abs(ax @ a) - 1) < 1e-6                      # axis direction recovered
+    off = piv - PIV
+    assert np.linalg.norm(off - (off @ a) * a) < 1e-2       # pivot back on the true axis line
