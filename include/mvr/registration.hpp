@@ -91,6 +91,7 @@ class IterativeClosestPoint {
   IterativeClosestPoint()
   {
     // PCL defaults
+    p_ = mvr_icp_params();     // zero every field, incl. the point_to_plane extension switch
     p_.use_reciprocal = 0; p_.max_corr_dist = std::sqrt(DBL_MAX); p_.max_iterations = 10;
     p_.transformation_epsilon = 0.0; p_.euclidean_fitness_eps = -DBL_MAX; p_.fma_dist = 0;
   }

@@ -59,6 +59,10 @@ typedef struct {
   double euclidean_fitness_eps;   /* setEuclideanFitnessEpsilon(double)     */
   int    fma_dist;                /* 0 (spec): d2 = (dx*dx+dy*dy)+dz*dz, each op
                                      rounded (FLANN L2_Simple); 1: fma chain */
+  int    point_to_plane;          /* 0 (the reference): TransformationEstimationSVD;
+                                     1 (EXTENSION, BASELINE config 2; no counterpart in
+                                     the reference): PCL's point-to-plane LLS estimator on
+                                     the same correspondences; needs target normals */
 } mvr_icp_params;
 
 /* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
@@ -127,6 +131,12 @@ int  mvr_cloud_transform(mvr_ctx *ctx, int dst_slot, int src_slot, const double 
 /* pcl transformPointCloud / ICP::transformCloud (inside align, App. A.1):
  * x' = ((T00 x + T01 y) + T02 z) + T03 in f32, no contraction. */
 int  mvr_cloud_transform_f32(mvr_ctx *ctx, int dst_slot, int src_slot, const float T[16]);
+/* EXTENSION (point-to-plane): unit normals of the cloud in `slot`, one per point
+ * (n must equal the cloud's size; stride 16 {nx,ny,nz,*} or 12).  Normals follow
+ * the cloud through copy / transform (rotated) / append (kept only if both
+ * clouds carry normals); a new upload of points drops them. */
+int  mvr_cloud_upload_normals(mvr_ctx *ctx, int slot, const float *nxyz, size_t n, size_t stride_bytes);
+int  mvr_cloud_download_normals(mvr_ctx *ctx, int slot, float *nxyz, size_t cap_points, size_t stride_bytes, size_t *n);
 
 /* ---- the hot path ------------------------------------------------------------ */
 /* exact 1-NN of every point of q_slot in t_slot: tree_->nearestKSearch(p,1,..)

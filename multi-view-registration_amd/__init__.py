@@ -68,7 +68,7 @@ class MvrError(RuntimeError):
 class IcpParams(C.Structure):
     _fields_ = [("use_reciprocal", C.c_int), ("max_corr_dist", C.c_double),
                 ("max_iterations", C.c_int), ("transformation_epsilon", C.c_double),
-                ("euclidean_fitness_eps", C.c_double), ("fma_dist", C.c_int)]
+                ("euclidean_fitness_eps", C.c_double), ("fma_dist", C.c_int), ("point_to_plane", C.c_int)]
 
 
 class IcpStats(C.Structure):
@@ -115,6 +115,8 @@ SIGNATURES = {
     "mvr_cloud_clear": (C.c_int, [_vp, C.c_int]),
     "mvr_cloud_transform": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "mvr_cloud_transform_f32": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
+    "mvr_cloud_upload_normals": (C.c_int, [_vp, C.c_int, _fp, _sz, _sz]),
+    "mvr_cloud_download_normals": (C.c_int, [_vp, C.c_int, _fp, _sz, _sz, C.POINTER(_sz)]),
     "mvr_nn": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _u32p, _fp]),
     "mvr_correspondences": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                       _i32p, _i32p, _fp, _sz, C.POINTER(_sz)]),
@@ -176,11 +178,11 @@ def from_cm(v):
 
 # --------------------------------------------------------------- host helpers
 
-def icp_params(reciprocal=True, max_dist=4.0, max_iter=10, teps=1e-6, feps=64.0, fma=False):
+def icp_params(reciprocal=True, max_dist=4.0, max_iter=10, teps=1e-6, feps=64.0, fma=False, point_to_plane=False):
     """Defaults = the reference's settings at mvr/src/registrator.cpp:551-560
     (max_iterations is the caller's; with feps=64 every align is one iteration)."""
     return IcpParams(int(reciprocal), float(max_dist), int(max_iter), float(teps), float(feps),
-                     int(fma))
+                     int(fma), int(point_to_plane))
 
 
 def synth_params(n_views=12, config_id=0) -> SynthParams:
@@ -327,6 +329,19 @@ class Context:
         _chk(_lib.mvr_cloud_download(self._h, slot, _p(out, C.c_float), n, 12 if packed else 16,
                                      C.byref(got)), self._h)
         return out
+
+    def upload_normals(self, slot, normals):
+        nr = np.ascontiguousarray(normals, np.float32)
+        if nr.ndim != 2 or nr.shape[1] not in (3, 4):
+            raise ValueError("normals must be (n,4) or (n,3) float32")
+        _chk(_lib.mvr_cloud_upload_normals(self._h, slot, _p(nr, C.c_float), len(nr), 4 * nr.shape[1]), self._h)
+
+    def download_normals(self, slot):
+        n = self.size(slot)
+        out = np.empty((n, 4), np.float32)
+        got = _sz()
+        _chk(_lib.mvr_cloud_download_normals(self._h, slot, _p(out, C.c_float), n, 16, C.byref(got)), self._h)
+        return out[:got.value]
 
     def reserve(self, slot, cap):
         _chk(_lib.mvr_cloud_reserve(self._h, slot, cap), self._h)

@@ -145,6 +145,26 @@ int invert6(const double A[36], double Ainv[36])
   return MVR_OK;
 }
 
+// Extension (K10): pcl::registration::TransformationEstimationPointToPlaneLLS --
+// x = (A^T A)^-1 A^T b with x = (alpha, beta, gamma, tx, ty, tz), then
+// constructTransformationMatrix: R = Rz(gamma) Ry(beta) Rx(alpha), t.
+int p2plane_solve(const double ata_upper[21], const double atb[6], float T[16])
+{
+  double A[36], Ainv[36], x[6] = {0, 0, 0, 0, 0, 0};
+  int t = 0;
+  for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[6 * r + c] = ata_upper[t]; A[6 * c + r] = ata_upper[t]; ++t; }
+  if (invert6(A, Ainv) != MVR_OK) return MVR_E_SINGULAR;
+  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) x[r] += Ainv[6 * r + c] * atb[c];
+  const double ca = std::cos(x[0]), sa = std::sin(x[0]), cb = std::cos(x[1]), sb = std::sin(x[1]);
+  const double cg = std::cos(x[2]), sg = std::sin(x[2]);
+  std::memset(T, 0, 16 * sizeof(float));
+  T[0] = (float)(cg * cb);  T[4] = (float)(-sg * ca + cg * sb * sa);  T[8]  = (float)(sg * sa + cg * sb * ca);   T[12] = (float)x[3];
+  T[1] = (float)(sg * cb);  T[5] = (float)(cg * ca + sg * sb * sa);   T[9]  = (float)(-cg * sa + sg * sb * ca);  T[13] = (float)x[4];
+  T[2] = (float)(-sb);      T[6] = (float)(cb * sa);                  T[10] = (float)(cb * ca);                  T[14] = (float)x[5];
+  T[15] = 1.0f;
+  return MVR_OK;
+}
+
 int solve_dense(int n, double *A, double *b)
 {
   for (int k = 0; k < n; ++k) {

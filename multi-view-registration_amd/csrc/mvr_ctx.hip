@@ -100,6 +100,7 @@ void cloud_free(Cloud &cl)
   if (cl.sorted) (void)hipFree(cl.sorted);
   if (cl.tlo) (void)hipFree(cl.tlo);
   if (cl.thi) (void)hipFree(cl.thi);
+  if (cl.nrm) (void)hipFree(cl.nrm);
   cl.order.reset();
   cl = Cloud();
 }
@@ -294,6 +295,7 @@ API int mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, siz
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   Cloud &cl = c->slots[slot];
   cl.n = 0;
+  cl.has_normals = false;
   new_point_set(c, cl);
   if (int rc = cloud_reserve(c, cl, n, false)) return rc;
   if (n) {
@@ -340,6 +342,59 @@ API int mvr_cloud_download(mvr_ctx *ctx, int slot, float *xyz, size_t cap, size_
   return MVR_OK;
 }
 
+// EXTENSION (point-to-plane): normals ride along with the points
+API int mvr_cloud_upload_normals(mvr_ctx *ctx, int slot, const float *nxyz, size_t n, size_t stride)
+{
+  if (!ctx || !slot_ok(slot) || (n && !nxyz) || (stride != 16 && stride != 12)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &cl = c->slots[slot];
+  if (n != cl.n) return set_error(c, MVR_E_ARG, "normals: one per point expected");
+  cl.has_normals = false;
+  if (n == 0) return MVR_OK;
+  if (int rc = ensure(c, cl.nrm, cl.nrm_cap, n)) return rc;
+  if (stride == 16) {
+    MVR_HIP_TRY(c, hipMemcpyAsync(cl.nrm, nxyz, n * 16, hipMemcpyHostToDevice, c->stream));
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    float *tmp = nullptr;
+    MVR_HIP_TRY(c, hipMalloc(&tmp, n * 12));
+    hipError_t e = hipMemcpyAsync(tmp, nxyz, n * 12, hipMemcpyHostToDevice, c->stream);
+    int rc = (e == hipSuccess) ? launch_unpack_xyz(c, tmp, cl.nrm, n) : set_error(c, MVR_E_HIP, "upload normals", e);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+  }
+  cl.has_normals = true;
+  return MVR_OK;
+}
+
+API int mvr_cloud_download_normals(mvr_ctx *ctx, int slot, float *nxyz, size_t cap, size_t stride, size_t *n)
+{
+  if (!ctx || !slot_ok(slot) || (stride != 16 && stride != 12)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const Cloud &cl = c->slots[slot];
+  const size_t have = cl.has_normals ? cl.n : 0;
+  if (n) *n = have;
+  const size_t m = std::min(cap, have);
+  if (!m || !nxyz) return MVR_OK;
+  if (stride == 16) {
+    MVR_HIP_TRY(c, hipMemcpyAsync(nxyz, cl.nrm, m * 16, hipMemcpyDeviceToHost, c->stream));
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    float *tmp = nullptr;
+    MVR_HIP_TRY(c, hipMalloc(&tmp, m * 12));
+    int rc = launch_pack_xyz(c, cl.nrm, tmp, m);
+    hipError_t e = hipMemcpyAsync(nxyz, tmp, m * 12, hipMemcpyDeviceToHost, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_error(c, MVR_E_HIP, "download normals", e);
+  }
+  return MVR_OK;
+}
+
 API int mvr_cloud_size(mvr_ctx *ctx, int slot, size_t *n)
 {
   if (!ctx || !slot_ok(slot) || !n) return MVR_E_ARG;
@@ -352,6 +407,7 @@ API int mvr_cloud_clear(mvr_ctx *ctx, int slot)
   if (!ctx || !slot_ok(slot)) return MVR_E_ARG;
   Ctx *c = CTX(ctx);
   c->slots[slot].n = 0;
+  c->slots[slot].has_normals = false;
   new_point_set(c, c->slots[slot]);
   return MVR_OK;
 }
@@ -371,6 +427,12 @@ API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
   }
   d.n = s.n;
   inherit_point_set(d, s);
+  d.has_normals = false;
+  if (s.has_normals && s.n) {
+    if (int rc = ensure(c, d.nrm, d.nrm_cap, s.n)) return rc;
+    MVR_HIP_TRY(c, hipMemcpyAsync(d.nrm, s.nrm, s.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    d.has_normals = true;
+  }
   return MVR_OK;
 }
 
@@ -387,6 +449,21 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
     ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)add);
     MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     new_point_set(c, d);                      // a different point set: its order is rebuilt on next use
+    // normals survive only if both parts carry them
+    const bool keep = s.has_normals && (d.has_normals || d.n == 0);
+    if (keep) {
+      if (d.nrm_cap < d.n + add) {
+        float4 *nn = nullptr;
+        const size_t ncap = std::max(d.n + add, d.cap);
+        MVR_HIP_TRY(c, hipMalloc(&nn, ncap * sizeof(float4)));
+        if (d.n) MVR_HIP_TRY(c, hipMemcpyAsync(nn, d.nrm, d.n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (d.nrm) (void)hipFree(d.nrm);
+        d.nrm = nn; d.nrm_cap = ncap;
+      }
+      MVR_HIP_TRY(c, hipMemcpyAsync(d.nrm + d.n, s.nrm, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    }
+    d.has_normals = keep;
   }
   d.n += add;
   return MVR_OK;
@@ -403,6 +480,11 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   c->slots[dst].n = n;
   if (dst != src) inherit_point_set(c->slots[dst], c->slots[src]);
   c->slots[dst].coords_valid = false;
+  if (c->slots[src].has_normals && n) {
+    if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
+    if (int rc = launch_rotate_normals_f64(c, c->slots[src].nrm, c->slots[dst].nrm, n, T)) return rc;
+  }
+  c->slots[dst].has_normals = c->slots[src].has_normals;
   return MVR_OK;
 }
 
@@ -417,6 +499,11 @@ API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16
   c->slots[dst].n = n;
   if (dst != src) inherit_point_set(c->slots[dst], c->slots[src]);
   c->slots[dst].coords_valid = false;
+  if (c->slots[src].has_normals && n) {
+    if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
+    if (int rc = launch_rotate_normals_f32(c, c->slots[src].nrm, c->slots[dst].nrm, n, T)) return rc;
+  }
+  c->slots[dst].has_normals = c->slots[src].has_normals;
   return MVR_OK;
 }
 
@@ -579,6 +666,8 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_ms();
   const size_t ns = c->slots[ss].n;
+  if (p->point_to_plane && c->slots[ts].n && !c->slots[ts].has_normals)
+    return set_error(c, MVR_E_ARG, "point-to-plane needs target normals (mvr_cloud_upload_normals)");
   // App. A.1: input_transformed = *input (guess == identity)
   Cloud &cur = c->slots[kScratchCur];
   cur.n = 0;
@@ -604,14 +693,23 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, c->slot, c->count, plan.qperm, plan.tinv, 0, ns,
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
-    if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
-    if (int rc = read_moments(c, 18)) return rc;
+    if (p->point_to_plane) {
+      if (int rc = launch_p2plane(c, cur.pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc;
+      if (int rc = read_moments(c, 64)) return rc;
+    } else {
+      if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
+      if (int rc = read_moments(c, 18)) return rc;
+    }
     const double *h = c->h_moments;
     fwdq += (double)ns;
     evals += (c->nn_mode != 0) ? 0.0 : ev + h[17] * (double)ns;   // forward Ns*Nt + reverse Nt'*Ns (brute force)
     ncorr = (int)h[0];
     if (h[0] < 3.0) { state = MVR_CONV_NO_CORRESPONDENCES; converged = 0; status = MVR_E_NOCORR; break; }
-    umeyama_from_moments(h + 1, h + 4, h + 8, tr, nullptr);
+    if (p->point_to_plane) {
+      if (p2plane_solve(h + 32, h + 32 + 21, tr) != MVR_OK) { state = MVR_CONV_NO_CORRESPONDENCES; converged = 0; status = MVR_E_SINGULAR; break; }
+    } else {
+      umeyama_from_moments(h + 1, h + 4, h + 8, tr, nullptr);
+    }
     cur_mse = h[7];
     if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
     cur.coords_valid = false;
@@ -635,6 +733,11 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     c->slots[os].n = ns;
     if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
     c->slots[os].coords_valid = false;
+    if (c->slots[ss].has_normals && ns) {      // ICP::transformCloud rotates the source normals too
+      if (int rc = ensure(c, c->slots[os].nrm, c->slots[os].nrm_cap, ns)) return rc;
+      if (int rc = launch_rotate_normals_f32(c, c->slots[ss].nrm, c->slots[os].nrm, ns, fin)) return rc;
+    }
+    c->slots[os].has_normals = c->slots[ss].has_normals;
   }
   std::memcpy(T_out, fin, sizeof fin);
   if (st && c->nn_mode != 0) {

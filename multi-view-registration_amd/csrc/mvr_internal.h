@@ -39,6 +39,9 @@ struct Cloud {
   float4 *sorted = nullptr; size_t sorted_cap = 0;
   float4 *tlo = nullptr, *thi = nullptr; size_t tiles_cap = 0;
   bool coords_valid = false;           // sorted[] / tlo / thi match pts[]
+  // optional unit normals {nx,ny,nz,0} (point-to-plane extension, K10)
+  float4 *nrm = nullptr; size_t nrm_cap = 0;
+  bool has_normals = false;
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;      // "no neighbour" index
@@ -185,6 +188,13 @@ int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *ma
 // raw second moments about `origin` into out[0..31] (device pointer)
 int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
                     size_t q_begin, size_t q_count, const double origin[3], double *out);
+// K10 (extension): point-to-plane normal equations over the accepted pairs:
+// out[0..20] = upper triangle of sum a a^T (a = [p x n, n]), out[21..26] = sum a*d,
+// out[27] = count, out[28] = sum d^2  (d = n . (q - p)); device pointer
+int launch_p2plane(Ctx *c, const float4 *src, const float4 *tgt, const float4 *tnrm, const int32_t *match,
+                   const uint32_t *qperm, size_t q_begin, size_t q_count, double *out);
+int launch_rotate_normals_f32(Ctx *c, const float4 *in, float4 *out, size_t n, const float T[16]);
+int launch_rotate_normals_f64(Ctx *c, const float4 *in, float4 *out, size_t n, const double T[16]);
 int launch_fitness(Ctx *c, const nnkey_t *keys, size_t n, double max_range, double *moments);
 int launch_transform_f32(Ctx *c, const float4 *in, float4 *out, size_t n, const float T[16]);
 int launch_transform_f64(Ctx *c, const float4 *in, float4 *out, size_t n, const double T[16]);
@@ -196,6 +206,8 @@ int launch_decode_keys(Ctx *c, const nnkey_t *keys, size_t n, uint32_t *idx, flo
 void svd3(const double A[9], double U[9], double S[3], double V[9]);
 void umeyama_from_moments(const double mean_src[3], const double mean_tgt[3],
                           const double sigma[9], float T[16], double sv[3]);
+// pcl TransformationEstimationPointToPlaneLLS: x = (A^T A)^-1 A^T b, T = Rz(g) Ry(b) Rx(a) + t
+int p2plane_solve(const double ata_upper[21], const double atb[6], float T[16]);
 int invert6(const double A[36], double Ainv[36]);
 int solve_dense(int n, double *A, double *b);
 

@@ -301,6 +301,82 @@ __global__ void __launch_bounds__(kRT) moments2_final_kernel(const double *__res
   }
 }
 
+// -------------------------------------------------------------- K10 point-to-plane
+// Extension (BASELINE config 2; no counterpart in the reference).
+// PCL TransformationEstimationPointToPlaneLLS: row a = [p x n, n], d = n.(q - p),
+// all in double.  acc: 0..20 upper triangle of a a^T (row-major), 21..26 a*d, 27 count, 28 d^2
+__global__ void __launch_bounds__(kRT)
+p2plane_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const float4 *__restrict__ tnrm,
+               const int32_t *__restrict__ match, const uint32_t *__restrict__ qperm, size_t q_begin, size_t q_count,
+               double *__restrict__ partials)
+{
+  double acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
+    const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
+    const int32_t j = match[i];
+    if (j < 0) continue;
+    const float4 p = src[i], q = tgt[j], n4 = tnrm[j];
+    const double sx = p.x, sy = p.y, sz = p.z, nx = n4.x, ny = n4.y, nz = n4.z;
+    double a[6];
+    a[0] = nz * sy - ny * sz; a[1] = nx * sz - nz * sx; a[2] = ny * sx - nx * sy;
+    a[3] = nx; a[4] = ny; a[5] = nz;
+    const double d = nx * (double)q.x + ny * (double)q.y + nz * (double)q.z - nx * sx - ny * sy - nz * sz;
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = r; cc < 6; ++cc) acc[t++] += a[r] * a[cc];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * d;
+    acc[27] += 1.0;
+    acc[28] += d * d;
+  }
+  block_partials<29>(acc, partials);
+}
+
+__global__ void __launch_bounds__(kRT) p2plane_final_kernel(const double *__restrict__ partials, int rows,
+                                                             double *__restrict__ out)
+{
+  double s[29];
+  sum_rows<29>(partials, rows, s, nullptr);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 29; ++k) out[k] = s[k];
+}
+
+struct Mat33f { float m[9]; };
+struct Mat33d { double m[9]; };
+
+// normals rotate with the cloud: n' = R n, same operation order as the points, no translation
+__global__ void rotate_normals_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n, Mat33f R)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = in[i];
+  float4 o;
+  o.x = (R.m[0] * v.x + R.m[1] * v.y) + R.m[2] * v.z;
+  o.y = (R.m[3] * v.x + R.m[4] * v.y) + R.m[5] * v.z;
+  o.z = (R.m[6] * v.x + R.m[7] * v.y) + R.m[8] * v.z;
+  o.w = 0.0f;
+  out[i] = o;
+}
+
+__global__ void rotate_normals_f64_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n, Mat33d R)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = in[i];
+  const double x = v.x, y = v.y, z = v.z;
+  float4 o;
+  o.x = (float)((R.m[0] * x + R.m[1] * y) + R.m[2] * z);
+  o.y = (float)((R.m[3] * x + R.m[4] * y) + R.m[5] * z);
+  o.z = (float)((R.m[6] * x + R.m[7] * y) + R.m[8] * z);
+  o.w = 0.0f;
+  out[i] = o;
+}
+
 // -------------------------------------------------------------- K7 fitness
 __global__ void __launch_bounds__(kRT)
 fitness_kernel(const nnkey_t *__restrict__ keys, size_t n, double max_range, double *__restrict__ partials)
@@ -434,6 +510,39 @@ int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t 
   hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, qperm, q_begin, q_count,
                      o, c->partials);
   hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_p2plane(Ctx *c, const float4 *src, const float4 *tgt, const float4 *tnrm, const int32_t *match,
+                   const uint32_t *qperm, size_t q_begin, size_t q_count, double *out)
+{
+  const int blocks = reduce_blocks(c, q_count);
+  if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
+  ProfScope ps(c, MVR_K_REDUCE, 32.0 * (double)q_count);
+  hipLaunchKernelGGL(p2plane_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, tnrm, match, qperm, q_begin,
+                     q_count, c->partials);
+  hipLaunchKernelGGL(p2plane_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, out);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_rotate_normals_f32(Ctx *c, const float4 *in, float4 *out, size_t n, const float T[16])
+{
+  if (n == 0) return MVR_OK;
+  Mat33f R;
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) R.m[3 * r + k] = T[r + 4 * k];
+  hipLaunchKernelGGL(rotate_normals_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, out, n, R);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_rotate_normals_f64(Ctx *c, const float4 *in, float4 *out, size_t n, const double T[16])
+{
+  if (n == 0) return MVR_OK;
+  Mat33d R;
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) R.m[3 * r + k] = T[r + 4 * k];
+  hipLaunchKernelGGL(rotate_normals_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, out, n, R);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }

@@ -79,6 +79,11 @@ def lib():
         L.orc_icp_align.restype = C.c_int
         L.orc_icp_align.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.POINTER(IcpParams),
                                     fp, fp, C.POINTER(IcpStats)]
+        L.orc_p2plane.restype = C.c_int
+        L.orc_p2plane.argtypes = [fp, fp, fp, vp, C.c_size_t, fp, dp]
+        L.orc_icp_align_p2plane.restype = C.c_int
+        L.orc_icp_align_p2plane.argtypes = [fp, C.c_size_t, fp, fp, C.c_size_t, C.POINTER(IcpParams),
+                                            fp, fp, C.POINTER(IcpStats)]
         L.orc_fitness.restype = C.c_double
         L.orc_fitness.argtypes = [fp, C.c_size_t, fp, C.c_size_t, fp, C.c_double,
                                   C.c_int, C.c_int]
@@ -218,6 +223,28 @@ def icp_align(src, tgt, params: IcpParams):
                              C.byref(params), _p(out, C.c_float), _p(T, C.c_float), C.byref(st))
     stats = dict(iterations=st.iterations, converged=bool(st.converged),
                  state=CONV_STATES[st.state], n_corr=st.n_corr, mse=st.mse, evals=st.evals)
+    return out, from_cm(T), stats, rc
+
+
+def p2plane(src, tgt, tnrm, corr):
+    """EXTENSION: point-to-plane LLS estimate -> (T (4,4) float32, sums[29]) or (None, None)."""
+    src, tgt, tnrm = _pts(src), _pts(tgt), _pts(tnrm)
+    corr = np.ascontiguousarray(corr, dtype=CORR_DTYPE)
+    T, sums = np.empty(16, np.float32), np.empty(29, np.float64)
+    rc = lib().orc_p2plane(_p(src, C.c_float), _p(tgt, C.c_float), _p(tnrm, C.c_float), corr.ctypes.data, len(corr),
+                           _p(T, C.c_float), _p(sums, C.c_double))
+    return (from_cm(T), sums) if rc == 0 else (None, None)
+
+
+def icp_align_p2plane(src, tgt, tnrm, params: IcpParams):
+    src, tgt, tnrm = _pts(src), _pts(tgt), _pts(tnrm)
+    out = np.empty_like(src)
+    T = np.empty(16, np.float32)
+    st = IcpStats()
+    rc = lib().orc_icp_align_p2plane(_p(src, C.c_float), len(src), _p(tgt, C.c_float), _p(tnrm, C.c_float), len(tgt),
+                                     C.byref(params), _p(out, C.c_float), _p(T, C.c_float), C.byref(st))
+    stats = dict(iterations=st.iterations, converged=bool(st.converged), state=CONV_STATES[st.state],
+                 n_corr=st.n_corr, mse=st.mse, evals=st.evals)
     return out, from_cm(T), stats, rc
 
 

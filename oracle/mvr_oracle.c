@@ -439,8 +439,41 @@ API int orc_umeyama(const float *src, const float *tgt, const orc_corr *c, size_
 /* --------------------------------------------------------------------- ICP */
 
 /* a4 + a7 / App. A.1 + A.4.  Call sites mvr/src/registrator.cpp:569,920,1012,1024. */
-API int orc_icp_align(const float *src, size_t ns, const float *tgt, size_t nt,
-                      const orc_icp_params *p, float *out, float T[16], orc_icp_stats *st)
+/* EXTENSION: pcl TransformationEstimationPointToPlaneLLS (all sums in double, in
+ * correspondence order).  sums29: 21 upper-triangle of A^T A, 6 of A^T d, count, sum d^2. */
+API int orc_p2plane(const float *src, const float *tgt, const float *tnrm, const orc_corr *c, size_t m,
+                    float T[16], double *sums29)
+{
+  if (m < 3) return -1;
+  double acc[29] = { 0 };
+  for (size_t k = 0; k < m; ++k) {
+    const float *p = src + 4 * (size_t)c[k].query, *q = tgt + 4 * (size_t)c[k].match, *n = tnrm + 4 * (size_t)c[k].match;
+    double sx = p[0], sy = p[1], sz = p[2], nx = n[0], ny = n[1], nz = n[2];
+    double a[6] = { nz * sy - ny * sz, nx * sz - nz * sx, ny * sx - nx * sy, nx, ny, nz };
+    double d = nx * (double)q[0] + ny * (double)q[1] + nz * (double)q[2] - nx * sx - ny * sy - nz * sz;
+    int t = 0;
+    for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) acc[t++] += a[r] * a[cc];
+    for (int r = 0; r < 6; ++r) acc[21 + r] += a[r] * d;
+    acc[27] += 1.0; acc[28] += d * d;
+  }
+  if (sums29) memcpy(sums29, acc, sizeof acc);
+  double A[36], Ainv[36], x[6] = { 0 };
+  int t = 0;
+  for (int r = 0; r < 6; ++r) for (int cc = r; cc < 6; ++cc) { A[6 * r + cc] = A[6 * cc + r] = acc[t++]; }
+  if (orc_invert6(A, Ainv) != 0) return -2;
+  for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) x[r] += Ainv[6 * r + cc] * acc[21 + cc];
+  /* constructTransformationMatrix(alpha, beta, gamma, tx, ty, tz) */
+  double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+  memset(T, 0, 16 * sizeof(float));
+  T[0] = (float)(cg * cb); T[4] = (float)(-sg * ca + cg * sb * sa); T[8]  = (float)(sg * sa + cg * sb * ca);  T[12] = (float)x[3];
+  T[1] = (float)(sg * cb); T[5] = (float)(cg * ca + sg * sb * sa);  T[9]  = (float)(-cg * sa + sg * sb * ca); T[13] = (float)x[4];
+  T[2] = (float)(-sb);     T[6] = (float)(cb * sa);                 T[10] = (float)(cb * ca);                 T[14] = (float)x[5];
+  T[15] = 1.0f;
+  return 0;
+}
+
+static int icp_align_impl(const float *src, size_t ns, const float *tgt, const float *tnrm, size_t nt,
+                          const orc_icp_params *p, float *out, float T[16], orc_icp_stats *st)
 {
   float *cur = malloc((ns ? ns : 1) * 16);
   orc_corr *corr = malloc((ns ? ns : 1) * sizeof(orc_corr));
@@ -463,6 +496,7 @@ API int orc_icp_align(const float *src, size_t ns, const float *tgt, size_t nt,
     double mom[20];
     orc_umeyama(cur, tgt, corr, m, tr, mom);
     cur_mse = mom[7];
+    if (tnrm && orc_p2plane(cur, tgt, tnrm, corr, m, tr, NULL) != 0) { state = ORC_CONV_NO_CORRESPONDENCES; converged = 0; break; }
     orc_transform_f32(tr, cur, cur, ns);
     orc_mat4f_mul(tr, fin, fin);
     ++iters;
@@ -484,6 +518,18 @@ API int orc_icp_align(const float *src, size_t ns, const float *tgt, size_t nt,
   if (st) { st->iterations = iters; st->converged = converged; st->state = state; st->n_corr = ncorr; st->mse = cur_mse; st->evals = evals; }
   free(cur); free(corr);
   return state == ORC_CONV_NO_CORRESPONDENCES ? -1 : 0;
+}
+
+API int orc_icp_align(const float *src, size_t ns, const float *tgt, size_t nt,
+                      const orc_icp_params *p, float *out, float T[16], orc_icp_stats *st)
+{
+  return icp_align_impl(src, ns, tgt, NULL, nt, p, out, T, st);
+}
+
+API int orc_icp_align_p2plane(const float *src, size_t ns, const float *tgt, const float *tnrm, size_t nt,
+                              const orc_icp_params *p, float *out, float T[16], orc_icp_stats *st)
+{
+  return icp_align_impl(src, ns, tgt, tnrm, nt, p, out, T, st);
 }
 
 /* a8 / App. A.5.  mvr/src/registrator.cpp:572,923,1015. */

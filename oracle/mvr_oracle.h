@@ -101,6 +101,17 @@ int    orc_icp_align(const float *src, size_t ns, const float *tgt, size_t nt,
                      const orc_icp_params *p, float *out, float T[16],
                      orc_icp_stats *st);
 
+/* EXTENSION (BASELINE config 2; NO counterpart in the reference):
+ * pcl::registration::TransformationEstimationPointToPlaneLLS on the same
+ * correspondences: rows a = [p x n_q, n_q], d = n_q . (q - p), x = (A^T A)^-1 A^T d,
+ * T = Rz(x2) Ry(x1) Rx(x0) + (x3,x4,x5).  tnrm: target normals (stride 4 floats).
+ * Returns 0, -1 for < 3 pairs, -2 for a singular system. */
+int    orc_p2plane(const float *src, const float *tgt, const float *tnrm, const orc_corr *c, size_t m,
+                   float T[16], double *sums29);
+/* orc_icp_align with the point-to-plane estimator instead of Umeyama. */
+int    orc_icp_align_p2plane(const float *src, size_t ns, const float *tgt, const float *tnrm, size_t nt,
+                             const orc_icp_params *p, float *out, float T[16], orc_icp_stats *st);
+
 /* a8: Registration::getFitnessScore(max_range). input = cloud handed to
  * setInputSource; T = final transformation. */
 double orc_fitness(const float *input, size_t ns, const float *tgt, size_t nt,

@@ -261,3 +261,36 @@ def test_full_size_200k_pair(gpu, orc, mvr):
         assert st["evals"] >= 200000.0 * 200000.0
     else:       # the culled kernel evaluates a small fraction of the pairs, with identical results
         assert 200000.0 * 256 <= st["evals"] < 0.2 * 200000.0 * 200000.0
+
+
+# ------------------------------------------------- point-to-plane (extension)
+
+def test_point_to_plane_extension(gpu, orc, mvr):
+    """BASELINE config 2 shape (2 scans, point-to-plane ICP).  No counterpart in
+    the reference: parity is GPU vs this repo's own oracle."""
+    sp = mvr.synth_params(12, 11)
+    tgt, tn = mvr.synth_view(sp, 0, 30000, normals=True)
+    raw = mvr.synth_view(sp, 1, 30000)
+    piv, ax = mvr.synth_prior(sp)
+    prior = mvr.axis_rotation(piv, ax, mvr.turntable_angle(1, 12))
+    src = orc.transform_f64(prior, raw)
+    gpu.upload(0, tgt); gpu.upload_normals(0, tn); gpu.upload(1, src)
+    assert np.array_equal(gpu.download_normals(0)[:, :3], tn[:, :3])
+    for kw in (dict(), dict(max_iter=4, teps=0.0, feps=-1e300)):
+        T, st, rc = gpu.icp_align(1, 0, 2, mvr.icp_params(point_to_plane=True, **kw))
+        out, To, sto, _ = orc.icp_align_p2plane(src, tgt, tn, orc.make_params(**kw))
+        assert rc == 0 and st["iterations"] == sto["iterations"] and abs(st["n_corr"] - sto["n_corr"]) <= 2
+        assert_pose_close(T, To)
+    # point-to-plane converges faster than point-to-point on this surface
+    Tp, stp, _ = gpu.icp_align(1, 0, 2, mvr.icp_params(max_iter=4, teps=0.0, feps=-1e300))
+    assert st["mse"] < stp["mse"]
+    # normals follow the cloud: rotate with a transform, drop on a fresh upload
+    gpu.transform(3, 0, prior)
+    rn = gpu.download_normals(3)
+    assert np.abs(rn[:, :3] - tn[:, :3].astype(np.float64) @ prior[:3, :3].T).max() < 1e-6
+    gpu.upload(3, src)
+    assert len(gpu.download_normals(3)) == 0
+    # without target normals the estimator is refused loudly
+    gpu.upload(4, tgt)
+    with pytest.raises(mvr.MvrError):
+        gpu.icp_align(1, 4, 2, mvr.icp_params(point_to_plane=True))

@@ -304,3 +304,24 @@ def test_solve_dense(orc):
     A = rng.standard_normal((20, 20)) + 5 * np.eye(20); b = rng.standard_normal(20)
     assert np.allclose(orc.solve_dense(A, b), np.linalg.solve(A, b))
     assert orc.solve_dense(np.zeros((3, 3)), np.ones(3)) is None
+
+
+# ------------------------------------------------- point-to-plane (extension)
+
+def test_p2plane_kat_recovers_small_motion(orc, mvr):
+    """EXTENSION (no reference counterpart): PCL's linearised point-to-plane
+    estimator recovers a small known rigid motion from exact correspondences."""
+    sp = mvr.synth_params(12, 4)
+    tgt, nrm = mvr.synth_view(sp, 0, 4000, normals=True)
+    ang, t = 0.004, np.array([0.05, -0.03, 0.02])
+    R = rot([0.2, 1.0, -0.4], ang)
+    src = tgt.copy()
+    src[:, :3] = ((tgt[:, :3].astype(np.float64) - t) @ R).astype(np.float32)      # src = R^T (tgt - t)
+    corr = np.zeros(4000, orc.CORR_DTYPE); corr["query"] = corr["match"] = np.arange(4000)
+    T, sums = orc.p2plane(src, tgt, nrm, corr)
+    assert sums[27] == 4000
+    assert np.abs(T[:3, :3] - R).max() < 2e-5 and np.abs(T[:3, 3] - t).max() < 2e-2    # linearisation error ~ angle^2/2 * |p| (|p| ~ 920 mm)
+    moved = src[:, :3].astype(np.float64) @ T[:3, :3].T.astype(np.float64) + T[:3, 3]
+    d = ((moved - tgt[:, :3]) * nrm[:, :3]).sum(1)
+    assert np.abs(d).max() < 2e-2
+    assert orc.p2plane(src, tgt, nrm, corr[:2])[0] is None
