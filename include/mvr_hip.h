@@ -47,7 +47,7 @@ typedef enum {
   MVR_E_SINGULAR= -5    /* singular system in a host solve (LUM)            */
 } mvr_status;
 
-#define MVR_MAX_SLOTS 64
+#define MVR_MAX_SLOTS 256
 
 /* ---- parameters of one IterativeClosestPoint::align ----------------------
  * Setters at mvr/src/registrator.cpp:551-560, :768-771, :901-904.           */
@@ -210,6 +210,13 @@ int  mvr_lum_edge_from_moments(const mvr_pair_moments2_t *m2, const double pose_
 int  mvr_lum_compute(int n, int ne, const int *edge_src, const int *edge_tgt,
                      const mvr_pair_moments2_t *edge_m2, int max_iterations,
                      double convergence_threshold, double *poses, int *iters);
+/* the host side of one global step of registrationLUM (registrator.cpp:650-662)
+ * from the (all-reduced) ne x 32 edge table: per-pair Umeyama + residual,
+ * LUM::compute, pose_v <- LUM_v * pose_v (poses: n_views x 16 column-major,
+ * in/out; vertex 0 fixed).  pair_T (ne x 16) may be NULL. */
+int  mvr_ring_host_step(int n_views, int ne, const int *edge_src, const int *edge_tgt, const double *rows,
+                        const double origin[3], int lum_iterations, double *poses, double *lum_pose,
+                        float *pair_T, double *pair_n, double *pair_mse, int *lum_iters);
 /* pcl::getTransformation(x,y,z,roll,pitch,yaw) -> column-major 4x4. */
 void mvr_pose_to_mat4(const double pose[6], double T[16]);
 

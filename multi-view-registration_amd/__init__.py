@@ -51,7 +51,7 @@ def _share_hip_runtime_with_torch():
 _share_hip_runtime_with_torch()
 _lib = C.CDLL(LIB_PATH)
 
-MAX_SLOTS = 64
+MAX_SLOTS = 256
 OK, E_ARG, E_HIP, E_NOCORR, E_NOMEM, E_SINGULAR = 0, -1, -2, -3, -4, -5
 CONV_STATES = ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
                "NO_CORRESPONDENCES")
@@ -137,6 +137,8 @@ SIGNATURES = {
     "mvr_lum_compute": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(PairMoments2), C.c_int, C.c_double, _dp,
                                   C.POINTER(C.c_int)]),
+    "mvr_ring_host_step": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int,
+                                     _dp, _dp, _fp, _dp, _dp, C.POINTER(C.c_int)]),
     "mvr_pose_to_mat4": (None, [_dp, _dp]),
     "mvr_turntable_angle": (C.c_double, [C.c_int, C.c_int]),
     "mvr_axis_rotation": (None, [_dp, _dp, C.c_double, _dp]),
@@ -266,6 +268,26 @@ def lum_edge_from_moments(m2: PairMoments2, pose_s, pose_t):
     rc = _lib.mvr_lum_edge_from_moments(C.byref(m2), _p(ps, C.c_double), _p(pt, C.c_double),
                                         _p(MM, C.c_double), _p(MZ, C.c_double), C.byref(ss))
     return rc, MM.reshape(6, 6), MZ, ss.value
+
+
+def ring_host_step(n_views, edges, rows, origin, poses, lum_iterations=16):
+    """One call for the host side of a global step.  rows: (ne, 32) float64 edge
+    table; poses: list of (4,4) float64.  Returns (rc, new_poses, info dict)."""
+    ne = len(edges)
+    es = (C.c_int * ne)(*[e[0] for e in edges])
+    et = (C.c_int * ne)(*[e[1] for e in edges])
+    R = np.ascontiguousarray(rows, np.float64).reshape(ne, 32)
+    o = np.ascontiguousarray(origin, np.float64)
+    P = np.ascontiguousarray(np.stack([np.asarray(p, np.float64).T for p in poses])).reshape(n_views, 16)
+    lum = np.zeros((n_views, 6))
+    pT, pn, pm, its = np.empty((ne, 16), np.float32), np.empty(ne), np.empty(ne), C.c_int()
+    rc = _lib.mvr_ring_host_step(n_views, ne, es, et, _p(R, C.c_double), _p(o, C.c_double), int(lum_iterations),
+                                 _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float), _p(pn, C.c_double),
+                                 _p(pm, C.c_double), C.byref(its))
+    new = [P[v].reshape(4, 4).T.copy() for v in range(n_views)]
+    info = dict(pair_T=[pT[e].reshape(4, 4).T.copy() for e in range(ne)], pair_n=list(pn), pair_mse=list(pm),
+                lum_pose=lum, lum_iterations=its.value)
+    return rc, new, info
 
 
 def lum_compute(n, edges, moments2, max_iterations=5, threshold=0.0, poses=None):

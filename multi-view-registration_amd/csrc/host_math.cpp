@@ -389,6 +389,43 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   return MVR_OK;
 }
 
+// The whole host side of one global step (registrator.cpp:650-662) in one call:
+// per-pair Umeyama + residual from the all-reduced edge table, LUM::compute,
+// pose_v <- LUM_v (as Eigen::Affine3f) * pose_v.  rows: ne x 32 doubles
+// {n, origin[3], sp, sq, spp, sqq, spq, 0}; poses: n_views x 16 column-major, in/out.
+API int mvr_ring_host_step(int n_views, int ne, const int *es, const int *et, const double *rows, const double origin[3],
+                           int lum_iterations, double *poses, double *lum_pose /* n_views*6, out */,
+                           float *pair_T /* ne*16, out, may be NULL */, double *pair_n /* ne */, double *pair_mse /* ne */,
+                           int *lum_iters)
+{
+  if (n_views < 2 || ne < 0 || !es || !et || !rows || !origin || !poses || !lum_pose) return MVR_E_ARG;
+  std::vector<mvr_pair_moments2_t> m2((size_t)ne);
+  for (int e = 0; e < ne; ++e) {
+    std::memcpy(&m2[e], rows + 32 * (size_t)e, sizeof(mvr_pair_moments2_t));
+    for (int k = 0; k < 3; ++k) m2[e].origin[k] = origin[k];     // a constant, not a sum over ranks
+    mvr_pair_moments_t pm;
+    mvr_moments_from_moments2(&m2[e], &pm);
+    if (pair_n) pair_n[e] = pm.n;
+    if (pair_mse) pair_mse[e] = pm.mse;
+    if (pair_T) {
+      float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      if (pm.n >= 3.0) umeyama_from_moments(pm.mean_src, pm.mean_tgt, pm.sigma, T, nullptr);
+      std::memcpy(pair_T + 16 * (size_t)e, T, sizeof T);
+    }
+  }
+  std::fill(lum_pose, lum_pose + 6 * (size_t)n_views, 0.0);
+  const int rc = mvr_lum_compute(n_views, ne, es, et, m2.data(), lum_iterations, 0.0, lum_pose, lum_iters);
+  if (rc != MVR_OK) return rc;
+  for (int v = 1; v < n_views; ++v) {
+    double L[16], Lf[16], P[16];
+    mvr_pose_to_mat4(lum_pose + 6 * (size_t)v, L);
+    for (int k = 0; k < 16; ++k) Lf[k] = (double)(float)L[k];        // lum.getTransformation(i) is an Eigen::Affine3f
+    mvr_mat4d_mul(Lf, poses + 16 * (size_t)v, P);
+    std::memcpy(poses + 16 * (size_t)v, P, sizeof P);
+  }
+  return MVR_OK;
+}
+
 API double mvr_turntable_angle(int view, int n_views)
 {
   // point_cloud.cpp:409: ((view<7)?(-view):(12-view))*M_PI/6, generalised to V views

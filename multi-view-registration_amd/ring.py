@@ -23,8 +23,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import (Context, lum_compute, mat4d_mul, moments2_from_row, moments_from_moments2,
-               pose_to_mat4, umeyama_from_moments)
+from . import Context, ring_host_step
 
 ROW = 32   # doubles per edge row: {n, origin[3], sp[3], sq[3], spp[6], sqq[6], spq[9], 0}
 
@@ -110,6 +109,7 @@ class RingLUM:
         self.lum_iterations = lum_iterations
         # edge e's queries are the points of its SOURCE view
         self.segments = split_queries([sizes[s] for s, _ in self.edges], world, rank)
+        self.views_needed = sorted({v for e, _, _ in self.segments for v in self.edges[e]})
         self.last = {}
 
     def step(self, poses):
@@ -117,34 +117,21 @@ class RingLUM:
         import time
         b = self.b
         t0 = time.perf_counter()
-        b.pose_clouds(poses)
+        b.pose_clouds(poses, self.views_needed)     # only the scans this rank's segments touch
         table = b.edge_rows(self.segments, self.edges, self.max_dist, self.origin)
         t1 = time.perf_counter()              # everything enqueued (asynchronous)
         if self.all_reduce is not None:
             self.all_reduce(table)            # per-pair sums/residuals of all ranks -> every rank
         rows = b.to_host(table)
         t2 = time.perf_counter()              # GPU drained, table on the host
-        m2s = []
-        for e in range(len(self.edges)):
-            r = np.array(rows[e], np.float64)
-            r[1:4] = self.origin              # a constant, not a sum
-            m2s.append(moments2_from_row(r))
-        pair_T, pair_n, pair_mse = [], [], []
-        for m2 in m2s:                        # per-pair rigid solve: host 3x3 SVD on the moments
-            pm = moments_from_moments2(m2)
-            T, _ = umeyama_from_moments(pm)
-            pair_T.append(T); pair_n.append(pm.n); pair_mse.append(pm.mse)
-        rc, P, its = lum_compute(self.V, self.edges, m2s, max_iterations=self.lum_iterations)
+        # host: per-pair rigid solve (3x3 SVD on the moments) + residuals, LUM graph
+        # solve, pose_v <- LUM_v * pose_v -- one native call, identical on every rank
+        rc, new, info = ring_host_step(self.V, self.edges, rows, self.origin, poses, self.lum_iterations)
         if rc != 0:
             raise RuntimeError("LUM solve failed with status %d" % rc)
-        new = [poses[0].copy()]
-        for v in range(1, self.V):
-            # lum.getTransformation(i) is an Eigen::Affine3f before it meets the f64 pose
-            L = pose_to_mat4(P[v]).astype(np.float32).astype(np.float64)
-            new.append(mat4d_mul(L, poses[v]))
-        n = float(sum(pair_n))
+        n = float(sum(info["pair_n"]))
         t3 = time.perf_counter()
-        self.last = dict(pair_T=pair_T, pair_n=pair_n, pair_mse=pair_mse, lum_pose=P, lum_iterations=its,
-                         n_corr=n, mse=(sum(a * b for a, b in zip(pair_n, pair_mse)) / n) if n else 0.0,
+        self.last = dict(info, n_corr=n,
+                         mse=(sum(a * b for a, b in zip(info["pair_n"], info["pair_mse"])) / n) if n else 0.0,
                          ms_enqueue=1e3 * (t1 - t0), ms_drain=1e3 * (t2 - t1), ms_host_solve=1e3 * (t3 - t2))
         return new
