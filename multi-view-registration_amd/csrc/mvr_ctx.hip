@@ -814,6 +814,26 @@ API int mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset)
     out[2] = std::max<uint64_t>(out[2], h[kEvalRegion + (size_t)k * kEvalStride + 1]);
     out[3] = std::max<uint64_t>(out[3], h[kEvalRegion + (size_t)k * kEvalStride + 2]);
   }
+  if (std::getenv("MVR_STAMP_DUMP")) {     // diagnostic builds (-DMVR_STAMP): per-phase cycle sums of the culled kernel
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < kEvalShards; ++k) for (int j = 0; j < 10; ++j) ph[j] += h[kEvalRegion + (size_t)k * kEvalStride + 4 + j];
+    if (ph[5]) std::fprintf(stderr, "[mvr stamp] prologue %.0f epilogue %.0f lifetime %.0f cycles, %.2f us (100 MHz clock)\n", (double)ph[6] / ph[5],
+                            (double)ph[7] / ph[5], (double)ph[8] / ph[5], (double)ph[9] / ph[5] / 100.0);
+    std::fprintf(stderr, "[mvr stamp] waves %llu  cycles/wave: stage %.0f advance %.0f process %.0f revalidate %.0f  loop-total %.0f\n",
+                 (unsigned long long)ph[5], ph[5] ? (double)ph[0] / ph[5] : 0.0, ph[5] ? (double)ph[1] / ph[5] : 0.0,
+                 ph[5] ? (double)ph[2] / ph[5] : 0.0, ph[5] ? (double)ph[3] / ph[5] : 0.0, ph[5] ? (double)ph[4] / ph[5] : 0.0);
+  }
+  if (std::getenv("MVR_STAMP_DUMP")) {
+    std::fprintf(stderr, "[mvr stamp] waves by tiles evaluated (count:mean kcycles):");
+    for (int k = 0; k < 32; ++k) {
+      const uint64_t n = h[kEvalRegion + (size_t)(32 + k) * kEvalStride + 3], cyc = h[kEvalRegion + (size_t)k * kEvalStride + 3];
+      if (n) std::fprintf(stderr, " %d=%llu:%.0f", k, (unsigned long long)n, (double)cyc / n / 1000.0);
+    }
+    std::fprintf(stderr, "\n");
+    std::fprintf(stderr, "[mvr stamp] wave end-time histogram (5 us bins, all launches since reset):");
+    for (int k = 0; k < kEvalShards; ++k) std::fprintf(stderr, " %llu", (unsigned long long)h[kEvalRegion + (size_t)k * kEvalStride + 14]);
+    std::fprintf(stderr, "\n");
+  }
   if (reset) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, 2 * kEvalRegion * sizeof(uint64_t), c->stream));
   return MVR_OK;
 }

@@ -1,0 +1,436 @@
+// csrc/mvr_cull.hip -- the exact culled 1-NN kernel (gfx950) over the index of mvr_index.hip.
+//
+// Same results as the brute-force kernel of mvr_nn.hip (bit-identical d2,
+// lowest ORIGINAL index on ties) with O(N * k) instead of O(N^2) distance
+// evaluations -- the GPU-native counterpart of the kd-tree the reference gets
+// from PCL/FLANN (tree_->nearestKSearch inside icp.align, registrator.cpp:569,
+// and inside determineReciprocalCorrespondences, :502/:649).
+//
+// One BLOCK = one set of 64*Q Hilbert-consecutive queries, held by all 4 waves;
+// wave w owns the target tiles with (tile & 3) == w, so the serial chain of
+// tiles a query set has to visit is cut four ways.  The waves share nothing
+// but a per-query "best so far" in LDS (ds_min_u32 on the float bits, read
+// without a barrier: it only ever decreases, a stale value merely prunes less)
+// and meet once, at the end, to combine their partial results.
+//
+// Inside a wave the 64 lanes are 4 GROUPS of 16: every group holds the SAME
+// 64*Q queries (4*Q per lane) and evaluates them against its own quarter of
+// the staged 256-target tile.  One ds_read_b128 therefore feeds 4*Q distance
+// evaluations per lane instead of Q: with one query per lane (the first
+// version of this kernel) the LDS pipe was the busiest unit of the CU (in-kernel
+// cycle stamps, tools/build_stamp.sh: 25k cycles per tile against 4.4k of VALU
+// work).  The four groups read four different addresses; the group regions
+// are 65 float4 apart so that they fall into disjoint LDS banks.
+//
+// A tile is visited only if SOME query of the set can still find an
+// equal-or-closer point inside the tile's box (exact per-query point/box
+// test with a 1e-5 relative safety margin for the rounding of the box
+// distance), so every point that could win or tie is evaluated: results stay
+// exact.  Inside a tile the inner loop is the brute-force one (min3 tracking
+// per 32-target sub-tile); the index is recovered once, at the very end, by a
+// re-scan of the winning sub-tile that the 4 lane groups share (8 points each).
+// Compiled with -ffp-contract=off.
+#include "mvr_internal.h"
+
+namespace mvr {
+namespace {
+
+constexpr int kSub = 32;        // min-tracking sub-tile
+constexpr int kGrpPitch = 65;   // float4 between the lane groups' LDS regions (64 + 1: disjoint banks)
+
+template <bool FMA>
+__device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float qz)
+{
+  const float dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+  if (FMA) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+__device__ __forceinline__ float box_dist2(const float qlo[3], const float qhi[3], const float4 lo, const float4 hi)
+{
+  const float dx = fmaxf(0.f, fmaxf(lo.x - qhi[0], qlo[0] - hi.x));
+  const float dy = fmaxf(0.f, fmaxf(lo.y - qhi[1], qlo[1] - hi.y));
+  const float dz = fmaxf(0.f, fmaxf(lo.z - qhi[2], qlo[2] - hi.z));
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  // LDS hand-off between lanes of ONE wave: DS ops of a wave complete in order;
+  // the fences keep the compiler from moving accesses across this point.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lowest original index among points [first, first + count) of the sorted
+// target array at distance exactly `d`; the loads are independent (one L2 round trip)
+template <bool FMA, int COUNT>
+__device__ __forceinline__ uint32_t span_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t first, float d,
+                                                float qx, float qy, float qz)
+{
+  float4 p[COUNT];
+#pragma unroll
+  for (int k = 0; k < COUNT; ++k) p[k] = ts[min(first + (uint32_t)k, nt - 1u)];
+  uint32_t best = kNone;
+#pragma unroll
+  for (int k = 0; k < COUNT; ++k)
+    if (first + (uint32_t)k < nt && dist2<FMA>(p[k], qx, qy, qz) == d) best = min(best, __float_as_uint(p[k].w));
+  return best;
+}
+
+// the rare tie path: a whole sub-tile, 2 points at a time (keeps the register footprint of the hot path)
+template <bool FMA>
+__device__ __forceinline__ uint32_t sub_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t sub, float d, float qx,
+                                            float qy, float qz)
+{
+  uint32_t best = kNone;
+#pragma unroll 1
+  for (int k = 0; k < kSub; k += 2) best = min(best, span_argmin<FMA, 2>(ts, nt, sub * kSub + (uint32_t)k, d, qx, qy, qz));
+  return best;
+}
+
+__device__ __forceinline__ float lane_value(float v, int lane_uniform)     // v of one lane, as a wave-uniform (SGPR) value
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+
+#ifdef MVR_STAMP    // diagnostic build only (tools/build_stamp.sh): where does a wave's lifetime go?
+#define MVR_CLK() __builtin_readcyclecounter()
+#else
+#define MVR_CLK() 0ull
+#endif
+
+template <bool FMA, int Q>
+__device__ __forceinline__ void
+nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,
+               const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
+               const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n_tiles, float cap2,
+               nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals)
+{
+  constexpr int NQ = 4 * Q;      // queries per lane
+  constexpr int NB = 64 * Q;     // queries per block
+  static_assert(16 * NB * sizeof(nnkey_t) <= 4 * 4 * kGrpPitch * sizeof(float4), "partials must fit the tile buffers");
+  __shared__ float4 lds[4][4 * kGrpPitch];
+  __shared__ unsigned sbest[NB];
+  // readfirstlane tells the compiler the wave index is wave-uniform: everything
+  // derived from it (tile ids, loop conditions) then lives in SGPRs / scalar branches
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = lane >> 4, l16 = lane & 15;
+  const unsigned long long st_entry = MVR_CLK();
+#ifdef MVR_STAMP
+  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
+  if (evals && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(evals + kEvalRegion + 15, st_rt0);
+#endif
+  float4 *T = lds[wv];
+  const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
+  const uint32_t b_begin = blockIdx.x * NB;
+  if (b_begin >= nq) return;                      // block-uniform
+
+  // query q of this lane = position b_begin + 16 q + l16 (the same in all 4 groups);
+  // positions past the end repeat the block's first query (a duplicate changes no bound)
+  float qx[NQ], qy[NQ], qz[NQ], best[NQ];
+  uint32_t bsub[NQ];
+  float qlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, qhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    uint32_t pos = b_begin + q * 16 + l16;
+    pos = pos < nq ? pos : b_begin;
+    const float4 p = qs[qlist ? qlist[pos] : (q_begin + pos)];
+    qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
+    best[q] = __builtin_inff(); bsub[q] = kNone;
+    qlo[0] = fminf(qlo[0], p.x); qlo[1] = fminf(qlo[1], p.y); qlo[2] = fminf(qlo[2], p.z);
+    qhi[0] = fmaxf(qhi[0], p.x); qhi[1] = fmaxf(qhi[1], p.y); qhi[2] = fmaxf(qhi[2], p.z);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1)
+    for (int k = 0; k < 3; ++k) {
+      qlo[k] = fminf(qlo[k], __shfl_xor(qlo[k], o, 64));
+      qhi[k] = fmaxf(qhi[k], __shfl_xor(qhi[k], o, 64));
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {       // the set's box is wave-uniform: keep it in SGPRs
+    qlo[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qlo[k])));
+    qhi[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qhi[k])));
+  }
+  // the queries this lane TESTS tile boxes with: positions lane + 64 j, i.e. its own queries g + 4 j
+  float tx[Q], ty[Q], tz[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    tx[j] = qx[4 * j]; ty[j] = qy[4 * j]; tz[j] = qz[4 * j];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (g == k) { tx[j] = qx[4 * j + k]; ty[j] = qy[4 * j + k]; tz[j] = qz[4 * j + k]; }
+  }
+  if (threadIdx.x < NB) sbest[threadIdx.x] = 0x7F800000u;   // +inf
+  __syncthreads();
+
+  float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
+  uint32_t tiles_done = 0, tiles_tested = 0;
+
+  auto shared_bound = [&](int j) {
+    return fminf(__uint_as_float(__atomic_load_n(&sbest[j * 64 + lane], __ATOMIC_RELAXED)), cap2);
+  };
+
+  // register prefetch buffer: the NEXT tile's points travel from L2 while the
+  // current tile is being evaluated out of LDS
+  float4 pre[kCullTile / 64];
+  auto fetch = [&](uint32_t tile) {
+#pragma unroll
+    for (int r = 0; r < kCullTile / 64; ++r) {
+      const uint32_t j = tile * kCullTile + r * 64 + lane;
+      pre[r] = (j < nt) ? ts[j] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+    }
+  };
+  auto stage = [&]() {      // targets 64 r .. 64 r + 63 of the tile -> region of lane group r
+#pragma unroll
+    for (int r = 0; r < kCullTile / 64; ++r) T[r * kGrpPitch + lane] = pre[r];
+    wave_lds_sync();
+  };
+
+  // evaluates the tile currently staged in this wave's LDS buffer: group g takes targets 64 g .. 64 g + 63
+  auto process = [&](uint32_t tile) {
+    const float4 *Tg = T + g * kGrpPitch;
+#pragma unroll 1
+    for (int s = 0; s < 64; s += kSub) {
+      float m[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) m[q] = __builtin_inff();
+#pragma unroll 4
+      for (int k = 0; k < kSub; k += 2) {
+        const float4 a = Tg[s + k], b = Tg[s + k + 1];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float da = dist2<FMA>(a, qx[q], qy[q], qz[q]);
+          const float db = dist2<FMA>(b, qx[q], qy[q], qz[q]);
+          m[q] = __builtin_fminf(__builtin_fminf(m[q], da), db);
+        }
+      }
+      const uint32_t sub = tile * (kCullTile / kSub) + (uint32_t)(g * 64 + s) / kSub;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (m[q] < best[q]) { best[q] = m[q]; bsub[q] = sub; }
+        else if (m[q] == best[q] && bsub[q] != kNone && m[q] < 3.0e38f) {
+          // exact tie between two sub-tiles (visited in any order): keep the one
+          // holding the lowest original index.  Rare; only duplicates / symmetric data.
+          const uint32_t o1 = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
+          const uint32_t o2 = sub_argmin<FMA>(ts, nt, sub, best[q], qx[q], qy[q], qz[q]);
+          if (o2 < o1) bsub[q] = sub;
+        }
+      }
+    }
+    wave_lds_sync();     // all lanes done reading before the buffer is overwritten
+    ++tiles_done;
+    // publish this wave's bests, then a wave max-reduction of the set-wide bounds -> new U
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) atomicMin(&sbest[q * 16 + l16], __float_as_uint(best[q]));
+    float w = 0.f;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) w = fmaxf(w, shared_bound(j));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
+    U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fminf(cap2, w))));
+  };
+
+  // exact per-query test: the tile is needed iff SOME query of this set can
+  // still find an equal-or-closer point inside the tile's box
+  auto needed = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
+                    const float hi_z) {
+    bool need = false;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const float dx = fmaxf(0.f, fmaxf(lo_x - tx[j], tx[j] - hi_x));
+      const float dy = fmaxf(0.f, fmaxf(lo_y - ty[j], ty[j] - hi_y));
+      const float dz = fmaxf(0.f, fmaxf(lo_z - tz[j], tz[j] - hi_z));
+      const float pb = dx * dx + dy * dy + dz * dz;
+      need |= (pb * 0.99999f <= shared_bound(j));
+    }
+    ++tiles_tested;
+    return __any(need) != 0;
+  };
+
+  // candidate stream over this wave's own tiles (tile = 4*i + wv, lane <-> i):
+  // round 0 = tiles whose box overlaps the query box, round 1 = the rest within U.
+  const uint32_t n_own = (n_tiles > (uint32_t)wv) ? (n_tiles - (uint32_t)wv + 3u) / 4u : 0u;
+  int round = 0;
+  uint32_t ibase = 0;                 // next block of 64 own tiles to ballot
+  uint32_t cbase = 0;                 // block the current mask belongs to
+  unsigned long long mask = 0ull;
+  float lb = __builtin_inff();
+  float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;     // this lane's tile box of the current ballot block
+  float sel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};               // box of the tile last returned (wave-uniform)
+  auto advance = [&]() -> uint32_t {
+    for (;;) {
+      while (mask == 0ull) {
+        if (ibase >= n_own) {
+          if (round == 1) return kNone;
+          round = 1; ibase = 0;
+          if (n_own == 0) return kNone;
+        }
+        const uint32_t i = ibase + lane;
+        const uint32_t t = 4u * i + (uint32_t)wv;
+        lb = __builtin_inff();
+        if (i < n_own) { blo = tlo[t]; bhi = thi[t]; lb = box_dist2(qlo, qhi, blo, bhi); }
+        const bool pred = (i < n_own) && ((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
+        mask = __ballot(pred);
+        cbase = ibase;
+        ibase += 64;
+      }
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if (round == 1 && lane_value(lb, b) * 0.99999f > U) continue;     // U shrank since the ballot
+      // the candidate's box sits in lane b's registers: v_readlane it into SGPRs instead of re-reading memory
+      sel[0] = lane_value(blo.x, b); sel[1] = lane_value(blo.y, b); sel[2] = lane_value(blo.z, b);
+      sel[3] = lane_value(bhi.x, b); sel[4] = lane_value(bhi.y, b); sel[5] = lane_value(bhi.z, b);
+      if (needed(sel[0], sel[1], sel[2], sel[3], sel[4], sel[5])) return 4u * (cbase + (uint32_t)b) + (uint32_t)wv;
+    }
+  };
+
+  unsigned long long st_stage = 0, st_adv = 0, st_proc = 0, st_reval = 0;
+  const unsigned long long st_begin = MVR_CLK();
+  uint32_t cur = advance();
+  if (cur != kNone) fetch(cur);
+  while (cur != kNone) {
+    const unsigned long long t0 = MVR_CLK();
+    stage();                                  // registers -> LDS (waits for the prefetch)
+    const unsigned long long t1 = MVR_CLK();
+    uint32_t nxt = advance();                 // chosen with the bounds as they are NOW
+    if (nxt != kNone) fetch(nxt);             // in flight during the evaluation below
+    const unsigned long long t2 = MVR_CLK();
+    process(cur);
+    const unsigned long long t3 = MVR_CLK();
+    // the bounds have shrunk: re-validate the prefetched tile (its data is dropped if it is no longer needed)
+    while (nxt != kNone && !needed(sel[0], sel[1], sel[2], sel[3], sel[4], sel[5])) {
+      nxt = advance();
+      if (nxt != kNone) fetch(nxt);
+    }
+    st_stage += t1 - t0; st_adv += t2 - t1; st_proc += t3 - t2; st_reval += MVR_CLK() - t3;
+    cur = nxt;
+  }
+  const unsigned long long st_loopend = MVR_CLK();
+
+  // ---- combine: 16 partial results per query (4 waves x 4 lane groups) meet in LDS (over the tile buffers)
+  __syncthreads();
+  nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [16][NB]: (d2 bits, sub-tile)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    part[(wv * 4 + g) * NB + q * 16 + l16] = ((nnkey_t)__float_as_uint(best[q]) << 32) | bsub[q];
+  __syncthreads();
+  // wave wv finishes the queries wv + 4 j of every lane column; the index (lowest original
+  // index at distance == best) comes from one re-scan of the winning sub-tile, 8 points per lane group
+#pragma unroll
+  for (int j = 0; j < Q; ++j) {
+    const int q = wv + 4 * j, i = q * 16 + l16;
+    // this query's coordinates again (re-read: indexing the register arrays by the wave id would put them in scratch)
+    const uint32_t pos = b_begin + i, rpos = pos < nq ? pos : b_begin;
+    const float4 fq = qs[qlist ? qlist[rpos] : (q_begin + rpos)];
+    const float fx = fq.x, fy = fq.y, fz = fq.z;
+    nnkey_t pm = kKeyInit;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) pm = min(pm, part[p * NB + i]);
+    const uint32_t dbits = (uint32_t)(pm >> 32), sub = (uint32_t)pm;
+    const float d = __uint_as_float(dbits);
+    const bool found = sub != kNone && d <= cap2;
+    uint32_t o = kNone;
+    if (found) {
+      o = span_argmin<FMA, kSub / 4>(ts, nt, sub * kSub + g * (kSub / 4), d, fx, fy, fz);
+      // rare: another partial reached the same distance in a different sub-tile
+#pragma unroll 1
+      for (int p = 0; p < 16; ++p) {
+        const nnkey_t k = part[p * NB + i];
+        if ((uint32_t)(k >> 32) == dbits && (uint32_t)k != sub && (uint32_t)k != kNone)
+          o = min(o, span_argmin<FMA, kSub / 4>(ts, nt, (uint32_t)k * kSub + g * (kSub / 4), d, fx, fy, fz));
+      }
+    }
+    o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
+    o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
+    if (g == 0 && pos < nq) {
+      const uint32_t ord = qlist ? pos : __float_as_uint(fq.w);     // key slot: list position / original index
+      keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
+    }
+  }
+  if (evals && lane == 0) {
+    const uint32_t nvalid = min(nq - b_begin, (uint32_t)NB);
+    const unsigned long long e = (unsigned long long)tiles_done * kCullTile * nvalid;
+    // sharded counters: one 128-byte line per shard, or thousands of waves serialise on one address
+    unsigned long long *a = evals + (size_t)(blockIdx.x & (kEvalShards - 1)) * kEvalStride;
+    unsigned long long *b = a + kEvalRegion;
+    atomicAdd(a, e);              // this launch (profiling)
+    atomicAdd(b, e);              // running total (mvr_icp_stats.evals)
+    atomicMax(b + 1, (unsigned long long)tiles_done);     // diagnostics: heaviest wave
+    atomicMax(b + 2, (unsigned long long)tiles_tested);
+#ifdef MVR_STAMP
+    atomicAdd(b + 4, st_stage); atomicAdd(b + 5, st_adv); atomicAdd(b + 6, st_proc); atomicAdd(b + 7, st_reval);
+    atomicAdd(b + 8, st_loopend - st_begin); atomicAdd(b + 9, 1ull); atomicAdd(b + 10, st_begin - st_entry);
+    atomicAdd(b + 11, MVR_CLK() - st_loopend); atomicAdd(b + 12, MVR_CLK() - st_entry);
+    atomicAdd(b + 13, __builtin_amdgcn_s_memrealtime() - st_rt0);
+    {   // lifetime by number of tiles evaluated: shard k slot 3 = sum of cycles, shard 32 + k slot 3 = waves
+      const unsigned long long k = min((unsigned long long)tiles_done, 31ull);
+      atomicAdd(evals + kEvalRegion + k * kEvalStride + 3, MVR_CLK() - st_entry);
+      atomicAdd(evals + kEvalRegion + (32 + k) * kEvalStride + 3, 1ull);
+    }
+    // histogram of wave end times (5 us bins since block 0 started): shard k, slot 14 = bin k; shard 0 slot 15 = base
+    unsigned long long *h = evals + kEvalRegion;
+    const unsigned long long base = atomicAdd(h + 15, 0ull);
+    if (base != 0 && blockIdx.x != 0) {
+      const unsigned long long bin = min((__builtin_amdgcn_s_memrealtime() - base) / 500ull, (unsigned long long)(kEvalShards - 1));
+      atomicAdd(h + bin * kEvalStride + 14, 1ull);
+    }
+#endif
+  }
+  (void)st_entry; (void)st_stage; (void)st_adv; (void)st_proc; (void)st_reval; (void)st_begin; (void)st_loopend;
+}
+
+// Register budgets: the 64-query kernel is compiled for 4 waves per SIMD (<= 128 VGPRs; measured: 4, 5 and 6 resident waves run
+// equally fast, and the packed-math loop needs even-aligned register pairs), like the 128-query one.
+#ifndef MVR_CULL_WAVES
+#define MVR_CULL_WAVES 4
+#endif
+#define MVR_CULL_ARGS                                                                                                  \
+  const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,               \
+      const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt, const float4 *__restrict__ tlo, \
+      const float4 *__restrict__ thi, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys,                        \
+      unsigned long long *__restrict__ evals
+template <bool FMA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVR_CULL_WAVES))) nn_cull_q1(MVR_CULL_ARGS)
+{
+  nn_cull_body<FMA, 1>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, n_tiles, cap2, keys, evals);
+}
+template <bool FMA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) nn_cull_q2(MVR_CULL_ARGS)
+{
+  nn_cull_body<FMA, 2>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, n_tiles, cap2, keys, evals);
+}
+#undef MVR_CULL_ARGS
+
+}  // namespace
+
+int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint32_t *qlist,
+                   const uint32_t *qcount, const Cloud &t, float cap2, bool fma, nnkey_t *keys)
+{
+  if (q_count == 0 || t.n == 0) return MVR_OK;
+  if (q.n > 0xFFFFFFF0ull || t.n > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+  const uint32_t n_tiles = (uint32_t)((t.n + kCullTile - 1) / kCullTile);
+  // measured (tools/cull_sweep.sh): the kernel is bound by its longest serial tile chain, so small query
+  // sets win until there are far more sets than the chip holds at once
+  int Q = (q_count <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
+  if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
+  const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (4 cooperating waves) per query set
+  MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+  ProfScope ps(c, MVR_K_NN, c->evals, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, (double)q_count * (double)t.n,
+               kEvalShards);
+#define MVR_LAUNCH_CULL(F, QQ)                                                                                        \
+  hipLaunchKernelGGL((nn_cull_q##QQ<F>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q_begin,      \
+                     (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, n_tiles, cap2, keys,    \
+                     c->evals)
+  if (fma) { if (Q == 2) MVR_LAUNCH_CULL(true, 2); else MVR_LAUNCH_CULL(true, 1); }
+  else     { if (Q == 2) MVR_LAUNCH_CULL(false, 2); else MVR_LAUNCH_CULL(false, 1); }
+#undef MVR_LAUNCH_CULL
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+}  // namespace mvr

@@ -1,4 +1,5 @@
-// csrc/mvr_index.hip -- exact nearest neighbours with spatial culling (gfx950).
+// csrc/mvr_index.hip -- spatial index for the exact culled nearest-neighbour search (gfx950);
+// the search kernel itself lives in mvr_cull.hip.
 //
 // Same results as the brute-force kernel of mvr_nn.hip (bit-identical d2,
 // lowest ORIGINAL index on ties) with O(N * k) instead of O(N^2) distance
@@ -163,266 +164,6 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(const float4 *__res
   }
 }
 
-// ------------------------------------------------------------------ culled NN
-
-template <bool FMA>
-__device__ __forceinline__ float dist2(const float4 t, float qx, float qy, float qz)
-{
-  const float dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
-  if (FMA) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-  float r = dx * dx;
-  r = r + dy * dy;
-  r = r + dz * dz;
-  return r;
-}
-
-__device__ __forceinline__ float box_dist2(const float qlo[3], const float qhi[3], const float4 lo, const float4 hi)
-{
-  const float dx = fmaxf(0.f, fmaxf(lo.x - qhi[0], qlo[0] - hi.x));
-  const float dy = fmaxf(0.f, fmaxf(lo.y - qhi[1], qlo[1] - hi.y));
-  const float dz = fmaxf(0.f, fmaxf(lo.z - qhi[2], qlo[2] - hi.z));
-  return dx * dx + dy * dy + dz * dz;
-}
-
-__device__ __forceinline__ void wave_lds_sync()
-{
-  // LDS hand-off between lanes of ONE wave: DS ops of a wave complete in order;
-  // the fences keep the compiler from moving accesses across this point.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// lowest original index among the points of sub-tile `sub` at distance exactly `d`
-template <bool FMA>
-__device__ __forceinline__ uint32_t sub_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t sub, float d,
-                                               float qx, float qy, float qz)
-{
-  uint32_t best = kNone;
-  const uint32_t base = sub * kSub;
-  for (int k = 0; k < kSub; ++k) {
-    const uint32_t j = base + k;
-    if (j < nt) {
-      const float4 p = ts[j];
-      if (dist2<FMA>(p, qx, qy, qz) == d) best = min(best, __float_as_uint(p.w));
-    }
-  }
-  return best;
-}
-
-// One BLOCK = one set of 64*Q Hilbert-consecutive queries, held by all 4 waves;
-// wave w owns the target tiles with (tile & 3) == w, so the serial chain of
-// tiles a query set has to visit is cut four ways.  The waves share nothing
-// but a per-query "best so far" in LDS (ds_min_u32 on the float bits, read
-// without a barrier: it only ever decreases, a stale value merely prunes less)
-// and meet once, at the end, to combine their keys.
-template <bool FMA, int Q>
-__global__ void __launch_bounds__(256)
-nn_cull_kernel(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,
-               const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
-               const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n_tiles, float cap2,
-               nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals)
-{
-  __shared__ float4 lds[4][kCullTile];
-  __shared__ unsigned sbest[64 * Q];
-  __shared__ nnkey_t skey[4][64 * Q];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float4 *__restrict__ T = lds[wv];
-  const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
-  const uint32_t b_begin = blockIdx.x * 64 * Q;
-  if (b_begin >= nq) return;                      // block-uniform
-
-  float qx[Q], qy[Q], qz[Q], best[Q];
-  uint32_t bsub[Q], ord[Q];
-  float qlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, qhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const uint32_t pos = b_begin + q * 64 + lane;
-    best[q] = __builtin_inff(); bsub[q] = kNone; ord[q] = kNone;
-    qx[q] = qy[q] = qz[q] = 0.f;
-    if (pos < nq) {
-      const float4 p = qs[qlist ? qlist[pos] : (q_begin + pos)];
-      qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
-      ord[q] = qlist ? pos : __float_as_uint(p.w);     // key slot: list position / original index
-      qlo[0] = fminf(qlo[0], p.x); qlo[1] = fminf(qlo[1], p.y); qlo[2] = fminf(qlo[2], p.z);
-      qhi[0] = fmaxf(qhi[0], p.x); qhi[1] = fmaxf(qhi[1], p.y); qhi[2] = fmaxf(qhi[2], p.z);
-    }
-    if (wv == 0) sbest[q * 64 + lane] = 0x7F800000u;   // +inf
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-    for (int k = 0; k < 3; ++k) {
-      qlo[k] = fminf(qlo[k], __shfl_xor(qlo[k], o, 64));
-      qhi[k] = fmaxf(qhi[k], __shfl_xor(qhi[k], o, 64));
-    }
-  __syncthreads();
-
-  float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
-  uint32_t tiles_done = 0, tiles_tested = 0;
-
-  auto shared_bound = [&](int q) {
-    return fminf(__uint_as_float(__atomic_load_n(&sbest[q * 64 + lane], __ATOMIC_RELAXED)), cap2);
-  };
-
-  // register prefetch buffer: the NEXT tile's points travel from L2 while the
-  // current tile is being evaluated out of LDS
-  float4 pre[kCullTile / 64];
-  auto fetch = [&](uint32_t tile) {
-#pragma unroll
-    for (int r = 0; r < kCullTile / 64; ++r) {
-      const uint32_t j = tile * kCullTile + r * 64 + lane;
-      pre[r] = (j < nt) ? ts[j] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
-    }
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int r = 0; r < kCullTile / 64; ++r) T[r * 64 + lane] = pre[r];
-    wave_lds_sync();
-  };
-
-  // evaluates the tile currently staged in this wave's LDS buffer
-  auto process = [&](uint32_t tile) {
-#pragma unroll 1
-    for (int s = 0; s < kCullTile; s += kSub) {
-      float m[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) m[q] = __builtin_inff();
-#pragma unroll
-      for (int k = 0; k < kSub; k += 2) {
-        const float4 a = T[s + k], b = T[s + k + 1];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          const float da = dist2<FMA>(a, qx[q], qy[q], qz[q]);
-          const float db = dist2<FMA>(b, qx[q], qy[q], qz[q]);
-          m[q] = __builtin_fminf(__builtin_fminf(m[q], da), db);
-        }
-      }
-      const uint32_t sub = tile * (kCullTile / kSub) + (uint32_t)s / kSub;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        if (m[q] < best[q]) { best[q] = m[q]; bsub[q] = sub; }
-        else if (m[q] == best[q] && bsub[q] != kNone && m[q] < 3.0e38f) {
-          // exact tie between two sub-tiles (visited in any order): keep the one
-          // holding the lowest original index.  Rare; only duplicates / symmetric data.
-          const uint32_t o1 = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
-          const uint32_t o2 = sub_argmin<FMA>(ts, nt, sub, best[q], qx[q], qy[q], qz[q]);
-          if (o2 < o1) bsub[q] = sub;
-        }
-      }
-    }
-    wave_lds_sync();     // all lanes done reading before the buffer is overwritten
-    ++tiles_done;
-    // publish this wave's bests, then a wave max-reduction of the set-wide bounds -> new U
-    float w = 0.f;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      if (ord[q] != kNone) {
-        atomicMin(&sbest[q * 64 + lane], __float_as_uint(best[q]));
-        w = fmaxf(w, shared_bound(q));
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
-    U = fminf(cap2, w);
-  };
-
-  // exact per-query test: the tile is needed iff SOME query of this set can
-  // still find an equal-or-closer point inside the tile's box
-  auto needed = [&](uint32_t tile) {
-    const float4 lo = tlo[tile], hi = thi[tile];
-    bool need = false;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const float dx = fmaxf(0.f, fmaxf(lo.x - qx[q], qx[q] - hi.x));
-      const float dy = fmaxf(0.f, fmaxf(lo.y - qy[q], qy[q] - hi.y));
-      const float dz = fmaxf(0.f, fmaxf(lo.z - qz[q], qz[q] - hi.z));
-      const float pb = dx * dx + dy * dy + dz * dz;
-      need |= (ord[q] != kNone) && (pb * 0.99999f <= shared_bound(q));
-    }
-    ++tiles_tested;
-    return __any(need) != 0;
-  };
-
-  // candidate stream over this wave's own tiles (tile = 4*i + wv, lane <-> i):
-  // round 0 = tiles whose box overlaps the query box, round 1 = the rest within U.
-  const uint32_t n_own = (n_tiles > (uint32_t)wv) ? (n_tiles - (uint32_t)wv + 3u) / 4u : 0u;
-  int round = 0;
-  uint32_t ibase = 0;                 // next block of 64 own tiles to ballot
-  uint32_t cbase = 0;                 // block the current mask belongs to
-  unsigned long long mask = 0ull;
-  float lb = __builtin_inff();
-  auto advance = [&]() -> uint32_t {
-    for (;;) {
-      while (mask == 0ull) {
-        if (ibase >= n_own) {
-          if (round == 1) return kNone;
-          round = 1; ibase = 0;
-          if (n_own == 0) return kNone;
-        }
-        const uint32_t i = ibase + lane;
-        const uint32_t t = 4u * i + (uint32_t)wv;
-        lb = __builtin_inff();
-        if (i < n_own) lb = box_dist2(qlo, qhi, tlo[t], thi[t]);
-        const bool pred = (i < n_own) && ((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
-        mask = __ballot(pred);
-        cbase = ibase;
-        ibase += 64;
-      }
-      const int b = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      if (round == 1 && __shfl(lb, b, 64) * 0.99999f > U) continue;     // U shrank since the ballot
-      const uint32_t tile = 4u * (cbase + (uint32_t)b) + (uint32_t)wv;
-      if (needed(tile)) return tile;
-    }
-  };
-
-  uint32_t cur = advance();
-  if (cur != kNone) fetch(cur);
-  while (cur != kNone) {
-    stage();                                  // registers -> LDS (waits for the prefetch)
-    uint32_t nxt = advance();                 // chosen with the bounds as they are NOW
-    if (nxt != kNone) fetch(nxt);             // in flight during the evaluation below
-    process(cur);
-    // the bounds have shrunk: re-validate the prefetched tile (its data is dropped if it is no longer needed)
-    while (nxt != kNone && !needed(nxt)) {
-      nxt = advance();
-      if (nxt != kNone) fetch(nxt);
-    }
-    cur = nxt;
-  }
-
-  // recover indices (lowest original index at distance == best); combine the 4 waves
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    nnkey_t key = kKeyInit;
-    if (ord[q] != kNone && bsub[q] != kNone && best[q] <= cap2) {
-      const uint32_t o = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
-      key = ((nnkey_t)__float_as_uint(best[q]) << 32) | o;
-    }
-    skey[wv][q * 64 + lane] = key;
-  }
-  __syncthreads();
-  if (wv == 0) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      if (ord[q] == kNone) continue;
-      const int i = q * 64 + lane;
-      keys[ord[q]] = min(min(skey[0][i], skey[1][i]), min(skey[2][i], skey[3][i]));
-    }
-  }
-  if (evals && lane == 0) {
-    const uint32_t nvalid = min(nq - b_begin, (uint32_t)(64 * Q));
-    const unsigned long long e = (unsigned long long)tiles_done * kCullTile * nvalid;
-    // sharded counters: one 128-byte line per shard, or thousands of waves serialise on one address
-    unsigned long long *a = evals + (size_t)(blockIdx.x & (kEvalShards - 1)) * kEvalStride;
-    unsigned long long *b = a + kEvalRegion;
-    atomicAdd(a, e);              // this launch (profiling)
-    atomicAdd(b, e);              // running total (mvr_icp_stats.evals)
-    atomicMax(b + 1, (unsigned long long)tiles_done);     // diagnostics: heaviest wave
-    atomicMax(b + 2, (unsigned long long)tiles_tested);
-  }
-}
-
 // ------------------------------------------------------ reciprocal glue (sorted space)
 
 __global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ qperm,
@@ -552,32 +293,6 @@ int ensure_index(Ctx *c, Cloud &cl)
     MVR_HIP_TRY(c, hipGetLastError());
     cl.coords_valid = true;
   }
-  return MVR_OK;
-}
-
-int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint32_t *qlist,
-                   const uint32_t *qcount, const Cloud &t, float cap2, bool fma, nnkey_t *keys)
-{
-  if (q_count == 0 || t.n == 0) return MVR_OK;
-  if (q.n > 0xFFFFFFF0ull || t.n > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
-  const uint32_t n_tiles = (uint32_t)((t.n + kCullTile - 1) / kCullTile);
-  // enough waves to fill the chip: fewer queries per lane for small problems
-  // (Q = 1 would make the wave-uniform LDS reads the bottleneck: one ds_read per 8.5 VALU)
-  // measured (tools/cull_sweep.sh): the kernel is bound by its longest serial tile chain, so small query sets win
-  int Q = (q_count <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
-  if (c->cull_q == 1 || c->cull_q == 2 || c->cull_q == 4) Q = c->cull_q;      // tuning override
-  const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (4 cooperating waves) per query set
-  MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
-  ProfScope ps(c, MVR_K_NN, c->evals, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, (double)q_count * (double)t.n,
-               kEvalShards);
-#define MVR_LAUNCH_CULL(F, QQ)                                                                                       \
-  hipLaunchKernelGGL((nn_cull_kernel<F, QQ>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q_begin,     \
-                     (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, n_tiles, cap2, keys,    \
-                     c->evals)
-  if (fma) { if (Q == 4) MVR_LAUNCH_CULL(true, 4); else if (Q == 2) MVR_LAUNCH_CULL(true, 2); else MVR_LAUNCH_CULL(true, 1); }
-  else     { if (Q == 4) MVR_LAUNCH_CULL(false, 4); else if (Q == 2) MVR_LAUNCH_CULL(false, 2); else MVR_LAUNCH_CULL(false, 1); }
-#undef MVR_LAUNCH_CULL
-  MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
 
