@@ -123,7 +123,7 @@ def main():
     for _ in range(args.warmup):
         step()
     reset()
-    ctx.prof_reset(); ctx.prof_enable(True)
+    ctx.prof_reset(); ctx.prof_enable(int(os.environ.get("MVR_BENCH_PROF", "2")))     # 2: time the NN kernels only
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -173,6 +173,8 @@ def main():
             return None
 
     def nn_roofline(kernel, launches, ms, evals, traffic, extra=None):
+        if not launches:
+            return None
         avg_s = ms * 1e-3 / launches
         achieved = FLOP_PER_EVAL * (evals / launches) / avg_s / 1e12
         r = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
@@ -186,13 +188,30 @@ def main():
             r.update(extra)
         return r
 
+    # Roofline of the dominant kernel.  In the timed region the scan pairs run on concurrent worker
+    # streams, so a launch there shares the chip with its neighbours and its HIP-event duration says
+    # little about the kernel; the same steps are therefore repeated ON ONE STREAM (pair_streams=1,
+    # all kernel families timed) and the launch durations of that pass price the kernel.
+    iso = None
+    if world == 1:
+        ctx.tune(pair_streams=1)
+        reset(); step(); reset()
+        ctx.prof_reset(); ctx.prof_enable(1)
+        barrier(); ti = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier(); iso_elapsed = time.perf_counter() - ti
+        ctx.prof_enable(False)
+        iso = dict(nn=ctx.prof_get(mvr.K_NN), rd=ctx.prof_get(mvr.K_REDUCE), gl=ctx.prof_get(mvr.K_GLUE),
+                   ms_per_step=1e3 * iso_elapsed / args.steps)
+        rd_launches, rd_ms, rd_bytes = iso["rd"]
     # the brute-force kernel (the plain VALU-roofline kernel) on the same pairs: one extra, untimed ring pass
     bf = None
     if world == 1 and not args.no_bruteforce_pass:
-        ctx.tune(nn_mode=0)
+        ctx.tune(nn_mode=0, pair_streams=1)
         reset()
         step()
-        ctx.prof_reset(); ctx.prof_enable(True)
+        ctx.prof_reset(); ctx.prof_enable(2)
         reset()
         step()
         ctx.prof_enable(False)
@@ -200,18 +219,28 @@ def main():
         ctx.tune(nn_mode=args.nn_mode)
         if bl:
             brute_equiv = bev
-            bf = nn_roofline("nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal; one untimed ring pass)", bl, bms, bev,
-                             traffic_of("nn_traffic.json"))
-    if nn_launches:
-        extra = {"nn_share_of_step": nn_ms * 1e-3 / elapsed}
+            bf = nn_roofline("nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal; one untimed ring pass, one stream)", bl, bms,
+                             bev, traffic_of("nn_traffic.json"))
+    kname = "nn_cull_kernel (exact culled 1-NN, fwd + reciprocal)" if culled else "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)"
+    ktraffic = traffic_of("nn_cull_traffic.json" if culled else "nn_traffic.json")
+    if iso and iso["nn"][0]:
+        il, ims, iev = iso["nn"]
+        extra = {"measured": "isolated: %d steps on one stream right after the timed region (HIP events per launch)" % args.steps,
+                 "ms_per_step_one_stream_profiled": iso["ms_per_step"]}
         if culled:
             extra["evals_bruteforce_equivalent_per_step"] = brute_equiv
             if brute_equiv:
-                extra["culling_factor"] = brute_equiv / (nn_evals / args.steps)
-                extra["bruteforce_equivalent_tflops"] = FLOP_PER_EVAL * brute_equiv / (nn_ms * 1e-3 / args.steps) / 1e12
-        out["roofline"] = nn_roofline("nn_cull_kernel (exact culled 1-NN, fwd + reciprocal)" if culled else
-                                      "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)", nn_launches, nn_ms,
-                                      nn_evals, traffic_of("nn_cull_traffic.json" if culled else "nn_traffic.json"), extra)
+                extra["culling_factor"] = brute_equiv / (iev / args.steps)
+                extra["bruteforce_equivalent_tflops"] = FLOP_PER_EVAL * brute_equiv / (ims * 1e-3 / args.steps) / 1e12
+        out["roofline"] = nn_roofline(kname, il, ims, iev, ktraffic, extra)
+    if nn_launches:      # the same kernel inside the timed region, overlapped with other pairs' kernels
+        r = nn_roofline(kname, nn_launches, nn_ms, nn_evals, ktraffic,
+                        {"measured": "timed region: launches overlap on %s worker streams, durations include the time "
+                                     "shared with neighbouring kernels" % os.environ.get("MVR_PAIR_STREAMS", "6")})
+        if "roofline" in out:
+            out["roofline_timed_region"] = r
+        else:
+            out["roofline"] = r
     if bf:
         out["roofline_bruteforce"] = bf
     if rd_launches:
@@ -220,7 +249,7 @@ def main():
             "achieved": rd_bytes / (rd_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": rd_bytes / (rd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "launches": rd_launches,
             "avg_launch_ms": rd_ms / rd_launches,
-            "note": "launch-latency bound at 200k points per scan (4 MB per launch)",
+            "note": "launch-latency bound at 200k points per scan (4 MB per launch); one-stream pass",
         }
     out["pcie"] = {"h2d_s": h2d, "h2d_bytes": V * N * 16}
 

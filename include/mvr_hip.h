@@ -171,6 +171,18 @@ int  mvr_pair_moments2(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist
 int  mvr_pair_moments2_dev(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist,
                            int reciprocal, int fma_dist, size_t q_begin, size_t q_count,
                            const double origin[3], double *dev_out);
+/* The whole edge list of one global iteration in one call (the `for` loops over
+ * scan pairs of registrator.cpp:482-502 and :640-651): pair k = (src[k], dst[k])
+ * with query range q_begin[k], q_count[k] (null arrays: all queries).  The pairs
+ * are independent, so they run on `pair_streams` worker HIP streams (mvr_ctx_tune,
+ * default 6) forked from and joined back into the context's stream: the tail of
+ * one pair's search overlaps the next pair's kernels.  Results are identical to
+ * n_pairs calls of mvr_pair_moments2.  out (host, [n_pairs]) and/or dev_out
+ * (device, [n_pairs][32] doubles, no host synchronisation) receive the sums. */
+int  mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src_slots, const int *tgt_slots,
+                             double max_dist, int reciprocal, int fma_dist, const size_t *q_begin,
+                             const size_t *q_count, const double origin[3],
+                             mvr_pair_moments2_t *out, double *dev_out);
 
 /* raw second moments of caller-supplied correspondences (lum.setCorrespondences,
  * registrator.cpp:650): query[k] indexes src_slot, match[k] indexes tgt_slot. */
@@ -236,11 +248,14 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_CO
  * kernel, 0 = brute-force kernel (also MVR_NN_MODE in the environment);
  * brute-force launch shape: "nn_q" (queries per lane: 2,4,6,8), "nn_sub"
  * (min-tracking sub-tile: 16,32,64), "nn_blocks_per_cu" (1..5); culled kernel:
- * "cull_q" (queries per lane: 1,2,4; 0 = auto).  Results never depend on them. */
+ * "cull_q" (64-query groups per set: 1,2; 0 = auto), "cull_w" (waves sharing one
+ * query set: 1,2,4; also MVR_CULL_W); "pair_streams" (worker streams of
+ * mvr_pair_moments2_batch, 1..16; also MVR_PAIR_STREAMS).  Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,
  * running total, max tiles processed by one wave, max tiles tested by one wave} */
 int  mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset);
+/* per-launch HIP-event timing: 0 off, 1 all kernel families, 2 the NN search kernels only */
 int  mvr_prof_enable(mvr_ctx *ctx, int on);
 int  mvr_prof_reset(mvr_ctx *ctx);
 /* launches, total ms, point-pair evals (nn family) / bytes (others) */

@@ -126,6 +126,9 @@ SIGNATURES = {
                                     _dp, C.POINTER(PairMoments2)]),
     "mvr_pair_moments2_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _sz,
                                         _sz, _dp, _vp]),
+    "mvr_pair_moments2_batch": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, C.c_int,
+                                          C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _dp,
+                                          C.POINTER(PairMoments2), _vp]),
     "mvr_pair_moments2_from_corr": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _sz, _dp,
                                               C.POINTER(PairMoments2)]),
     "mvr_umeyama_from_moments": (C.c_int, [C.POINTER(PairMoments), _fp, _dp]),
@@ -425,6 +428,23 @@ class Context:
         qc = (1 << 62) if q_count is None else int(q_count)
         _chk(_lib.mvr_pair_moments2_dev(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
                                         int(q_begin), qc, _p(o, C.c_double), _vp(dev_ptr)), self._h)
+
+    def pair_moments2_batch(self, pairs, max_dist, origin, dev_ptr=None, reciprocal=True, fma=False, ranges=None):
+        """All scan pairs of one global iteration in one call; the pairs run concurrently on the
+        context's worker streams.  pairs: [(src, tgt)]; ranges: [(q_begin, q_count)] or None.
+        Returns a list of PairMoments2 (host) or, with dev_ptr (device [n][32] float64), None."""
+        n = len(pairs)
+        src = (C.c_int * n)(*[int(a) for a, _ in pairs])
+        dst = (C.c_int * n)(*[int(b) for _, b in pairs])
+        qb = qn = None
+        if ranges is not None:
+            qb = (C.c_size_t * n)(*[int(a) for a, _ in ranges])
+            qn = (C.c_size_t * n)(*[(1 << 62) if c is None else int(c) for _, c in ranges])
+        o = np.ascontiguousarray(origin, np.float64)
+        out = None if dev_ptr else (PairMoments2 * n)()
+        _chk(_lib.mvr_pair_moments2_batch(self._h, n, src, dst, float(max_dist), int(reciprocal), int(fma), qb, qn,
+                                          _p(o, C.c_double), out, _vp(dev_ptr) if dev_ptr else None), self._h)
+        return None if dev_ptr else list(out)
 
     def pair_moments2_from_corr(self, s, t, query, match, origin) -> PairMoments2:
         q = np.ascontiguousarray(query, np.int32)

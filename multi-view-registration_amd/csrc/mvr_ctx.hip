@@ -24,10 +24,18 @@ int set_error(Ctx *c, int status, const char *what, hipError_t e)
   return status;
 }
 
+static hipEvent_t take_event(Ctx *c)
+{
+  if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+
 ProfScope::ProfScope(Ctx *ctx, int family, double w) : c(ctx), fam(family), work(w)
 {
-  if (!c->prof) return;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+  if (!c->prof || !((c->prof_mask >> family) & 1u)) return;
+  a = take_event(c); b = take_event(c);
+  if (!a || !b) { a = b = nullptr; return; }
   (void)hipEventRecord(a, c->stream);
 }
 ProfScope::ProfScope(Ctx *ctx, int family, const void *dev_count, int bytes, double per_cnt, double upper_bound, int shards)
@@ -55,6 +63,13 @@ namespace {
 
 int prof_drain(Ctx *c)
 {
+  for (Ctx *w : c->workers) {          // worker launches are accounted in the parent
+    if (int rc = prof_drain(w)) return rc;
+    for (int f = 0; f < MVR_K_COUNT; ++f) {
+      c->prof_launches[f] += w->prof_launches[f]; c->prof_ms[f] += w->prof_ms[f]; c->prof_work[f] += w->prof_work[f];
+      w->prof_launches[f] = 0; w->prof_ms[f] = 0.0; w->prof_work[f] = 0.0;
+    }
+  }
   if (c->recs.empty()) return MVR_OK;
   MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (auto &r : c->recs) {
@@ -69,7 +84,7 @@ int prof_drain(Ctx *c)
         c->prof_work[r.family] += r.h_count ? (double)*r.h_count * r.per_count : r.work;
       }
     }
-    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    c->event_pool.push_back(r.a); c->event_pool.push_back(r.b);
   }
   c->recs.clear();
   c->h_counts_used = 0;
@@ -100,6 +115,8 @@ void cloud_free(Cloud &cl)
   if (cl.sorted) (void)hipFree(cl.sorted);
   if (cl.tlo) (void)hipFree(cl.tlo);
   if (cl.thi) (void)hipFree(cl.thi);
+  if (cl.cbox) (void)hipFree(cl.cbox);
+  if (cl.sbox) (void)hipFree(cl.sbox);
   if (cl.nrm) (void)hipFree(cl.nrm);
   cl.order.reset();
   cl = Cloud();
@@ -222,19 +239,21 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return MVR_E_HIP; }
   c->n_cu = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; c->name = prop.gcnArchName;
   if (const char *m = std::getenv("MVR_NN_MODE")) c->nn_mode = std::atoi(m);   // 0 brute force, 1 culled (default)
+  if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
+  if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MVR_E_HIP; }
     c->own_stream = true;
   }
-  if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->evals, 2 * kEvalRegion * sizeof(uint64_t)) != hipSuccess ||
+  if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->evals, (2 * kEvalRegion + kTraceRec * kTraceBlocks) * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc(&c->bbox, 64) != hipSuccess || hipMalloc(&c->moments, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&c->h_moments, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&c->h_counts, kProfCounts * sizeof(uint64_t)) != hipSuccess) {
     mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(c));
     return MVR_E_HIP;
   }
-  (void)hipMemset(c->evals, 0, 2 * kEvalRegion * sizeof(uint64_t));
+  (void)hipMemset(c->evals, 0, (2 * kEvalRegion + kTraceRec * kTraceBlocks) * sizeof(uint64_t));
   *out = reinterpret_cast<mvr_ctx *>(c);
   return MVR_OK;
 }
@@ -247,11 +266,19 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   Ctx *c = CTX(ctx);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (Ctx *w : c->workers) {
+    w->slots[0] = Cloud(); w->slots[1] = Cloud();      // borrowed views: nothing to free
+    (void)mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(w));
+  }
+  c->workers.clear();
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (auto &s : c->slots) cloud_free(s);
   c->orders.clear();
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -633,6 +660,77 @@ API int mvr_pair_moments2(mvr_ctx *ctx, int ss, int ts, double max_dist, int rec
   return MVR_OK;
 }
 
+// Worker k of a context: created on first use, with a private non-blocking stream.
+static int get_worker(Ctx *c, size_t k, Ctx **out)
+{
+  while (c->workers.size() <= k) {
+    mvr_ctx *w = nullptr;
+    if (int rc = mvr_ctx_create_on_stream(&w, c->device, nullptr)) return set_error(c, rc, "worker context");
+    CTX(w)->parent = c;
+    c->workers.push_back(CTX(w));
+  }
+  Ctx *w = c->workers[k];
+  w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->prof = c->prof; w->prof_mask = c->prof_mask;
+  if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
+    return set_error(c, MVR_E_HIP, "worker event");
+  *out = w;
+  return MVR_OK;
+}
+
+API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const int *dst, double max_dist,
+                                int reciprocal, int fma, const size_t *q_begin, const size_t *q_count,
+                                const double origin[3], mvr_pair_moments2_t *out, double *dev_out)
+{
+  if (!ctx || n_pairs < 0 || (n_pairs && (!src || !dst)) || !origin || (!out && !dev_out)) return MVR_E_ARG;
+  for (int k = 0; k < n_pairs; ++k) if (!slot_ok(src[k]) || !slot_ok(dst[k])) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  if (n_pairs == 0) return MVR_OK;
+  const int n_workers = std::max(1, std::min(c->pair_streams, n_pairs));
+  double *table = dev_out;
+  if (!table) {                      // results wanted on the host: stage them in a device table first
+    if (int rc = ensure(c, c->batch_table, c->batch_cap, (size_t)n_pairs * 32)) return rc;
+    table = c->batch_table;
+  }
+  // everything the workers only READ is prepared here, on the caller's stream
+  if (c->nn_mode != 0)
+    for (int k = 0; k < n_pairs; ++k) {
+      if (int rc = ensure_index(c, c->slots[src[k]])) return rc;
+      if (int rc = ensure_index(c, c->slots[dst[k]])) return rc;
+    }
+  if (!c->ev_fork) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  MVR_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+  int status = MVR_OK;
+  for (int k = 0; k < n_pairs && status == MVR_OK; ++k) {
+    Ctx *w = nullptr;
+    if ((status = get_worker(c, (size_t)(k % n_workers), &w)) != MVR_OK) break;
+    if (k < n_workers && hipStreamWaitEvent(w->stream, c->ev_fork, 0) != hipSuccess) { status = set_error(c, MVR_E_HIP, "fork"); break; }
+    w->slots[0] = c->slots[src[k]];        // borrowed views (pointers + shared ordering); the parent keeps ownership
+    w->slots[1] = c->slots[dst[k]];
+    const size_t ns = w->slots[0].n;
+    const size_t qb = q_begin ? q_begin[k] : 0, qn = q_count ? q_count[k] : ns;
+    status = moments2_impl(w, 0, 1, max_dist, reciprocal, fma, qb, qn, origin, table + (size_t)k * 32);
+    if (status != MVR_OK) c->last_error = w->last_error;
+  }
+  // join: the caller's stream continues after every worker; always executed so that no borrowed view outlives the call
+  for (int k = 0; k < n_workers && (size_t)k < c->workers.size(); ++k) {
+    Ctx *w = c->workers[k];
+    if (w->ev_join && hipEventRecord(w->ev_join, w->stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, w->ev_join, 0);
+    else (void)hipStreamSynchronize(w->stream);
+    w->slots[0] = Cloud(); w->slots[1] = Cloud();
+  }
+  if (status != MVR_OK) return status;
+  if (out) {
+    static_assert(sizeof(mvr_pair_moments2_t) == 31 * sizeof(double), "moments2 layout");
+    std::vector<double> h((size_t)n_pairs * 32);
+    MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n_pairs; ++k) std::memcpy(&out[k], &h[(size_t)k * 32], sizeof(mvr_pair_moments2_t));
+  }
+  return MVR_OK;
+}
+
 API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t *query, const int32_t *match,
                                     size_t m, const double origin[3], mvr_pair_moments2_t *out)
 {
@@ -796,6 +894,8 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "nn_blocks_per_cu")) c->nn_blocks_per_cu = value;
   else if (!std::strcmp(key, "nn_mode")) c->nn_mode = value;
   else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
+  else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
+  else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
   else return MVR_E_ARG;
   return MVR_OK;
 }
@@ -823,6 +923,19 @@ API int mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset)
                  (unsigned long long)ph[5], ph[5] ? (double)ph[0] / ph[5] : 0.0, ph[5] ? (double)ph[1] / ph[5] : 0.0,
                  ph[5] ? (double)ph[2] / ph[5] : 0.0, ph[5] ? (double)ph[3] / ph[5] : 0.0, ph[5] ? (double)ph[4] / ph[5] : 0.0);
   }
+  if (const char *path = std::getenv("MVR_STAMP_TRACE")) {     // per-block records of the LAST culled launch -> text file
+    std::vector<uint64_t> tr(kTraceRec * kTraceBlocks);
+    MVR_HIP_TRY(c, hipMemcpy(tr.data(), c->evals + 2 * kEvalRegion, tr.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (FILE *f = std::fopen(path, "w")) {
+      for (size_t k = 0; k < kTraceBlocks; ++k)
+        if (tr[kTraceRec * k + 1]) {
+          std::fprintf(f, "%zu", k);
+          for (size_t j = 0; j < kTraceRec; ++j) std::fprintf(f, " %llu", (unsigned long long)tr[kTraceRec * k + j]);
+          std::fprintf(f, "\n");
+        }
+      std::fclose(f);
+    }
+  }
   if (std::getenv("MVR_STAMP_DUMP")) {
     std::fprintf(stderr, "[mvr stamp] waves by tiles evaluated (count:mean kcycles):");
     for (int k = 0; k < 32; ++k) {
@@ -844,6 +957,7 @@ API int mvr_prof_enable(mvr_ctx *ctx, int on)
   Ctx *c = CTX(ctx);
   if (!on) { if (int rc = prof_drain(c)) return rc; }
   c->prof = on != 0;
+  c->prof_mask = (on == 2) ? (1u << MVR_K_NN) : ~0u;       // 2: time the search kernels only (cheapest)
   return MVR_OK;
 }
 

@@ -22,13 +22,17 @@
 // work).  The four groups read four different addresses; the group regions
 // are 65 float4 apart so that they fall into disjoint LDS banks.
 //
-// A tile is visited only if SOME query of the set can still find an
-// equal-or-closer point inside the tile's box (exact per-query point/box
-// test with a 1e-5 relative safety margin for the rounding of the box
-// distance), so every point that could win or tie is evaluated: results stay
-// exact.  Inside a tile the inner loop is the brute-force one (min3 tracking
-// per 32-target sub-tile); the index is recovered once, at the very end, by a
-// re-scan of the winning sub-tile that the 4 lane groups share (8 points each).
+// Culling is two-level.  A 256-point tile is looked at only if SOME query of
+// the set can still find an equal-or-closer point inside the tile's box (exact
+// per-query point/box test with a 1e-5 relative safety margin for the rounding
+// of the box distance); the same test then runs on the boxes of the tile's four
+// 64-point CELLS, and only the cells that pass are queued.  The wave evaluates
+// four queued cells at a time, one per lane group, wherever they come from
+// (tools/cull_model.py: 64-point boxes need 2.3x fewer evaluations than 256-point
+// ones on the turntable pair).  Every point that could win or tie is still
+// evaluated: results stay exact.  The inner loop is the brute-force one (min3
+// tracking per 32-target sub-tile); the index is recovered once, at the very end,
+// by a re-scan of the winning sub-tile that the 4 lane groups share (8 points each).
 // Compiled with -ffp-contract=off.
 #include "mvr_internal.h"
 
@@ -104,23 +108,33 @@ __device__ __forceinline__ float lane_value(float v, int lane_uniform)     // v 
 #define MVR_CLK() 0ull
 #endif
 
-template <bool FMA, int Q>
+template <bool FMA, int Q, int W>
 __device__ __forceinline__ void
 nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,
                const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
-               const float4 *__restrict__ tlo, const float4 *__restrict__ thi, uint32_t n_tiles, float cap2,
-               nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals)
+               const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
+               const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys,
+               unsigned long long *__restrict__ evals)
 {
   constexpr int NQ = 4 * Q;      // queries per lane
   constexpr int NB = 64 * Q;     // queries per block
-  static_assert(16 * NB * sizeof(nnkey_t) <= 4 * 4 * kGrpPitch * sizeof(float4), "partials must fit the tile buffers");
-  __shared__ float4 lds[4][4 * kGrpPitch];
+  static_assert(W == 1 || W == 2 || W == 4, "waves per query set");
+  static_assert(4 * NB * sizeof(nnkey_t) <= 4 * kGrpPitch * sizeof(float4), "partials must fit the tile buffers");
+  __shared__ float4 lds[W][4 * kGrpPitch];
   __shared__ unsigned sbest[NB];
   // readfirstlane tells the compiler the wave index is wave-uniform: everything
   // derived from it (tile ids, loop conditions) then lives in SGPRs / scalar branches
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int g = lane >> 4, l16 = lane & 15;
   const unsigned long long st_entry = MVR_CLK();
+#ifdef MVR_TRACE      // diagnostic build: phase marks of wave 0 (100 MHz clock), first occurrence of each
+  const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long trm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned trq = 0;
+#define MVR_MARK(i) do { if (!trm[i]) trm[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MVR_MARK(i) do { } while (0)
+#endif
 #ifdef MVR_STAMP
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
   if (evals && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(evals + kEvalRegion + 15, st_rt0);
@@ -129,6 +143,27 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
   const uint32_t b_begin = blockIdx.x * NB;
   if (b_begin >= nq) return;                      // block-uniform
+
+  // This wave's own tiles (own tile i <-> tile W i + wv) are looked at in ballot BLOCKS of 64; block k lies
+  // inside the super boxes W k .. W k + W - 1 (one box per 64 consecutive tiles of the Hilbert order).  Lane l
+  // keeps the box of block sbase + l, so one load instruction decides which blocks are worth opening at all:
+  // a query set reads a handful of the tile boxes instead of all of them.  First chunk requested here, early.
+  const uint32_t n_own = (n_tiles > (uint32_t)wv) ? (n_tiles - (uint32_t)wv + (uint32_t)W - 1u) / (uint32_t)W : 0u;
+  const uint32_t n_blk = (n_own + 63u) / 64u, n_super = (n_tiles + 63u) / 64u;
+  float sblo[3], sbhi[3];
+  auto load_block_boxes = [&](uint32_t sbase) {
+    sblo[0] = sblo[1] = sblo[2] = 3.0e38f; sbhi[0] = sbhi[1] = sbhi[2] = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const uint32_t sb = (uint32_t)W * (sbase + lane) + (uint32_t)j;
+      if (sbase + lane < n_blk && sb < n_super) {
+        const float4 a = sbox[2 * (size_t)sb], b = sbox[2 * (size_t)sb + 1];
+        sblo[0] = fminf(sblo[0], a.x); sblo[1] = fminf(sblo[1], a.y); sblo[2] = fminf(sblo[2], a.z);
+        sbhi[0] = fmaxf(sbhi[0], b.x); sbhi[1] = fmaxf(sbhi[1], b.y); sbhi[2] = fmaxf(sbhi[2], b.z);
+      }
+    }
+  };
+  load_block_boxes(0);
 
   // query q of this lane = position b_begin + 16 q + l16 (the same in all 4 groups);
   // positions past the end repeat the block's first query (a duplicate changes no bound)
@@ -167,39 +202,57 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   }
   if (threadIdx.x < NB) sbest[threadIdx.x] = 0x7F800000u;   // +inf
   __syncthreads();
+  MVR_MARK(0);
 
   float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
-  uint32_t tiles_done = 0, tiles_tested = 0;
+  uint32_t cells_done = 0, tiles_tested = 0;
 
   auto shared_bound = [&](int j) {
     return fminf(__uint_as_float(__atomic_load_n(&sbest[j * 64 + lane], __ATOMIC_RELAXED)), cap2);
   };
-
-  // register prefetch buffer: the NEXT tile's points travel from L2 while the
-  // current tile is being evaluated out of LDS
-  float4 pre[kCullTile / 64];
-  auto fetch = [&](uint32_t tile) {
+  // the bounds the box tests use live in registers: re-read from LDS once per group of tests (after every
+  // evaluation and whenever four more cells are looked for), not once per test -- a candidate costs ~5 box
+  // tests and each LDS round trip in that serial chain was ~100 ns of a wave's life (tools/block_trace.py)
+  float bnd[Q];
 #pragma unroll
-    for (int r = 0; r < kCullTile / 64; ++r) {
-      const uint32_t j = tile * kCullTile + r * 64 + lane;
-      pre[r] = (j < nt) ? ts[j] : make_float4(1.0e18f, 1.0e18f, 1.0e18f, 0.f);
+  for (int j = 0; j < Q; ++j) bnd[j] = cap2;
+
+  // register prefetch buffer: the NEXT four cells' points travel from L2 while the
+  // current four are being evaluated out of LDS (coordinates only: the index, w, is
+  // not needed before the final re-scan).  A missing cell / point is +inf: never a minimum.
+  float pre[4][3];
+  uint32_t gmask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) gmask[r] = (g == r) ? 0xFFFFFFFFu : 0u;
+  auto fetch = [&](const uint32_t (&cells)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t j = cells[r] * 64u + lane;
+      pre[r][0] = pre[r][1] = pre[r][2] = __builtin_inff();
+      if (cells[r] != kNone && j < nt) { const float4 p = ts[j]; pre[r][0] = p.x; pre[r][1] = p.y; pre[r][2] = p.z; }
     }
   };
-  auto stage = [&]() {      // targets 64 r .. 64 r + 63 of the tile -> region of lane group r
+  auto stage = [&](const uint32_t (&cells)[4]) {      // cell r -> LDS region of lane group r (a dropped cell becomes +inf)
 #pragma unroll
-    for (int r = 0; r < kCullTile / 64; ++r) T[r * kGrpPitch + lane] = pre[r];
+    for (int r = 0; r < 4; ++r) {
+      const bool live = cells[r] != kNone;
+      T[r * kGrpPitch + lane] = live ? make_float4(pre[r][0], pre[r][1], pre[r][2], 0.f)
+                                     : make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+    }
     wave_lds_sync();
   };
 
-  // evaluates the tile currently staged in this wave's LDS buffer: group g takes targets 64 g .. 64 g + 63
-  auto process = [&](uint32_t tile) {
+  // evaluates the four cells currently staged in this wave's LDS buffer: lane group g takes cell g
+  auto process = [&](const uint32_t (&cells)[4]) {
     const float4 *Tg = T + g * kGrpPitch;
+    // this lane group's cell (bit masks: a select chain over g gets turned into a scratch-memory table)
+    const uint32_t mycell = (cells[0] & gmask[0]) | (cells[1] & gmask[1]) | (cells[2] & gmask[2]) | (cells[3] & gmask[3]);
 #pragma unroll 1
     for (int s = 0; s < 64; s += kSub) {
       float m[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) m[q] = __builtin_inff();
-#pragma unroll 4
+#pragma unroll 2
       for (int k = 0; k < kSub; k += 2) {
         const float4 a = Tg[s + k], b = Tg[s + k + 1];
 #pragma unroll
@@ -209,7 +262,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
           m[q] = __builtin_fminf(__builtin_fminf(m[q], da), db);
         }
       }
-      const uint32_t sub = tile * (kCullTile / kSub) + (uint32_t)(g * 64 + s) / kSub;
+      const uint32_t sub = mycell * (64 / kSub) + (uint32_t)s / kSub;      // = first sorted index / kSub
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         if (m[q] < best[q]) { best[q] = m[q]; bsub[q] = sub; }
@@ -223,13 +276,14 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       }
     }
     wave_lds_sync();     // all lanes done reading before the buffer is overwritten
-    ++tiles_done;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cells_done += (cells[r] != kNone) ? 1u : 0u;
     // publish this wave's bests, then a wave max-reduction of the set-wide bounds -> new U
 #pragma unroll
     for (int q = 0; q < NQ; ++q) atomicMin(&sbest[q * 16 + l16], __float_as_uint(best[q]));
     float w = 0.f;
 #pragma unroll
-    for (int j = 0; j < Q; ++j) w = fmaxf(w, shared_bound(j));
+    for (int j = 0; j < Q; ++j) { bnd[j] = shared_bound(j); w = fmaxf(w, bnd[j]); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
     U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fminf(cap2, w))));
@@ -237,8 +291,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 
   // exact per-query test: the tile is needed iff SOME query of this set can
   // still find an equal-or-closer point inside the tile's box
-  auto needed = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
-                    const float hi_z) {
+  auto needed_mask = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
+                         const float hi_z) -> unsigned long long {
     bool need = false;
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
@@ -246,38 +300,69 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       const float dy = fmaxf(0.f, fmaxf(lo_y - ty[j], ty[j] - hi_y));
       const float dz = fmaxf(0.f, fmaxf(lo_z - tz[j], tz[j] - hi_z));
       const float pb = dx * dx + dy * dy + dz * dz;
-      need |= (pb * 0.99999f <= shared_bound(j));
+      need |= (pb * 0.99999f <= bnd[j]);
     }
     ++tiles_tested;
-    return __any(need) != 0;
+    return __ballot(need);
   };
+  auto needed = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
+                    const float hi_z) { return needed_mask(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) != 0ull; };
 
-  // candidate stream over this wave's own tiles (tile = 4*i + wv, lane <-> i):
-  // round 0 = tiles whose box overlaps the query box, round 1 = the rest within U.
-  const uint32_t n_own = (n_tiles > (uint32_t)wv) ? (n_tiles - (uint32_t)wv + 3u) / 4u : 0u;
+  // candidate stream over this wave's own tiles: round 0 = tiles whose box overlaps the
+  // query box, round 1 = the rest within U.  Distances are NaN where there is no block / tile.
+  auto block_dist = [&](uint32_t sbase) {
+    return (sbase + lane < n_blk) ? box_dist2(qlo, qhi, make_float4(sblo[0], sblo[1], sblo[2], 0.f), make_float4(sbhi[0], sbhi[1], sbhi[2], 0.f))
+                                  : __builtin_nanf("");
+  };
   int round = 0;
-  uint32_t ibase = 0;                 // next block of 64 own tiles to ballot
-  uint32_t cbase = 0;                 // block the current mask belongs to
-  unsigned long long mask = 0ull;
-  float lb = __builtin_inff();
-  float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;     // this lane's tile box of the current ballot block
-  float sel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};               // box of the tile last returned (wave-uniform)
+  uint32_t sbase = 0;                 // first block of the chunk of 64 blocks held in sb_lb
+  bool chunk_open = false;
+  float sb_lb = block_dist(0);        // set box <-> block box
+  unsigned long long sb_mask = 0ull;  // blocks of the chunk still to open in this round
+  uint32_t cbase = 0;                 // first own tile of the open block
+  unsigned long long mask = 0ull, mask0 = 0ull;      // its candidate tiles: remaining / as balloted
+  float lb = 0.f;
+  float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;     // this lane's tile box of the open block
+  float4 rec = blo;                   // cell boxes of the block's first 8 candidates: lane 8 c + k = float4 k of candidate c
+  int last_b = 0;                     // bit of the tile last returned
+  float sel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};               // its box (wave-uniform)
   auto advance = [&]() -> uint32_t {
+    if (n_blk == 0) return kNone;
     for (;;) {
       while (mask == 0ull) {
-        if (ibase >= n_own) {
-          if (round == 1) return kNone;
-          round = 1; ibase = 0;
-          if (n_own == 0) return kNone;
+        while (sb_mask == 0ull) {
+          if (chunk_open) {           // this chunk is done for this round
+            sbase += 64;
+            if (sbase >= n_blk) {
+              if (round == 1) return kNone;
+              round = 1; sbase = 0;
+            }
+            if (n_blk > 64) { load_block_boxes(sbase); sb_lb = block_dist(sbase); }     // a single chunk stays in registers
+          }
+          chunk_open = true;
+          // round 1 re-opens overlapping blocks too: they can hold tiles that do not overlap
+          sb_mask = __ballot((round == 0) ? (sb_lb == 0.f) : (sb_lb * 0.99999f <= U));
         }
-        const uint32_t i = ibase + lane;
-        const uint32_t t = 4u * i + (uint32_t)wv;
-        lb = __builtin_inff();
+        const int k = __ffsll((long long)sb_mask) - 1;
+        sb_mask &= sb_mask - 1;
+        if (round == 1 && lane_value(sb_lb, k) * 0.99999f > U) continue;   // U shrank since the ballot
+        cbase = (sbase + (uint32_t)k) * 64u;
+        const uint32_t i = cbase + lane;
+        const uint32_t t = (uint32_t)W * i + (uint32_t)wv;
+        lb = __builtin_nanf("");
         if (i < n_own) { blo = tlo[t]; bhi = thi[t]; lb = box_dist2(qlo, qhi, blo, bhi); }
-        const bool pred = (i < n_own) && ((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
-        mask = __ballot(pred);
-        cbase = ibase;
-        ibase += 64;
+        mask = mask0 = __ballot((round == 0) ? (lb == 0.f) : (lb > 0.f && lb * 0.99999f <= U));
+        // one load fetches the cell boxes of up to 8 candidate tiles: lane l takes float4 (l & 7) of candidate l >> 3
+        uint32_t mine = kNone;
+        unsigned long long mm = mask0;
+#pragma unroll
+        for (int cnd = 0; cnd < 8; ++cnd) {
+          if (mm == 0ull) break;
+          const int bit = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          if ((lane >> 3) == cnd) mine = (uint32_t)W * (cbase + (uint32_t)bit) + (uint32_t)wv;
+        }
+        if (mine != kNone) rec = cbox[(size_t)mine * 8 + (lane & 7)];
       }
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
@@ -285,52 +370,134 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       // the candidate's box sits in lane b's registers: v_readlane it into SGPRs instead of re-reading memory
       sel[0] = lane_value(blo.x, b); sel[1] = lane_value(blo.y, b); sel[2] = lane_value(blo.z, b);
       sel[3] = lane_value(bhi.x, b); sel[4] = lane_value(bhi.y, b); sel[5] = lane_value(bhi.z, b);
-      if (needed(sel[0], sel[1], sel[2], sel[3], sel[4], sel[5])) return 4u * (cbase + (uint32_t)b) + (uint32_t)wv;
+      if (needed(sel[0], sel[1], sel[2], sel[3], sel[4], sel[5])) {
+        last_b = b;
+        return (uint32_t)W * (cbase + (uint32_t)b) + (uint32_t)wv;
+      }
     }
+  };
+
+  // queue of needed cells: entry k lives in lane k & 63 of these registers (written under a lane
+  // compare, read back with v_readlane); it never holds more than 3 + 4 cells
+  uint32_t pq_cell = 0;
+  float pq_box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t pq_head = 0, pq_tail = 0;
+  // the four cells of a candidate tile: one 128-byte record {lo, hi} x 4, tested like the tile itself
+  auto expand_tile = [&](uint32_t tile) {
+    const int cnd = __popcll(mask0 & ((1ull << last_b) - 1ull));         // rank among the block's candidates
+    float4 r8 = rec;
+    int l0 = 8 * cnd;
+    if (cnd >= 8) { r8 = cbox[(size_t)tile * 8 + (lane & 7)]; l0 = 0; }   // beyond the prefetched eight: read it now
+    float bx[4][6];
+    unsigned long long nd[4];
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx) {       // four independent tests first, their ballots afterwards
+      bx[cidx][0] = lane_value(r8.x, l0 + 2 * cidx); bx[cidx][1] = lane_value(r8.y, l0 + 2 * cidx); bx[cidx][2] = lane_value(r8.z, l0 + 2 * cidx);
+      bx[cidx][3] = lane_value(r8.x, l0 + 2 * cidx + 1); bx[cidx][4] = lane_value(r8.y, l0 + 2 * cidx + 1); bx[cidx][5] = lane_value(r8.z, l0 + 2 * cidx + 1);
+      nd[cidx] = needed_mask(bx[cidx][0], bx[cidx][1], bx[cidx][2], bx[cidx][3], bx[cidx][4], bx[cidx][5]);
+    }
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx) {
+      if (nd[cidx] != 0ull) {
+        const int at = (int)(pq_tail & 63u);
+        pq_cell = (lane == at) ? tile * 4u + (uint32_t)cidx : pq_cell;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pq_box[k] = (lane == at) ? bx[cidx][k] : pq_box[k];
+        ++pq_tail;
+      }
+    }
+  };
+  // up to four queued cells (fewer only when the candidate stream is exhausted); 0 = done
+  auto next_quad = [&](uint32_t (&cells)[4], float (&boxes)[4][6]) -> uint32_t {
+    if (W > 1) {                      // pick up what the other waves of the set have found meanwhile
+#pragma unroll
+      for (int j = 0; j < Q; ++j) bnd[j] = shared_bound(j);
+    }
+    while (pq_tail - pq_head < 4u) {
+      const uint32_t tile = advance();
+      if (tile == kNone) break;
+      expand_tile(tile);
+    }
+    const uint32_t n = min(pq_tail - pq_head, 4u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cells[r] = kNone;
+      if ((uint32_t)r < n) {
+        const int at = (int)((pq_head + (uint32_t)r) & 63u);
+        cells[r] = (uint32_t)__builtin_amdgcn_readlane((int)pq_cell, at);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) boxes[r][k] = lane_value(pq_box[k], at);
+      }
+    }
+    pq_head += n;
+    return n;
   };
 
   unsigned long long st_stage = 0, st_adv = 0, st_proc = 0, st_reval = 0;
   const unsigned long long st_begin = MVR_CLK();
-  uint32_t cur = advance();
-  if (cur != kNone) fetch(cur);
-  while (cur != kNone) {
+  uint32_t cur[4], nxt[4];
+  float cbx[4][6], nbx[4][6];
+  uint32_t n_cur = next_quad(cur, cbx);
+  MVR_MARK(1);
+  if (n_cur) fetch(cur);
+  while (n_cur) {
     const unsigned long long t0 = MVR_CLK();
-    stage();                                  // registers -> LDS (waits for the prefetch)
+    stage(cur);                               // registers -> LDS (waits for the prefetch)
+    MVR_MARK(2);
+#ifdef MVR_TRACE
+    ++trq;
+#endif
     const unsigned long long t1 = MVR_CLK();
-    uint32_t nxt = advance();                 // chosen with the bounds as they are NOW
-    if (nxt != kNone) fetch(nxt);             // in flight during the evaluation below
+    uint32_t n_nxt = next_quad(nxt, nbx);     // chosen with the bounds as they are NOW
+    if (n_nxt) fetch(nxt);                    // in flight during the evaluation below
     const unsigned long long t2 = MVR_CLK();
+    MVR_MARK(3);
     process(cur);
+    MVR_MARK(4);
     const unsigned long long t3 = MVR_CLK();
-    // the bounds have shrunk: re-validate the prefetched tile (its data is dropped if it is no longer needed)
-    while (nxt != kNone && !needed(sel[0], sel[1], sel[2], sel[3], sel[4], sel[5])) {
-      nxt = advance();
-      if (nxt != kNone) fetch(nxt);
+    // the bounds have shrunk: re-validate the prefetched cells (a cell that is no longer needed is dropped,
+    // its lane group idles; if none is left the next four are requested)
+    while (n_nxt) {
+      uint32_t live = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nxt[r] != kNone && !needed(nbx[r][0], nbx[r][1], nbx[r][2], nbx[r][3], nbx[r][4], nbx[r][5])) nxt[r] = kNone;
+        live += (nxt[r] != kNone) ? 1u : 0u;
+      }
+      if (live) break;
+      n_nxt = next_quad(nxt, nbx);
+      if (n_nxt) fetch(nxt);
     }
     st_stage += t1 - t0; st_adv += t2 - t1; st_proc += t3 - t2; st_reval += MVR_CLK() - t3;
-    cur = nxt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cur[r] = nxt[r];
+    n_cur = n_nxt;
   }
+  (void)cbx;
   const unsigned long long st_loopend = MVR_CLK();
+  MVR_MARK(5);
 
-  // ---- combine: 16 partial results per query (4 waves x 4 lane groups) meet in LDS (over the tile buffers)
+  // ---- combine: 4 W partial results per query (W waves x 4 lane groups) meet in LDS (over the tile buffers)
   __syncthreads();
-  nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [16][NB]: (d2 bits, sub-tile)
+  nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [4 W][NB]: (d2 bits, sub-tile)
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
     part[(wv * 4 + g) * NB + q * 16 + l16] = ((nnkey_t)__float_as_uint(best[q]) << 32) | bsub[q];
   __syncthreads();
-  // wave wv finishes the queries wv + 4 j of every lane column; the index (lowest original
-  // index at distance == best) comes from one re-scan of the winning sub-tile, 8 points per lane group
+  MVR_MARK(6);
+  // the waves share out the 4 Q lane columns (16 queries each); the index (lowest original index at
+  // distance == best) comes from one re-scan of the winning sub-tile, 8 points per lane group
 #pragma unroll
-  for (int j = 0; j < Q; ++j) {
-    const int q = wv + 4 * j, i = q * 16 + l16;
+  for (int col = 0; col < 4 * Q; ++col) {
+    if ((col % W) != wv) continue;              // wave-uniform
+    const int i = col * 16 + l16;
     // this query's coordinates again (re-read: indexing the register arrays by the wave id would put them in scratch)
     const uint32_t pos = b_begin + i, rpos = pos < nq ? pos : b_begin;
     const float4 fq = qs[qlist ? qlist[rpos] : (q_begin + rpos)];
     const float fx = fq.x, fy = fq.y, fz = fq.z;
     nnkey_t pm = kKeyInit;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) pm = min(pm, part[p * NB + i]);
+    for (int p = 0; p < 4 * W; ++p) pm = min(pm, part[p * NB + i]);
     const uint32_t dbits = (uint32_t)(pm >> 32), sub = (uint32_t)pm;
     const float d = __uint_as_float(dbits);
     const bool found = sub != kNone && d <= cap2;
@@ -339,7 +506,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       o = span_argmin<FMA, kSub / 4>(ts, nt, sub * kSub + g * (kSub / 4), d, fx, fy, fz);
       // rare: another partial reached the same distance in a different sub-tile
 #pragma unroll 1
-      for (int p = 0; p < 16; ++p) {
+      for (int p = 0; p < 4 * W; ++p) {
         const nnkey_t k = part[p * NB + i];
         if ((uint32_t)(k >> 32) == dbits && (uint32_t)k != sub && (uint32_t)k != kNone)
           o = min(o, span_argmin<FMA, kSub / 4>(ts, nt, (uint32_t)k * kSub + g * (kSub / 4), d, fx, fy, fz));
@@ -352,23 +519,39 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
     }
   }
+  MVR_MARK(7);
   if (evals && lane == 0) {
     const uint32_t nvalid = min(nq - b_begin, (uint32_t)NB);
-    const unsigned long long e = (unsigned long long)tiles_done * kCullTile * nvalid;
+    const unsigned long long e = (unsigned long long)cells_done * 64ull * nvalid;
     // sharded counters: one 128-byte line per shard, or thousands of waves serialise on one address
     unsigned long long *a = evals + (size_t)(blockIdx.x & (kEvalShards - 1)) * kEvalStride;
     unsigned long long *b = a + kEvalRegion;
     atomicAdd(a, e);              // this launch (profiling)
     atomicAdd(b, e);              // running total (mvr_icp_stats.evals)
-    atomicMax(b + 1, (unsigned long long)tiles_done);     // diagnostics: heaviest wave
+    atomicMax(b + 1, (unsigned long long)cells_done);     // diagnostics: heaviest wave (cells evaluated)
     atomicMax(b + 2, (unsigned long long)tiles_tested);
+#ifdef MVR_TRACE
+    if (blockIdx.x < kTraceBlocks) {     // block record: start (first wave), end (last wave), cells (max over waves), XCC id
+      unsigned long long *tr = evals + 2 * kEvalRegion + kTraceRec * (size_t)blockIdx.x;
+      if (wv == 0) {
+        tr[0] = tr_rt0;
+        for (int k = 0; k < 8; ++k) tr[4 + k] = trm[k];
+        tr[12] = trq; tr[13] = tiles_tested;
+      }
+      atomicMax(tr + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+      atomicMax(tr + 2, (unsigned long long)cells_done);
+      unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      tr[3] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 #ifdef MVR_STAMP
     atomicAdd(b + 4, st_stage); atomicAdd(b + 5, st_adv); atomicAdd(b + 6, st_proc); atomicAdd(b + 7, st_reval);
     atomicAdd(b + 8, st_loopend - st_begin); atomicAdd(b + 9, 1ull); atomicAdd(b + 10, st_begin - st_entry);
     atomicAdd(b + 11, MVR_CLK() - st_loopend); atomicAdd(b + 12, MVR_CLK() - st_entry);
     atomicAdd(b + 13, __builtin_amdgcn_s_memrealtime() - st_rt0);
     {   // lifetime by number of tiles evaluated: shard k slot 3 = sum of cycles, shard 32 + k slot 3 = waves
-      const unsigned long long k = min((unsigned long long)tiles_done, 31ull);
+      const unsigned long long k = min((unsigned long long)cells_done, 31ull);
       atomicAdd(evals + kEvalRegion + k * kEvalStride + 3, MVR_CLK() - st_entry);
       atomicAdd(evals + kEvalRegion + (32 + k) * kEvalStride + 3, 1ull);
     }
@@ -384,25 +567,25 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   (void)st_entry; (void)st_stage; (void)st_adv; (void)st_proc; (void)st_reval; (void)st_begin; (void)st_loopend;
 }
 
-// Register budgets: the 64-query kernel is compiled for 4 waves per SIMD (<= 128 VGPRs; measured: 4, 5 and 6 resident waves run
-// equally fast, and the packed-math loop needs even-aligned register pairs), like the 128-query one.
+// One kernel per (queries per set, waves per set); all compiled for 4 waves per SIMD (<= 128 VGPRs:
+// measured, 4, 5 and 6 resident waves run equally fast).
 #ifndef MVR_CULL_WAVES
 #define MVR_CULL_WAVES 4
+#endif
+#ifdef MVR_CULL_WAVES_MAX          // experiments: cap the residency as well
+#define MVR_CULL_WAVES_ATTR MVR_CULL_WAVES, MVR_CULL_WAVES_MAX
+#else
+#define MVR_CULL_WAVES_ATTR MVR_CULL_WAVES
 #endif
 #define MVR_CULL_ARGS                                                                                                  \
   const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,               \
       const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt, const float4 *__restrict__ tlo, \
-      const float4 *__restrict__ thi, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys,                        \
-      unsigned long long *__restrict__ evals
-template <bool FMA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVR_CULL_WAVES))) nn_cull_q1(MVR_CULL_ARGS)
+      const float4 *__restrict__ thi, const float4 *__restrict__ cbox, const float4 *__restrict__ sbox,                \
+      uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals
+template <bool FMA, int Q, int W>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(MVR_CULL_WAVES_ATTR))) nn_cull_kernel(MVR_CULL_ARGS)
 {
-  nn_cull_body<FMA, 1>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, n_tiles, cap2, keys, evals);
-}
-template <bool FMA>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) nn_cull_q2(MVR_CULL_ARGS)
-{
-  nn_cull_body<FMA, 2>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, n_tiles, cap2, keys, evals);
+  nn_cull_body<FMA, Q, W>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, cbox, sbox, n_tiles, cap2, keys, evals);
 }
 #undef MVR_CULL_ARGS
 
@@ -418,16 +601,23 @@ int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const
   // sets win until there are far more sets than the chip holds at once
   int Q = (q_count <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
   if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
-  const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (4 cooperating waves) per query set
+  const int W = (c->cull_w == 1 || c->cull_w == 4) ? c->cull_w : 2;          // waves sharing one query set (measured best: 2)
+  const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (W cooperating waves) per query set
   MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+#ifdef MVR_TRACE
+  MVR_HIP_TRY(c, hipMemsetAsync(c->evals + 2 * kEvalRegion, 0, kTraceRec * kTraceBlocks * sizeof(unsigned long long), c->stream));
+#endif
   ProfScope ps(c, MVR_K_NN, c->evals, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, (double)q_count * (double)t.n,
                kEvalShards);
-#define MVR_LAUNCH_CULL(F, QQ)                                                                                        \
-  hipLaunchKernelGGL((nn_cull_q##QQ<F>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q_begin,      \
-                     (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, n_tiles, cap2, keys,    \
-                     c->evals)
-  if (fma) { if (Q == 2) MVR_LAUNCH_CULL(true, 2); else MVR_LAUNCH_CULL(true, 1); }
-  else     { if (Q == 2) MVR_LAUNCH_CULL(false, 2); else MVR_LAUNCH_CULL(false, 1); }
+#define MVR_LAUNCH_CULL(F, QQ, WW)                                                                                       \
+  hipLaunchKernelGGL((nn_cull_kernel<F, QQ, WW>), dim3(blocks), dim3(64 * WW), 0, c->stream, q.sorted, (uint32_t)q_begin, \
+                     (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, t.cbox, t.sbox, n_tiles,   \
+                     cap2, keys, c->evals)
+#define MVR_LAUNCH_CULL_W(F, QQ)                                                                  \
+  do { if (W == 1) MVR_LAUNCH_CULL(F, QQ, 1); else if (W == 2) MVR_LAUNCH_CULL(F, QQ, 2); else MVR_LAUNCH_CULL(F, QQ, 4); } while (0)
+  if (fma) { if (Q == 2) MVR_LAUNCH_CULL_W(true, 2); else MVR_LAUNCH_CULL_W(true, 1); }
+  else     { if (Q == 2) MVR_LAUNCH_CULL_W(false, 2); else MVR_LAUNCH_CULL_W(false, 1); }
+#undef MVR_LAUNCH_CULL_W
 #undef MVR_LAUNCH_CULL
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;

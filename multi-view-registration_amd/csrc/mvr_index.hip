@@ -130,27 +130,57 @@ __global__ void finish_order_kernel(const uint32_t *__restrict__ perm, size_t n,
   if (k < n) inv[perm[k]] = (uint32_t)k;
 }
 
-// sorted[k] = {pts[perm[k]].xyz, bits(perm[k])}; one wave per 256-point tile also reduces its AABB
+// sorted[k] = {pts[perm[k]].xyz, bits(perm[k])}; one wave per 256-point tile also reduces the AABBs
+// of its four 64-point cells (cbox[tile][cell] = {lo, hi}) and of the tile (their union)
 __global__ void __launch_bounds__(256) refresh_sorted_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ perm,
                                                               size_t n, float4 *__restrict__ sorted,
-                                                              float4 *__restrict__ tlo, float4 *__restrict__ thi)
+                                                              float4 *__restrict__ tlo, float4 *__restrict__ thi,
+                                                              float4 *__restrict__ cbox)
 {
   const int lane = threadIdx.x & 63;
   const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t base = tile * kCullTile;
   if (base >= n) return;
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  float tl[3] = {3.0e38f, 3.0e38f, 3.0e38f}, th[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
   for (int r = 0; r < kCullTile / 64; ++r) {
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};     // an empty cell is never needed
     const size_t k = base + r * 64 + lane;
     if (k < n) {
       const uint32_t o = perm[k];
       float4 v = pts[o];
       v.w = __uint_as_float(o);
       sorted[k] = v;
-      lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
-      hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
+      lo[0] = hi[0] = v.x; lo[1] = hi[1] = v.y; lo[2] = hi[2] = v.z;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      for (int k2 = 0; k2 < 3; ++k2) {
+        lo[k2] = fminf(lo[k2], __shfl_xor(lo[k2], o, 64));
+        hi[k2] = fmaxf(hi[k2], __shfl_xor(hi[k2], o, 64));
+      }
+    if (lane == 0) {
+      cbox[(tile * 4 + r) * 2 + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);
+      cbox[(tile * 4 + r) * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    for (int k2 = 0; k2 < 3; ++k2) { tl[k2] = fminf(tl[k2], lo[k2]); th[k2] = fmaxf(th[k2], hi[k2]); }
+  }
+  if (lane == 0) {
+    tlo[tile] = make_float4(tl[0], tl[1], tl[2], 0.f);
+    thi[tile] = make_float4(th[0], th[1], th[2], 0.f);
+  }
+}
+
+// one wave per super box: the union of 64 consecutive tile boxes
+__global__ void __launch_bounds__(64) super_box_kernel(const float4 *__restrict__ tlo, const float4 *__restrict__ thi,
+                                                        size_t n_tiles, float4 *__restrict__ sbox)
+{
+  const int lane = threadIdx.x;
+  const size_t t = (size_t)blockIdx.x * 64 + lane;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  if (t < n_tiles) {
+    const float4 a = tlo[t], b = thi[t];
+    lo[0] = a.x; lo[1] = a.y; lo[2] = a.z; hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
@@ -159,8 +189,8 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(const float4 *__res
       hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
     }
   if (lane == 0) {
-    tlo[tile] = make_float4(lo[0], lo[1], lo[2], 0.f);
-    thi[tile] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    sbox[2 * (size_t)blockIdx.x] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    sbox[2 * (size_t)blockIdx.x + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
   }
 }
 
@@ -281,15 +311,21 @@ int ensure_index(Ctx *c, Cloud &cl)
       (void)hipStreamSynchronize(c->stream);
       if (cl.tlo) (void)hipFree(cl.tlo);
       if (cl.thi) (void)hipFree(cl.thi);
-      cl.tlo = cl.thi = nullptr; cl.tiles_cap = 0;
+      if (cl.cbox) (void)hipFree(cl.cbox);
+      if (cl.sbox) (void)hipFree(cl.sbox);
+      cl.tlo = cl.thi = cl.cbox = cl.sbox = nullptr; cl.tiles_cap = 0;
       const size_t cap = tiles + tiles / 4 + 16;
       MVR_HIP_TRY(c, hipMalloc(&cl.tlo, cap * sizeof(float4)));
       MVR_HIP_TRY(c, hipMalloc(&cl.thi, cap * sizeof(float4)));
+      MVR_HIP_TRY(c, hipMalloc(&cl.cbox, cap * 8 * sizeof(float4)));
+      MVR_HIP_TRY(c, hipMalloc(&cl.sbox, (cap / 64 + 2) * 2 * sizeof(float4)));
       cl.tiles_cap = cap;
     }
     ProfScope ps(c, MVR_K_GLUE, 36.0 * (double)n);
     hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, cl.pts,
-                       cl.order->perm, n, cl.sorted, cl.tlo, cl.thi);
+                       cl.order->perm, n, cl.sorted, cl.tlo, cl.thi, cl.cbox);
+    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, c->stream, cl.tlo, cl.thi, tiles,
+                       cl.sbox);
     MVR_HIP_TRY(c, hipGetLastError());
     cl.coords_valid = true;
   }

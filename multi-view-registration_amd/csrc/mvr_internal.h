@@ -38,7 +38,9 @@ struct Cloud {
   std::shared_ptr<Order> order;        // null until first needed
   float4 *sorted = nullptr; size_t sorted_cap = 0;
   float4 *tlo = nullptr, *thi = nullptr; size_t tiles_cap = 0;
-  bool coords_valid = false;           // sorted[] / tlo / thi match pts[]
+  float4 *cbox = nullptr;              // [tiles][4 cells][lo, hi]: AABBs of the 64-point cells of every tile
+  float4 *sbox = nullptr;              // [ceil(tiles / 64)][lo, hi]: AABBs of 64 consecutive tiles
+  bool coords_valid = false;           // sorted[] / tlo / thi / cbox match pts[]
   // optional unit normals {nx,ny,nz,0} (point-to-plane extension, K10)
   float4 *nrm = nullptr; size_t nrm_cap = 0;
   bool has_normals = false;
@@ -66,6 +68,7 @@ constexpr int kCullTile = 256;
 // region B = {running total, max tiles per wave, max tiles tested} per shard
 constexpr int kEvalShards = 64, kEvalStride = 16;
 constexpr size_t kEvalRegion = (size_t)kEvalShards * kEvalStride;     // u64 per region
+constexpr size_t kTraceBlocks = 4096, kTraceRec = 16;   // diagnostic builds (-DMVR_TRACE): per-block records of the last launch, after the two regions
 
 // work = `work` unless `h_count` is set: then work = *h_count * per_count (the
 // query count / evaluation count is only known on the device)
@@ -102,8 +105,18 @@ struct Ctx {
   int nn_q = 8, nn_sub = 32, nn_blocks_per_cu = 2;
   int nn_mode = 1;                                    // 0: brute force, 1: culled (exact, identical results)
   int cull_q = 0;                                     // culled kernel: queries per lane (0 = auto)
+  int cull_w = 2;                                     // culled kernel: waves sharing one query set (1, 2, 4)
+  int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
+  // workers: contexts with their own stream and work buffers that BORROW clouds of this
+  // context (slots 0/1) so that independent scan pairs run concurrently on the GPU
+  std::vector<Ctx *> workers;
+  Ctx *parent = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  double *batch_table = nullptr; size_t batch_cap = 0;   // [pairs][32] staging of mvr_pair_moments2_batch
   // instrumentation
   bool prof = false;
+  unsigned prof_mask = ~0u;                           // families that are timed (bit f = family f)
+  std::vector<hipEvent_t> event_pool;                 // timing events are recycled, not re-created per launch
   std::vector<ProfRec> recs;
   uint64_t *h_counts = nullptr;                       // pinned: device counters copied per profiled launch
   size_t h_counts_used = 0;

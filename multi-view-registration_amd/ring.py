@@ -83,10 +83,13 @@ class HipBackend:
         """Fill this rank's rows (partial sums for split edges); returns the table."""
         with self._on_stream():
             self.table.zero_()
-        for e, qb, qn in segments:
-            s, t = edges[e]
-            self.ctx.pair_moments2_dev(s, t, max_dist, origin, self.table[e].data_ptr(), reciprocal=True,
-                                       fma=self.fma, q_begin=qb, q_count=qn)
+        if segments:
+            # a rank's segments cover consecutive edges: one batched call, rows e0.. of the table;
+            # the library runs the pairs concurrently on its worker streams and joins them back
+            es = [e for e, _, _ in segments]
+            assert es == list(range(es[0], es[0] + len(es)))
+            self.ctx.pair_moments2_batch([edges[e] for e in es], max_dist, origin, dev_ptr=self.table[es[0]].data_ptr(),
+                                         reciprocal=True, fma=self.fma, ranges=[(qb, qn) for _, qb, qn in segments])
         return self.table
 
     def to_host(self, table):

@@ -37,13 +37,15 @@ def orc():
     return oracle
 
 
-@pytest.fixture(scope="session", params=["culled", "brute"])
+@pytest.fixture(scope="session", params=["culled", "culled_w1", "culled_w4", "brute"])
 def gpu(mvr, request):
     """A GPU context; -m gpu tests fail loudly (no skip, no fallback) without one.
     Every parity test runs against both exact search kernels: the spatially
-    culled one (default) and the brute-force one."""
+    culled one (default: 2 waves share a query set; also 1 and 4) and the brute-force one."""
     ctx = mvr.Context(0)
-    ctx.tune(nn_mode=1 if request.param == "culled" else 0)
+    ctx.tune(nn_mode=0 if request.param == "brute" else 1)
+    if request.param.startswith("culled_w"):
+        ctx.tune(cull_w=int(request.param[-1]))
     ctx.mode = request.param
     yield ctx
     ctx.close()

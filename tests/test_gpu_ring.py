@@ -57,3 +57,33 @@ def test_fake_world_partition_sums_to_unsharded(mvr, ring, world):
         assert np.allclose(total[:, 4:], full[:, 4:], rtol=1e-12, atol=1e-7)
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("streams", [1, 3, 8])
+def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
+    """mvr_pair_moments2_batch (pairs on concurrent worker streams) returns exactly the sums of
+    one mvr_pair_moments2 call per pair, with and without query sub-ranges, whatever the stream count."""
+    g = load_golden("ring_12x2048.npz")
+    scans, poses0 = list(g["scans"]), list(g["poses0"])
+    sp = mvr.synth_params(12, 3)
+    origin = np.array(sp.pivot)
+    V = 7
+    for v in range(V):
+        gpu.upload(V + v, scans[v])
+        gpu.transform(v, V + v, poses0[v])
+    pairs = [(v, (v + 1) % V) for v in range(V)] + [(2, 5), (5, 2)]
+    ranges = [(0, None), (100, 700), (0, 0), (2000, None), (5, 1), (0, None), (1024, 1024), (3, 2040), (0, None)]
+    gpu.tune(pair_streams=streams)
+    try:
+        for rg in (None, ranges):
+            single = [gpu.pair_moments2(s, t, 8.0, origin, q_begin=0 if rg is None else rg[k][0],
+                                        q_count=None if rg is None else rg[k][1]) for k, (s, t) in enumerate(pairs)]
+            batch = gpu.pair_moments2_batch(pairs, 8.0, origin, ranges=rg)
+            assert len(batch) == len(pairs)
+            for k, (a, b) in enumerate(zip(single, batch)):
+                assert bytes(a) == bytes(b), (k, pairs[k], a.n, b.n)
+            assert sum(m.n for m in batch) > 1000
+        # an empty batch is a no-op
+        assert gpu.pair_moments2_batch([], 8.0, origin) == []
+    finally:
+        gpu.tune(pair_streams=6)
