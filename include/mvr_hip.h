@@ -128,6 +128,9 @@ int  mvr_cloud_clear(mvr_ctx *ctx, int slot);
  * the f64 pose (osg::Matrixd::preMult incl. the w divide), rounded to f32.
  * dst_slot may equal src_slot. */
 int  mvr_cloud_transform(mvr_ctx *ctx, int dst_slot, int src_slot, const double T[16]);
+/* the same for `count` clouds in ONE launch (the loop over all scans that poses them before a
+ * global iteration, registrator.cpp:630-637): T = count x 16 doubles. */
+int  mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst_slots, const int *src_slots, const double *T);
 /* pcl transformPointCloud / ICP::transformCloud (inside align, App. A.1):
  * x' = ((T00 x + T01 y) + T02 z) + T03 in f32, no contraction. */
 int  mvr_cloud_transform_f32(mvr_ctx *ctx, int dst_slot, int src_slot, const float T[16]);

@@ -126,6 +126,7 @@ SIGNATURES = {
                                     _dp, C.POINTER(PairMoments2)]),
     "mvr_pair_moments2_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _sz,
                                         _sz, _dp, _vp]),
+    "mvr_cloud_transform_batch": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp]),
     "mvr_pair_moments2_batch": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, C.c_int,
                                           C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _dp,
                                           C.POINTER(PairMoments2), _vp]),
@@ -428,6 +429,15 @@ class Context:
         qc = (1 << 62) if q_count is None else int(q_count)
         _chk(_lib.mvr_pair_moments2_dev(self._h, s, t, float(max_dist), int(reciprocal), int(fma),
                                         int(q_begin), qc, _p(o, C.c_double), _vp(dev_ptr)), self._h)
+
+    def transform_batch(self, dst_slots, src_slots, poses):
+        """slot dst[k] = pose[k] applied to slot src[k] (mvr_cloud_transform semantics), all clouds in one launch."""
+        n = len(dst_slots)
+        d = (C.c_int * n)(*[int(v) for v in dst_slots])
+        s = (C.c_int * n)(*[int(v) for v in src_slots])
+        T = np.ascontiguousarray(np.stack([to_cm(p, np.float64).reshape(16) for p in poses]) if n else np.zeros((0, 16)),
+                                 np.float64)
+        _chk(_lib.mvr_cloud_transform_batch(self._h, n, d, s, _p(T, C.c_double)), self._h)
 
     def pair_moments2_batch(self, pairs, max_dist, origin, dev_ptr=None, reciprocal=True, fma=False, ranges=None):
         """All scan pairs of one global iteration in one call; the pairs run concurrently on the

@@ -515,6 +515,36 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   return MVR_OK;
 }
 
+API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const int *src, const double *T)
+{
+  if (!ctx || count < 0 || (count && (!dst || !src || !T))) return MVR_E_ARG;
+  for (int k = 0; k < count; ++k) if (!slot_ok(dst[k]) || !slot_ok(src[k])) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<const float4 *> in((size_t)count);
+  std::vector<float4 *> out((size_t)count);
+  std::vector<size_t> n((size_t)count);
+  for (int k = 0; k < count; ++k) {
+    if (c->slots[src[k]].has_normals) {          // normals ride along: the one-cloud path rotates them too
+      if (int rc = mvr_cloud_transform(ctx, dst[k], src[k], T + (size_t)k * 16)) return rc;
+      n[k] = 0; in[k] = nullptr; out[k] = nullptr;
+      continue;
+    }
+    n[k] = c->slots[src[k]].n;
+    if (dst[k] != src[k]) { c->slots[dst[k]].n = 0; if (int rc = cloud_reserve(c, c->slots[dst[k]], n[k], false)) return rc; }
+    in[k] = c->slots[src[k]].pts; out[k] = c->slots[dst[k]].pts;
+  }
+  if (int rc = launch_transform_f64_batch(c, count, in.data(), out.data(), n.data(), T)) return rc;
+  for (int k = 0; k < count; ++k) {
+    if (!in[k] && !n[k] && c->slots[src[k]].has_normals) continue;
+    c->slots[dst[k]].n = n[k];
+    if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
+    c->slots[dst[k]].coords_valid = false;
+    c->slots[dst[k]].has_normals = false;
+  }
+  return MVR_OK;
+}
+
 API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16])
 {
   if (!ctx || !slot_ok(dst) || !slot_ok(src) || !T) return MVR_E_ARG;
@@ -694,11 +724,11 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     table = c->batch_table;
   }
   // everything the workers only READ is prepared here, on the caller's stream
-  if (c->nn_mode != 0)
-    for (int k = 0; k < n_pairs; ++k) {
-      if (int rc = ensure_index(c, c->slots[src[k]])) return rc;
-      if (int rc = ensure_index(c, c->slots[dst[k]])) return rc;
-    }
+  if (c->nn_mode != 0) {
+    std::vector<Cloud *> used;
+    for (int k = 0; k < n_pairs; ++k) { used.push_back(&c->slots[src[k]]); used.push_back(&c->slots[dst[k]]); }
+    if (int rc = ensure_index_batch(c, used.data(), (int)used.size())) return rc;      // one refresh launch for all views
+  }
   if (!c->ev_fork) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   MVR_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
   int status = MVR_OK;

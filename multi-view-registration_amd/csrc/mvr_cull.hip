@@ -200,7 +200,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     for (int k = 1; k < 4; ++k)
       if (g == k) { tx[j] = qx[4 * j + k]; ty[j] = qy[4 * j + k]; tz[j] = qz[4 * j + k]; }
   }
-  if (threadIdx.x < NB) sbest[threadIdx.x] = 0x7F800000u;   // +inf
+  for (int i = threadIdx.x; i < NB; i += 64 * W) sbest[i] = 0x7F800000u;   // +inf
   __syncthreads();
   MVR_MARK(0);
 
@@ -210,12 +210,6 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   auto shared_bound = [&](int j) {
     return fminf(__uint_as_float(__atomic_load_n(&sbest[j * 64 + lane], __ATOMIC_RELAXED)), cap2);
   };
-  // the bounds the box tests use live in registers: re-read from LDS once per group of tests (after every
-  // evaluation and whenever four more cells are looked for), not once per test -- a candidate costs ~5 box
-  // tests and each LDS round trip in that serial chain was ~100 ns of a wave's life (tools/block_trace.py)
-  float bnd[Q];
-#pragma unroll
-  for (int j = 0; j < Q; ++j) bnd[j] = cap2;
 
   // register prefetch buffer: the NEXT four cells' points travel from L2 while the
   // current four are being evaluated out of LDS (coordinates only: the index, w, is
@@ -283,7 +277,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     for (int q = 0; q < NQ; ++q) atomicMin(&sbest[q * 16 + l16], __float_as_uint(best[q]));
     float w = 0.f;
 #pragma unroll
-    for (int j = 0; j < Q; ++j) { bnd[j] = shared_bound(j); w = fmaxf(w, bnd[j]); }
+    for (int j = 0; j < Q; ++j) w = fmaxf(w, shared_bound(j));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
     U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fminf(cap2, w))));
@@ -291,8 +285,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 
   // exact per-query test: the tile is needed iff SOME query of this set can
   // still find an equal-or-closer point inside the tile's box
-  auto needed_mask = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
-                         const float hi_z) -> unsigned long long {
+  auto needed = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
+                    const float hi_z) {
     bool need = false;
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
@@ -300,13 +294,11 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       const float dy = fmaxf(0.f, fmaxf(lo_y - ty[j], ty[j] - hi_y));
       const float dz = fmaxf(0.f, fmaxf(lo_z - tz[j], tz[j] - hi_z));
       const float pb = dx * dx + dy * dy + dz * dz;
-      need |= (pb * 0.99999f <= bnd[j]);
+      need |= (pb * 0.99999f <= shared_bound(j));
     }
     ++tiles_tested;
-    return __ballot(need);
+    return __any(need) != 0;
   };
-  auto needed = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
-                    const float hi_z) { return needed_mask(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) != 0ull; };
 
   // candidate stream over this wave's own tiles: round 0 = tiles whose box overlaps the
   // query box, round 1 = the rest within U.  Distances are NaN where there is no block / tile.
@@ -388,31 +380,22 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     float4 r8 = rec;
     int l0 = 8 * cnd;
     if (cnd >= 8) { r8 = cbox[(size_t)tile * 8 + (lane & 7)]; l0 = 0; }   // beyond the prefetched eight: read it now
-    float bx[4][6];
-    unsigned long long nd[4];
-#pragma unroll
-    for (int cidx = 0; cidx < 4; ++cidx) {       // four independent tests first, their ballots afterwards
-      bx[cidx][0] = lane_value(r8.x, l0 + 2 * cidx); bx[cidx][1] = lane_value(r8.y, l0 + 2 * cidx); bx[cidx][2] = lane_value(r8.z, l0 + 2 * cidx);
-      bx[cidx][3] = lane_value(r8.x, l0 + 2 * cidx + 1); bx[cidx][4] = lane_value(r8.y, l0 + 2 * cidx + 1); bx[cidx][5] = lane_value(r8.z, l0 + 2 * cidx + 1);
-      nd[cidx] = needed_mask(bx[cidx][0], bx[cidx][1], bx[cidx][2], bx[cidx][3], bx[cidx][4], bx[cidx][5]);
-    }
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
-      if (nd[cidx] != 0ull) {
+      float bx[6];
+      bx[0] = lane_value(r8.x, l0 + 2 * cidx); bx[1] = lane_value(r8.y, l0 + 2 * cidx); bx[2] = lane_value(r8.z, l0 + 2 * cidx);
+      bx[3] = lane_value(r8.x, l0 + 2 * cidx + 1); bx[4] = lane_value(r8.y, l0 + 2 * cidx + 1); bx[5] = lane_value(r8.z, l0 + 2 * cidx + 1);
+      if (needed(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5])) {
         const int at = (int)(pq_tail & 63u);
         pq_cell = (lane == at) ? tile * 4u + (uint32_t)cidx : pq_cell;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) pq_box[k] = (lane == at) ? bx[cidx][k] : pq_box[k];
+        for (int k = 0; k < 6; ++k) pq_box[k] = (lane == at) ? bx[k] : pq_box[k];
         ++pq_tail;
       }
     }
   };
   // up to four queued cells (fewer only when the candidate stream is exhausted); 0 = done
   auto next_quad = [&](uint32_t (&cells)[4], float (&boxes)[4][6]) -> uint32_t {
-    if (W > 1) {                      // pick up what the other waves of the set have found meanwhile
-#pragma unroll
-      for (int j = 0; j < Q; ++j) bnd[j] = shared_bound(j);
-    }
     while (pq_tail - pq_head < 4u) {
       const uint32_t tile = advance();
       if (tile == kNone) break;

@@ -24,6 +24,9 @@
 // Compiled with -ffp-contract=off.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <vector>
+
 #include "mvr_internal.h"
 
 namespace mvr {
@@ -132,11 +135,15 @@ __global__ void finish_order_kernel(const uint32_t *__restrict__ perm, size_t n,
 
 // sorted[k] = {pts[perm[k]].xyz, bits(perm[k])}; one wave per 256-point tile also reduces the AABBs
 // of its four 64-point cells (cbox[tile][cell] = {lo, hi}) and of the tile (their union)
-__global__ void __launch_bounds__(256) refresh_sorted_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ perm,
-                                                              size_t n, float4 *__restrict__ sorted,
-                                                              float4 *__restrict__ tlo, float4 *__restrict__ thi,
-                                                              float4 *__restrict__ cbox)
+// blockIdx.y = cloud of the batch (posed scans of one global iteration are refreshed in one launch)
+__global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
 {
+  const int cloud = blockIdx.y;
+  const float4 *__restrict__ pts = rb.pts[cloud];
+  const uint32_t *__restrict__ perm = rb.perm[cloud];
+  const size_t n = rb.n[cloud];
+  float4 *__restrict__ sorted = rb.sorted[cloud], *__restrict__ tlo = rb.tlo[cloud], *__restrict__ thi = rb.thi[cloud],
+         *__restrict__ cbox = rb.cbox[cloud];
   const int lane = threadIdx.x & 63;
   const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t base = tile * kCullTile;
@@ -172,10 +179,14 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(const float4 *__res
 }
 
 // one wave per super box: the union of 64 consecutive tile boxes
-__global__ void __launch_bounds__(64) super_box_kernel(const float4 *__restrict__ tlo, const float4 *__restrict__ thi,
-                                                        size_t n_tiles, float4 *__restrict__ sbox)
+__global__ void __launch_bounds__(64) super_box_kernel(RefreshBatch rb)
 {
+  const int cloud = blockIdx.y;
+  const float4 *__restrict__ tlo = rb.tlo[cloud], *__restrict__ thi = rb.thi[cloud];
+  float4 *__restrict__ sbox = rb.sbox[cloud];
+  const size_t n_tiles = ((size_t)rb.n[cloud] + kCullTile - 1) / kCullTile;
   const int lane = threadIdx.x;
+  if ((size_t)blockIdx.x * 64 >= n_tiles) return;
   const size_t t = (size_t)blockIdx.x * 64 + lane;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   if (t < n_tiles) {
@@ -248,8 +259,10 @@ void inherit_point_set(Cloud &dst, const Cloud &src)
   dst.coords_valid = false;
 }
 
-int ensure_index(Ctx *c, Cloud &cl)
+// ordering (once per point set) and buffers; *stale = the sorted copy / boxes must be refreshed
+static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
 {
+  *stale = false;
   const size_t n = cl.n;
   if (n == 0) return MVR_OK;
   const size_t tiles = (n + kCullTile - 1) / kCullTile;
@@ -321,15 +334,54 @@ int ensure_index(Ctx *c, Cloud &cl)
       MVR_HIP_TRY(c, hipMalloc(&cl.sbox, (cap / 64 + 2) * 2 * sizeof(float4)));
       cl.tiles_cap = cap;
     }
-    ProfScope ps(c, MVR_K_GLUE, 36.0 * (double)n);
-    hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, cl.pts,
-                       cl.order->perm, n, cl.sorted, cl.tlo, cl.thi, cl.cbox);
-    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, c->stream, cl.tlo, cl.thi, tiles,
-                       cl.sbox);
-    MVR_HIP_TRY(c, hipGetLastError());
-    cl.coords_valid = true;
+    *stale = true;
   }
   return MVR_OK;
+}
+
+static int refresh_batch(Ctx *c, Cloud *const *clouds, int count)
+{
+  for (int base = 0; base < count; base += kBatchClouds) {
+    RefreshBatch rb;
+    const int m = std::min(kBatchClouds, count - base);
+    size_t tmax = 0; double work = 0.0;
+    for (int k = 0; k < kBatchClouds; ++k) {
+      Cloud *cl = k < m ? clouds[base + k] : nullptr;
+      rb.pts[k] = cl ? cl->pts : nullptr; rb.perm[k] = cl ? cl->order->perm : nullptr; rb.n[k] = cl ? cl->n : 0;
+      rb.sorted[k] = cl ? cl->sorted : nullptr; rb.tlo[k] = cl ? cl->tlo : nullptr; rb.thi[k] = cl ? cl->thi : nullptr;
+      rb.cbox[k] = cl ? cl->cbox : nullptr; rb.sbox[k] = cl ? cl->sbox : nullptr;
+      if (cl) { tmax = std::max(tmax, (cl->n + kCullTile - 1) / kCullTile); work += 36.0 * (double)cl->n; }
+    }
+    if (tmax == 0) continue;
+    ProfScope ps(c, MVR_K_GLUE, work);
+    hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tmax + 3) / 4), (unsigned)m), dim3(256), 0, c->stream, rb);
+    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64), (unsigned)m), dim3(64), 0, c->stream, rb);
+    MVR_HIP_TRY(c, hipGetLastError());
+    for (int k = 0; k < m; ++k) clouds[base + k]->coords_valid = true;
+  }
+  return MVR_OK;
+}
+
+int ensure_index(Ctx *c, Cloud &cl)
+{
+  bool stale = false;
+  if (int rc = prepare_index(c, cl, &stale)) return rc;
+  if (!stale) return MVR_OK;
+  Cloud *one = &cl;
+  return refresh_batch(c, &one, 1);
+}
+
+int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
+{
+  std::vector<Cloud *> todo;
+  for (int k = 0; k < count; ++k) {
+    Cloud *cl = clouds[k];
+    if (std::find(todo.begin(), todo.end(), cl) != todo.end()) continue;
+    bool stale = false;
+    if (int rc = prepare_index(c, *cl, &stale)) return rc;
+    if (stale) todo.push_back(cl);
+  }
+  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
 }
 
 int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,

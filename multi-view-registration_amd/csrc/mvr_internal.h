@@ -162,6 +162,17 @@ int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
   return MVR_OK;
 }
 
+// several clouds per launch (kernel arguments by value)
+constexpr int kBatchClouds = 16;
+struct Mat44d { double m[16]; };
+struct XformBatch { const float4 *src[kBatchClouds]; float4 *dst[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; };
+struct RefreshBatch {
+  const float4 *pts[kBatchClouds]; const uint32_t *perm[kBatchClouds]; unsigned long long n[kBatchClouds];
+  float4 *sorted[kBatchClouds], *tlo[kBatchClouds], *thi[kBatchClouds], *cbox[kBatchClouds], *sbox[kBatchClouds];
+};
+int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T);
+int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count);     // ensure_index for many clouds, coordinates refreshed in one launch
+
 // ---- kernel launchers (mvr_nn.hip / mvr_reduce.hip / mvr_index.hip) -----------
 // forward / reverse brute-force NN.  Queries: points [q_begin, q_begin+q_count)
 // of `q` (direct; key ordinal = point index), or, when `qlist` != null, the

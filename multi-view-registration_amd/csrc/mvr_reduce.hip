@@ -81,7 +81,6 @@ __device__ __forceinline__ void sum_rows(const double *__restrict__ partials, in
 // ---------------------------------------------------------------- K1 transforms
 
 struct Mat34f { float m[12]; };   // rows of the 3x4, row-major
-struct Mat44d { double m[16]; };  // column-major 4x4
 
 __global__ void transform_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n, Mat34f T)
 {
@@ -109,6 +108,25 @@ __global__ void transform_f64_kernel(const float4 *__restrict__ in, float4 *__re
   o.z = (float)((((T.m[2] * x + T.m[6] * y) + T.m[10] * z) + T.m[14]) * d);
   o.w = 1.0f;
   out[i] = o;
+}
+
+// up to kBatchClouds clouds in one launch (blockIdx.y = cloud): the per-view kernels of a global iteration
+// are a few microseconds each, so a dozen separate launches cost more than the work
+__global__ void transform_f64_batch_kernel(XformBatch b)
+{
+  const int k = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n[k]) return;
+  const Mat44d &T = b.T[k];
+  const float4 p = b.src[k][i];
+  const double x = p.x, y = p.y, z = p.z;
+  const double d = 1.0 / (((T.m[3] * x + T.m[7] * y) + T.m[11] * z) + T.m[15]);
+  float4 o;
+  o.x = (float)((((T.m[0] * x + T.m[4] * y) + T.m[8] * z) + T.m[12]) * d);
+  o.y = (float)((((T.m[1] * x + T.m[5] * y) + T.m[9] * z) + T.m[13]) * d);
+  o.z = (float)((((T.m[2] * x + T.m[6] * y) + T.m[10] * z) + T.m[14]) * d);
+  o.w = 1.0f;
+  b.dst[k][i] = o;
 }
 
 __global__ void unpack_xyz_kernel(const float *__restrict__ packed, float4 *__restrict__ out, size_t n)
@@ -433,6 +451,26 @@ int launch_transform_f64(Ctx *c, const float4 *in, float4 *out, size_t n, const 
   ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)n);
   hipLaunchKernelGGL(transform_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, out, n, M);
   MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T)
+{
+  for (int base = 0; base < count; base += kBatchClouds) {
+    XformBatch b;
+    const int m = std::min(kBatchClouds, count - base);
+    size_t nmax = 0; double work = 0.0;
+    for (int k = 0; k < kBatchClouds; ++k) {
+      const bool live = k < m;
+      b.src[k] = live ? in[base + k] : nullptr; b.dst[k] = live ? out[base + k] : nullptr; b.n[k] = live ? n[base + k] : 0;
+      for (int j = 0; j < 16; ++j) b.T[k].m[j] = live ? T[(size_t)(base + k) * 16 + j] : 0.0;
+      nmax = std::max(nmax, (size_t)b.n[k]); work += 32.0 * (double)b.n[k];
+    }
+    if (nmax == 0) continue;
+    ProfScope ps(c, MVR_K_XFORM, work);
+    hipLaunchKernelGGL(transform_f64_batch_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)m), dim3(256), 0, c->stream, b);
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
   return MVR_OK;
 }
 

@@ -76,8 +76,8 @@ class HipBackend:
         return self.torch.cuda.stream(self._tstream) if self._tstream is not None else contextlib.nullcontext()
 
     def pose_clouds(self, poses, views=None):
-        for v in (range(self.V) if views is None else views):
-            self.ctx.transform(v, self.V + v, poses[v])
+        vs = list(range(self.V) if views is None else views)
+        self.ctx.transform_batch(vs, [self.V + v for v in vs], [poses[v] for v in vs])     # one launch for all views
 
     def edge_rows(self, segments, edges, max_dist, origin):
         """Fill this rank's rows (partial sums for split edges); returns the table."""

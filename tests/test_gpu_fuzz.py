@@ -84,3 +84,29 @@ def test_random_shapes_and_caps(gpu, orc):
         gq, gm, gdd = gpu.correspondences(0, 1, md)
         c = orc.correspondences(q, t, md, kdtree=False)
         assert np.array_equal(gq, c["query"]) and np.array_equal(gm, c["match"]) and np.array_equal(bits(gdd), bits(c["dist2"])), trial
+
+
+def test_two_query_groups_per_set(gpu, orc):
+    """The 128-query variant of the culled kernel (picked automatically above 524k queries) on small inputs:
+    forced with cull_q=2, for whichever wave count the fixture selected."""
+    if gpu.mode == "brute":
+        pytest.skip("knob of the culled kernel")
+    rng = np.random.default_rng(23)
+    gpu.tune(cull_q=2)
+    try:
+        for name in ("regular_grid_midpoints", "two_far_clusters", "every_target_duplicated", "exactly_257_and_1025"):
+            q, t = CASES[name]
+            gpu.upload(0, q); gpu.upload(1, t)
+            gi, gd = gpu.nn(0, 1)
+            oi, od = orc.nn(q, t, kdtree=False)
+            assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od)), name
+        for trial in range(6):
+            nq, nt = int(rng.integers(1, 9000)), int(rng.integers(1, 12000))
+            q = cloud(rng.standard_normal((nq, 3)) * 20 + [0, 0, 900])
+            t = cloud(rng.standard_normal((nt, 3)) * 20 + [0, 0, 900])
+            gpu.upload(0, q); gpu.upload(1, t)
+            gq, gm, gdd = gpu.correspondences(0, 1, 2.0)
+            c = orc.correspondences(q, t, 2.0, kdtree=False)
+            assert np.array_equal(gq, c["query"]) and np.array_equal(gm, c["match"]) and np.array_equal(bits(gdd), bits(c["dist2"])), trial
+    finally:
+        gpu.tune(cull_q=0)

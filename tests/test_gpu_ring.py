@@ -59,7 +59,7 @@ def test_fake_world_partition_sums_to_unsharded(mvr, ring, world):
         be.close()
 
 
-@pytest.mark.parametrize("streams", [1, 3, 8])
+@pytest.mark.parametrize("streams", [1, 3, 6])
 def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
     """mvr_pair_moments2_batch (pairs on concurrent worker streams) returns exactly the sums of
     one mvr_pair_moments2 call per pair, with and without query sub-ranges, whatever the stream count."""
@@ -87,3 +87,24 @@ def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
         assert gpu.pair_moments2_batch([], 8.0, origin) == []
     finally:
         gpu.tune(pair_streams=6)
+
+
+def test_transform_batch_equals_single_transforms(gpu, mvr):
+    """mvr_cloud_transform_batch poses many clouds in one launch, bit for bit like mvr_cloud_transform."""
+    g = load_golden("ring_12x2048.npz")
+    scans, poses0 = list(g["scans"]), list(g["poses0"])
+    V = 5
+    for v in range(V):
+        gpu.upload(20 + v, scans[v][: 2048 - 37 * v])          # ragged sizes
+    for v in range(V):
+        gpu.transform(v, 20 + v, poses0[v])
+    single = [gpu.download(v) for v in range(V)]
+    gpu.transform_batch([10 + v for v in range(V)], [20 + v for v in range(V)], poses0[:V])
+    for v in range(V):
+        assert np.array_equal(gpu.download(10 + v).view(np.uint32), single[v].view(np.uint32))
+    # in place, and searchable afterwards (the index follows the new coordinates)
+    gpu.transform_batch([20, 21], [20, 21], poses0[:2])
+    assert np.array_equal(gpu.download(20).view(np.uint32), single[0].view(np.uint32))
+    a = gpu.pair_moments2(20, 21, 8.0, np.zeros(3))
+    b = gpu.pair_moments2(0, 1, 8.0, np.zeros(3))
+    assert bytes(a) == bytes(b) and a.n > 100
