@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
-"""Sum rocprofv3 --pmc counter_collection CSVs per kernel name (substring filter) and print per-dispatch means."""
+"""Per-dispatch means of rocprofv3 --pmc counter_collection CSVs, per counter, for kernels whose name contains a
+substring; forward (even) and reverse (odd) launches of the pair are listed separately.
+    python tools/pmc_summary.py gpurun_out/pmc_cull nn_cull"""
 import csv, glob, sys, collections
 root, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "nn_cull")
-acc = collections.defaultdict(lambda: collections.defaultdict(float)); nd = collections.defaultdict(set)
-for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
+    rows = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if pat not in k: continue
-        short = k.split("(")[0][-40:]
-        acc[short][r["Counter_Name"]] += float(r["Counter_Value"]); nd[short].add((f, r["Dispatch_Id"]))
-for k, c in acc.items():
-    n = len(nd[k]);  print(k, "dispatches(sum over passes):", n)
-    for name, v in sorted(c.items()): print("   %-24s %.4g per dispatch" % (name, v / max(1, sum(1 for x in nd[k] ))))
+        if pat in r["Kernel_Name"]:
+            rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+    ids = sorted(rows)
+    for label, sel in (("all", ids), ("forward (1st, 3rd, ...)", ids[0::2]), ("reverse (2nd, 4th, ...)", ids[1::2])):
+        if not sel: continue
+        acc = collections.defaultdict(float)
+        for i in sel:
+            for k, v in rows[i].items(): acc[k] += v
+        print("%s | %s: %d dispatches" % (f.split("/")[-3], label, len(sel)))
+        for k in sorted(acc): print("    %-24s %.5g" % (k, acc[k] / len(sel)))
