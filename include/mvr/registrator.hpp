@@ -18,6 +18,7 @@
 #pragma once
 
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 #include <utility>
 #include <vector>
@@ -272,6 +273,66 @@ class Registrator {
         RowMatrixd osg_transformation = PclMatrixCaster<RowMatrixd>(Matrix4f(transformation.data()));
         ScanCloud &pc = model_->getPointCloud(object, i);
         pc.setMatrix(pc.getMatrix() * osg_transformation);
+        pc.setRegisterState(true);
+      }
+    }
+  }
+
+  // The same outer passes (registrator.cpp:611-678) with everything DEVICE-RESIDENT -- the form the
+  // reference's loop takes when no correspondence list has to reach the host: the scans are uploaded
+  // once; per outer pass all views are posed and re-indexed by one launch each
+  // (mvr_cloud_transform_batch), the V ring pairs are searched concurrently on worker HIP streams and
+  // reduced to raw second moments (mvr_pair_moments2_batch), and the per-pair solve + LUM + pose
+  // update run on the host from those V x 31 doubles (mvr_ring_host_step).  Same poses as
+  // registrationLUM up to float rounding of the intermediate PCL-style transforms.
+  void registrationLUMDevice(int max_iterations, double max_distance, int object)
+  {
+    const int V = model_->numViews();
+    if (V < 2) return;
+    Device &d = Device::instance();
+    std::vector<SlotGuard> raw((size_t)V), posed((size_t)V);
+    std::vector<int> raw_s((size_t)V), posed_s((size_t)V), es((size_t)V), et((size_t)V);
+    double origin[3] = {0.0, 0.0, 0.0};
+    for (int v = 0; v < V; ++v) {
+      ScanCloud &pc = model_->getPointCloud(object, v);
+      d.upload(raw[v].s, pc.points);
+      raw_s[v] = raw[v].s; posed_s[v] = posed[v].s;
+      es[v] = v; et[v] = (v == V - 1) ? 0 : v + 1;
+    }
+    if (!model_->getPointCloud(object, 0).points.empty()) {
+      const PCLPoint &p = model_->getPointCloud(object, 0).points.points[0];
+      origin[0] = p.x; origin[1] = p.y; origin[2] = p.z;
+    }
+    std::vector<int> slot_src((size_t)V), slot_tgt((size_t)V);
+    for (int e = 0; e < V; ++e) { slot_src[e] = posed_s[es[e]]; slot_tgt[e] = posed_s[et[e]]; }
+    const int lum_max_iterations = 16;
+    const int outer_loop_num = std::max(1, max_iterations / lum_max_iterations);
+    std::vector<double> poses((size_t)V * 16), rows((size_t)V * 32), pair_n((size_t)V), pair_mse((size_t)V), lum_pose((size_t)V * 6);
+    std::vector<mvr_pair_moments2_t> m2((size_t)V);
+    for (int loop = 0; loop < outer_loop_num; ++loop) {
+      for (int v = 0; v < V; ++v) {
+        ScanCloud &pc = model_->getPointCloud(object, v);
+        pc.initRotation(*this);
+        pc.setRegisterState(true);
+        std::memcpy(&poses[(size_t)v * 16], pc.getMatrix().asColumnMajorColumnVector(), 16 * sizeof(double));
+      }
+      d.check(mvr_cloud_transform_batch(d.ctx(), V, posed_s.data(), raw_s.data(), poses.data()), "mvr_cloud_transform_batch");
+      d.check(mvr_pair_moments2_batch(d.ctx(), V, slot_src.data(), slot_tgt.data(), max_distance, 1, 0, nullptr, nullptr, origin,
+                                      m2.data(), nullptr), "mvr_pair_moments2_batch");
+      for (int e = 0; e < V; ++e) {
+        std::memset(&rows[(size_t)e * 32], 0, 32 * sizeof(double));
+        std::memcpy(&rows[(size_t)e * 32], &m2[e], sizeof(mvr_pair_moments2_t));
+      }
+      int iters = 0;
+      d.check(mvr_ring_host_step(V, V, es.data(), et.data(), rows.data(), origin, lum_max_iterations, poses.data(), lum_pose.data(),
+                                 nullptr, pair_n.data(), pair_mse.data(), &iters), "mvr_ring_host_step");
+      lum_ncorr.clear();
+      for (int e = 0; e < V; ++e) lum_ncorr.push_back((int)pair_n[e]);
+      for (int v = 0; v < V; ++v) {
+        RowMatrixd m;
+        std::memcpy(&m(0, 0), &poses[(size_t)v * 16], 16 * sizeof(double));
+        ScanCloud &pc = model_->getPointCloud(object, v);
+        pc.setMatrix(m);
         pc.setRegisterState(true);
       }
     }

@@ -4,7 +4,7 @@
 // to compare with the oracle-based restatement of the same driver loops.
 //
 // usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
-//   mode: seq | lum | auto | err | api
+//   mode: seq | lum | lumdev | auto | err | api
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +63,11 @@ int main(int argc, char **argv)
       std::printf("\"lum_ncorr\":[");
       for (size_t i = 0; i < reg.lum_ncorr.size(); ++i) std::printf("%d%s", reg.lum_ncorr[i], i + 1 < reg.lum_ncorr.size() ? "," : "");
       std::printf("],");
+    } else if (mode == "lumdev") {
+      reg.registrationLUMDevice(16 * repeat, max_d, 0);
+      std::printf("\"lum_ncorr\":[");
+      for (size_t i = 0; i < reg.lum_ncorr.size(); ++i) std::printf("%d%s", reg.lum_ncorr[i], i + 1 < reg.lum_ncorr.size() ? "," : "");
+      std::printf("],");
     } else if (mode == "auto") {
       reg.automaticRegistration(0, 1000, repeat, max_d, 50.0);
     } else if (mode == "err") {
@@ -118,7 +123,7 @@ int main(int argc, char **argv)
       std::printf("}%s", i + 1 < reg.log.size() ? "," : "");
     }
     std::printf("],");
-    if (mode == "seq" || mode == "auto" || mode == "lum") {
+    if (mode == "seq" || mode == "auto" || mode == "lum" || mode == "lumdev") {
       for (int v = 0; v < V; ++v) model.views[v].setRegisterState(true);
       reg.refineAxis(0);
       std::printf("\"refined_pivot\":[%.9g,%.9g,%.9g],\"refined_axis\":[%.9g,%.9g,%.9g],", reg.getPivotPoint()[0], reg.getPivotPoint()[1],

@@ -94,6 +94,19 @@ def test_registration_lum_driver(driver, mvr, orc):
     assert_poses(out["poses"], new, rot=2e-5, trans=2e-3)
 
 
+def test_registration_lum_device_resident(driver, mvr, orc):
+    """Registrator::registrationLUMDevice (batched pose, concurrent pairs, LUM from moments; nothing but
+    V x 31 doubles reaches the host) == the oracle LUM pass == the PCL-style registrationLUM."""
+    V, N, max_d = 12, 3000, 8.0
+    out, _ = run(driver, "lumdev", V, N, max_d, 1, 3)
+    ref, _ = run(driver, "lum", V, N, max_d, 1, 3)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 3)
+    new, P, corrs, its = ref_driver.lum_pass(orc, scans, poses0, max_d, 16)
+    assert out["lum_ncorr"] == [len(c) for c in corrs] == ref["lum_ncorr"]
+    assert_poses(out["poses"], new, rot=2e-5, trans=2e-3)
+    assert_poses(out["poses"], [np.array(p).reshape(4, 4) for p in ref["poses"]], rot=2e-5, trans=2e-3)
+
+
 def test_compute_error_pairs(driver, mvr, orc):
     """registrator.cpp:466-515: ring pairs + (0, V-1), reciprocal correspondences."""
     V, N, max_d = 12, 2500, 6.0
