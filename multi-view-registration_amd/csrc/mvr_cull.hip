@@ -130,10 +130,15 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 #ifdef MVR_TRACE      // diagnostic build: phase marks of wave 0 (100 MHz clock), first occurrence of each
   const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long trm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned trq = 0;
+  unsigned trq = 0, tr_open = 0, tr_exp = 0;
+  unsigned long long tr_t_open = 0, tr_t_exp = 0, tr_t_next = 0;
 #define MVR_MARK(i) do { if (!trm[i]) trm[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MVR_TIC() const unsigned long long tic_ = __builtin_amdgcn_s_memrealtime()
+#define MVR_TOC(acc, cnt) do { acc += __builtin_amdgcn_s_memrealtime() - tic_; ++cnt; } while (0)
 #else
 #define MVR_MARK(i) do { } while (0)
+#define MVR_TIC() do { } while (0)
+#define MVR_TOC(acc, cnt) do { } while (0)
 #endif
 #ifdef MVR_STAMP
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
@@ -191,20 +196,12 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     qlo[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qlo[k])));
     qhi[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qhi[k])));
   }
-  // the queries this lane TESTS tile boxes with: positions lane + 64 j, i.e. its own queries g + 4 j
-  float tx[Q], ty[Q], tz[Q];
-#pragma unroll
-  for (int j = 0; j < Q; ++j) {
-    tx[j] = qx[4 * j]; ty[j] = qy[4 * j]; tz[j] = qz[4 * j];
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-      if (g == k) { tx[j] = qx[4 * j + k]; ty[j] = qy[4 * j + k]; tz[j] = qz[4 * j + k]; }
-  }
   for (int i = threadIdx.x; i < NB; i += 64 * W) sbest[i] = 0x7F800000u;   // +inf
   __syncthreads();
   MVR_MARK(0);
 
   float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
+  bool U_stale = false;
   uint32_t cells_done = 0, tiles_tested = 0;
 
   auto shared_bound = [&](int j) {
@@ -246,8 +243,12 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       float m[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) m[q] = __builtin_inff();
+#ifdef MVR_SKIP_LOOP          // counter experiments only: everything but the distance loop (results are wrong)
+      for (int k = 0; k < 2; k += 2) {
+#else
 #pragma unroll 2
       for (int k = 0; k < kSub; k += 2) {
+#endif
         const float4 a = Tg[s + k], b = Tg[s + k + 1];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -272,32 +273,43 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     wave_lds_sync();     // all lanes done reading before the buffer is overwritten
 #pragma unroll
     for (int r = 0; r < 4; ++r) cells_done += (cells[r] != kNone) ? 1u : 0u;
-    // publish this wave's bests, then a wave max-reduction of the set-wide bounds -> new U
+    // publish this wave's bests; U (their set-wide maximum) is re-derived only when a ballot needs it
 #pragma unroll
     for (int q = 0; q < NQ; ++q) atomicMin(&sbest[q * 16 + l16], __float_as_uint(best[q]));
+    U_stale = true;
+  };
+  auto refresh_U = [&]() {       // wave max-reduction of the set-wide bounds
+    if (!U_stale) return;
     float w = 0.f;
 #pragma unroll
     for (int j = 0; j < Q; ++j) w = fmaxf(w, shared_bound(j));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w = fmaxf(w, __shfl_xor(w, o, 64));
     U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fminf(cap2, w))));
+    U_stale = false;
   };
 
-  // exact per-query test: the tile is needed iff SOME query of this set can
-  // still find an equal-or-closer point inside the tile's box
-  auto needed = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
-                    const float hi_z) {
+  // Exact per-query test of FOUR boxes at once, one per lane group: every lane measures its 4 Q queries
+  // against its group's box (the 16 lanes of a group hold all 64 Q queries between them), one ballot
+  // says which of the four boxes SOME query of the set can still find an equal-or-closer point in.
+  // (Testing one box with one query per lane was a ~60-instruction dependent chain per box; thirty of
+  // those per wave were a third of a wave's life -- tools/block_trace.py.)
+  auto needed4 = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
+                     const float hi_z) -> unsigned {
     bool need = false;
 #pragma unroll
-    for (int j = 0; j < Q; ++j) {
-      const float dx = fmaxf(0.f, fmaxf(lo_x - tx[j], tx[j] - hi_x));
-      const float dy = fmaxf(0.f, fmaxf(lo_y - ty[j], ty[j] - hi_y));
-      const float dz = fmaxf(0.f, fmaxf(lo_z - tz[j], tz[j] - hi_z));
+    for (int q = 0; q < NQ; ++q) {
+      const float dx = fmaxf(0.f, fmaxf(lo_x - qx[q], qx[q] - hi_x));
+      const float dy = fmaxf(0.f, fmaxf(lo_y - qy[q], qy[q] - hi_y));
+      const float dz = fmaxf(0.f, fmaxf(lo_z - qz[q], qz[q] - hi_z));
       const float pb = dx * dx + dy * dy + dz * dz;
-      need |= (pb * 0.99999f <= shared_bound(j));
+      const float bound = fminf(__uint_as_float(__atomic_load_n(&sbest[q * 16 + l16], __ATOMIC_RELAXED)), cap2);
+      need |= (pb * 0.99999f <= bound);
     }
     ++tiles_tested;
-    return __any(need) != 0;
+    const unsigned long long b = __ballot(need);
+    return ((b & 0xFFFFull) ? 1u : 0u) | ((b & 0xFFFF0000ull) ? 2u : 0u) | ((b & 0xFFFF00000000ull) ? 4u : 0u) |
+           ((b & 0xFFFF000000000000ull) ? 8u : 0u);
   };
 
   // candidate stream over this wave's own tiles: round 0 = tiles whose box overlaps the
@@ -317,9 +329,9 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;     // this lane's tile box of the open block
   float4 rec = blo;                   // cell boxes of the block's first 8 candidates: lane 8 c + k = float4 k of candidate c
   int last_b = 0;                     // bit of the tile last returned
-  float sel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};               // its box (wave-uniform)
   auto advance = [&]() -> uint32_t {
     if (n_blk == 0) return kNone;
+    if (round == 1) refresh_U();
     for (;;) {
       while (mask == 0ull) {
         while (sb_mask == 0ull) {
@@ -328,6 +340,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
             if (sbase >= n_blk) {
               if (round == 1) return kNone;
               round = 1; sbase = 0;
+              refresh_U();
             }
             if (n_blk > 64) { load_block_boxes(sbase); sb_lb = block_dist(sbase); }     // a single chunk stays in registers
           }
@@ -338,6 +351,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
         const int k = __ffsll((long long)sb_mask) - 1;
         sb_mask &= sb_mask - 1;
         if (round == 1 && lane_value(sb_lb, k) * 0.99999f > U) continue;   // U shrank since the ballot
+        MVR_TIC();
         cbase = (sbase + (uint32_t)k) * 64u;
         const uint32_t i = cbase + lane;
         const uint32_t t = (uint32_t)W * i + (uint32_t)wv;
@@ -355,17 +369,13 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
           if ((lane >> 3) == cnd) mine = (uint32_t)W * (cbase + (uint32_t)bit) + (uint32_t)wv;
         }
         if (mine != kNone) rec = cbox[(size_t)mine * 8 + (lane & 7)];
+        MVR_TOC(tr_t_open, tr_open);
       }
       const int b = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       if (round == 1 && lane_value(lb, b) * 0.99999f > U) continue;     // U shrank since the ballot
-      // the candidate's box sits in lane b's registers: v_readlane it into SGPRs instead of re-reading memory
-      sel[0] = lane_value(blo.x, b); sel[1] = lane_value(blo.y, b); sel[2] = lane_value(blo.z, b);
-      sel[3] = lane_value(bhi.x, b); sel[4] = lane_value(bhi.y, b); sel[5] = lane_value(bhi.z, b);
-      if (needed(sel[0], sel[1], sel[2], sel[3], sel[4], sel[5])) {
-        last_b = b;
-        return (uint32_t)W * (cbase + (uint32_t)b) + (uint32_t)wv;
-      }
+      last_b = b;
+      return (uint32_t)W * (cbase + (uint32_t)b) + (uint32_t)wv;
     }
   };
 
@@ -374,28 +384,39 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   uint32_t pq_cell = 0;
   float pq_box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint32_t pq_head = 0, pq_tail = 0;
-  // the four cells of a candidate tile: one 128-byte record {lo, hi} x 4, tested like the tile itself
+  // the four cells of a candidate tile (one 128-byte record {lo, hi} x 4): lane group g tests cell g
   auto expand_tile = [&](uint32_t tile) {
+    MVR_TIC();
     const int cnd = __popcll(mask0 & ((1ull << last_b) - 1ull));         // rank among the block's candidates
-    float4 r8 = rec;
-    int l0 = 8 * cnd;
-    if (cnd >= 8) { r8 = cbox[(size_t)tile * 8 + (lane & 7)]; l0 = 0; }   // beyond the prefetched eight: read it now
+    float4 clo, chi;
+    if (cnd < 8) {                       // prefetched: float4 k of candidate c sits in lane 8 c + k
+      const int src = 8 * cnd + 2 * g;
+      clo = make_float4(__shfl(rec.x, src, 64), __shfl(rec.y, src, 64), __shfl(rec.z, src, 64), 0.f);
+      chi = make_float4(__shfl(rec.x, src + 1, 64), __shfl(rec.y, src + 1, 64), __shfl(rec.z, src + 1, 64), 0.f);
+    } else {                             // beyond the prefetched eight: read it now
+      clo = cbox[(size_t)tile * 8 + 2 * g]; chi = cbox[(size_t)tile * 8 + 2 * g + 1];
+    }
+    const unsigned nd = needed4(clo.x, clo.y, clo.z, chi.x, chi.y, chi.z);
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
-      float bx[6];
-      bx[0] = lane_value(r8.x, l0 + 2 * cidx); bx[1] = lane_value(r8.y, l0 + 2 * cidx); bx[2] = lane_value(r8.z, l0 + 2 * cidx);
-      bx[3] = lane_value(r8.x, l0 + 2 * cidx + 1); bx[4] = lane_value(r8.y, l0 + 2 * cidx + 1); bx[5] = lane_value(r8.z, l0 + 2 * cidx + 1);
-      if (needed(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5])) {
-        const int at = (int)(pq_tail & 63u);
+      if ((nd >> cidx) & 1u) {
+        const int at = (int)(pq_tail & 63u), from = 16 * cidx;          // any lane of group cidx holds that cell's box
         pq_cell = (lane == at) ? tile * 4u + (uint32_t)cidx : pq_cell;
+        const float bx[6] = {lane_value(clo.x, from), lane_value(clo.y, from), lane_value(clo.z, from),
+                             lane_value(chi.x, from), lane_value(chi.y, from), lane_value(chi.z, from)};
 #pragma unroll
         for (int k = 0; k < 6; ++k) pq_box[k] = (lane == at) ? bx[k] : pq_box[k];
         ++pq_tail;
       }
     }
+    MVR_TOC(tr_t_exp, tr_exp);
   };
+
   // up to four queued cells (fewer only when the candidate stream is exhausted); 0 = done
   auto next_quad = [&](uint32_t (&cells)[4], float (&boxes)[4][6]) -> uint32_t {
+#ifdef MVR_TRACE
+    const unsigned long long tnq = __builtin_amdgcn_s_memrealtime();
+#endif
     while (pq_tail - pq_head < 4u) {
       const uint32_t tile = advance();
       if (tile == kNone) break;
@@ -413,6 +434,9 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       }
     }
     pq_head += n;
+#ifdef MVR_TRACE
+    tr_t_next += __builtin_amdgcn_s_memrealtime() - tnq;
+#endif
     return n;
   };
 
@@ -425,13 +449,13 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   if (n_cur) fetch(cur);
   while (n_cur) {
     const unsigned long long t0 = MVR_CLK();
+    uint32_t n_nxt = next_quad(nxt, nbx);     // chosen with the bounds as they are NOW, while the current four land
+    const unsigned long long t1 = MVR_CLK();
     stage(cur);                               // registers -> LDS (waits for the prefetch)
     MVR_MARK(2);
 #ifdef MVR_TRACE
     ++trq;
 #endif
-    const unsigned long long t1 = MVR_CLK();
-    uint32_t n_nxt = next_quad(nxt, nbx);     // chosen with the bounds as they are NOW
     if (n_nxt) fetch(nxt);                    // in flight during the evaluation below
     const unsigned long long t2 = MVR_CLK();
     MVR_MARK(3);
@@ -441,17 +465,25 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     // the bounds have shrunk: re-validate the prefetched cells (a cell that is no longer needed is dropped,
     // its lane group idles; if none is left the next four are requested)
     while (n_nxt) {
+      float bxg[6];                     // lane group g re-tests cell g of the prefetched four
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        bxg[k] = nbx[0][k];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) bxg[k] = (g == r) ? nbx[r][k] : bxg[k];
+      }
+      const unsigned nd = needed4(bxg[0], bxg[1], bxg[2], bxg[3], bxg[4], bxg[5]);
       uint32_t live = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (nxt[r] != kNone && !needed(nbx[r][0], nbx[r][1], nbx[r][2], nbx[r][3], nbx[r][4], nbx[r][5])) nxt[r] = kNone;
+        if (!((nd >> r) & 1u)) nxt[r] = kNone;        // (an empty slot has a stale box: it stays empty either way)
         live += (nxt[r] != kNone) ? 1u : 0u;
       }
       if (live) break;
       n_nxt = next_quad(nxt, nbx);
       if (n_nxt) fetch(nxt);
     }
-    st_stage += t1 - t0; st_adv += t2 - t1; st_proc += t3 - t2; st_reval += MVR_CLK() - t3;
+    st_adv += t1 - t0; st_stage += t2 - t1; st_proc += t3 - t2; st_reval += MVR_CLK() - t3;
 #pragma unroll
     for (int r = 0; r < 4; ++r) cur[r] = nxt[r];
     n_cur = n_nxt;
@@ -460,7 +492,16 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   const unsigned long long st_loopend = MVR_CLK();
   MVR_MARK(5);
 
-  // ---- combine: 4 W partial results per query (W waves x 4 lane groups) meet in LDS (over the tile buffers)
+  // ---- combine: 4 W partial results per query (W waves x 4 lane groups) meet in LDS (over the tile buffers).
+  // The waves share out the 4 Q lane columns (16 queries each): wave wv finishes columns wv, wv + W, ...
+  // The queries are re-read before the barrier (their latency hides behind the wait for the slowest wave).
+  constexpr int NC = 4 * Q / W;                                 // columns per wave
+  float4 fq[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const uint32_t pos = b_begin + (uint32_t)((wv + j * W) * 16 + l16), rpos = pos < nq ? pos : b_begin;
+    fq[j] = qs[qlist ? qlist[rpos] : (q_begin + rpos)];         // this query's coordinates (and its original index)
+  }
   __syncthreads();
   nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [4 W][NB]: (d2 bits, sub-tile)
 #pragma unroll
@@ -468,38 +509,64 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     part[(wv * 4 + g) * NB + q * 16 + l16] = ((nnkey_t)__float_as_uint(best[q]) << 32) | bsub[q];
   __syncthreads();
   MVR_MARK(6);
-  // the waves share out the 4 Q lane columns (16 queries each); the index (lowest original index at
-  // distance == best) comes from one re-scan of the winning sub-tile, 8 points per lane group
+  nnkey_t pm[NC];
+  bool tie[NC];
 #pragma unroll
-  for (int col = 0; col < 4 * Q; ++col) {
-    if ((col % W) != wv) continue;              // wave-uniform
-    const int i = col * 16 + l16;
-    // this query's coordinates again (re-read: indexing the register arrays by the wave id would put them in scratch)
-    const uint32_t pos = b_begin + i, rpos = pos < nq ? pos : b_begin;
-    const float4 fq = qs[qlist ? qlist[rpos] : (q_begin + rpos)];
-    const float fx = fq.x, fy = fq.y, fz = fq.z;
-    nnkey_t pm = kKeyInit;
+  for (int j = 0; j < NC; ++j) {
+    const int i = (wv + j * W) * 16 + l16;
+    nnkey_t pk[4 * W];
+    pm[j] = kKeyInit;
 #pragma unroll
-    for (int p = 0; p < 4 * W; ++p) pm = min(pm, part[p * NB + i]);
-    const uint32_t dbits = (uint32_t)(pm >> 32), sub = (uint32_t)pm;
-    const float d = __uint_as_float(dbits);
-    const bool found = sub != kNone && d <= cap2;
-    uint32_t o = kNone;
-    if (found) {
-      o = span_argmin<FMA, kSub / 4>(ts, nt, sub * kSub + g * (kSub / 4), d, fx, fy, fz);
-      // rare: another partial reached the same distance in a different sub-tile
-#pragma unroll 1
-      for (int p = 0; p < 4 * W; ++p) {
-        const nnkey_t k = part[p * NB + i];
-        if ((uint32_t)(k >> 32) == dbits && (uint32_t)k != sub && (uint32_t)k != kNone)
-          o = min(o, span_argmin<FMA, kSub / 4>(ts, nt, (uint32_t)k * kSub + g * (kSub / 4), d, fx, fy, fz));
-      }
+    for (int p = 0; p < 4 * W; ++p) { pk[p] = part[p * NB + i]; pm[j] = min(pm[j], pk[p]); }
+    tie[j] = false;      // another partial reached the same distance in a different sub-tile (rare: duplicates / symmetric data)
+#pragma unroll
+    for (int p = 0; p < 4 * W; ++p)
+      tie[j] |= (uint32_t)(pk[p] >> 32) == (uint32_t)(pm[j] >> 32) && (uint32_t)pk[p] != (uint32_t)pm[j] && (uint32_t)pk[p] != kNone;
+  }
+  // the index (lowest original index at distance == best): one re-scan of the winning sub-tile, 8 points
+  // per lane group (MVR_CULL_CB columns' loads in flight at a time: 2 needs 64 registers and spills; measured equal)
+#ifndef MVR_CULL_CB
+#define MVR_CULL_CB 1
+#endif
+  constexpr int CB = NC < MVR_CULL_CB ? NC : MVR_CULL_CB;
+#pragma unroll
+  for (int j0 = 0; j0 < NC; j0 += CB) {
+    float4 cand[CB][kSub / 4];
+#pragma unroll
+    for (int jj = 0; jj < CB; ++jj) {
+      const uint32_t first = (uint32_t)pm[j0 + jj] * kSub + g * (kSub / 4);     // (clamped below: harmless when there is no winner)
+#pragma unroll
+      for (int k = 0; k < kSub / 4; ++k) cand[jj][k] = ts[min(first + (uint32_t)k, nt - 1u)];
     }
-    o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
-    o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
-    if (g == 0 && pos < nq) {
-      const uint32_t ord = qlist ? pos : __float_as_uint(fq.w);     // key slot: list position / original index
-      keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
+#pragma unroll
+    for (int jj = 0; jj < CB; ++jj) {
+      const int j = j0 + jj;
+      const int i = (wv + j * W) * 16 + l16;
+      const uint32_t pos = b_begin + (uint32_t)i;
+      const uint32_t dbits = (uint32_t)(pm[j] >> 32), sub = (uint32_t)pm[j];
+      const float d = __uint_as_float(dbits);
+      const bool found = sub != kNone && d <= cap2;
+      uint32_t o = kNone;
+      if (found) {
+        const uint32_t first = sub * kSub + g * (kSub / 4);
+#pragma unroll
+        for (int k = 0; k < kSub / 4; ++k)
+          if (first + (uint32_t)k < nt && dist2<FMA>(cand[jj][k], fq[j].x, fq[j].y, fq[j].z) == d) o = min(o, __float_as_uint(cand[jj][k].w));
+        if (tie[j]) {
+#pragma unroll 1
+          for (int p = 0; p < 4 * W; ++p) {
+            const nnkey_t k = part[p * NB + i];
+            if ((uint32_t)(k >> 32) == dbits && (uint32_t)k != sub && (uint32_t)k != kNone)
+              o = min(o, span_argmin<FMA, kSub / 4>(ts, nt, (uint32_t)k * kSub + g * (kSub / 4), d, fq[j].x, fq[j].y, fq[j].z));
+          }
+        }
+      }
+      o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
+      o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
+      if (g == 0 && pos < nq) {
+        const uint32_t ord = qlist ? pos : __float_as_uint(fq[j].w);     // key slot: list position / original index
+        keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
+      }
     }
   }
   MVR_MARK(7);
@@ -519,7 +586,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       if (wv == 0) {
         tr[0] = tr_rt0;
         for (int k = 0; k < 8; ++k) tr[4 + k] = trm[k];
-        tr[12] = trq; tr[13] = tiles_tested;
+        tr[12] = trq; tr[13] = tiles_tested; tr[14] = ((unsigned long long)tr_open << 32) | tr_exp;
+        tr[15] = (tr_t_open << 40) | (tr_t_exp << 20) | tr_t_next;
       }
       atomicMax(tr + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
       atomicMax(tr + 2, (unsigned long long)cells_done);

@@ -23,6 +23,8 @@ with mvr.Context(0) as ctx:
 t = np.loadtxt(path, dtype=np.uint64)
 blk, st, en, cells, hw = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4]
 marks, nquads = t[:, 5:13].astype(np.float64), t[:, 13]
+ntests, n_open, n_exp = t[:, 14], t[:, 15] >> np.uint64(32), t[:, 15] & np.uint64(0xFFFFFFFF)
+t_open, t_exp, t_next = (t[:, 16] >> np.uint64(40)).astype(float) / 100, ((t[:, 16] >> np.uint64(20)) & np.uint64(0xFFFFF)).astype(float) / 100, (t[:, 16] & np.uint64(0xFFFFF)).astype(float) / 100
 t0 = st.min()
 st = (st - t0).astype(np.float64) / 100.0; en = (en - t0).astype(np.float64) / 100.0          # us
 dur = en - st
@@ -51,3 +53,5 @@ for label, sel in (("resident at t=0", st < 5), ("started later", st >= 5)):
         if m.sum() < 5: continue
         print("%s, wave 0 ran %d quad(s): %d blocks, block duration %.1f us" % (label, nq, m.sum(), dur[m].mean()))
         print("   " + "  ".join("%s %.1f" % (nm, v) for nm, v in zip(names, rel[m].mean(0))))
+        print("   wave 0: %.1f box tests, %.1f ballot blocks opened (%.2f us in all), %.1f tiles expanded (%.2f us), next_quad total %.2f us" %
+              (ntests[m].mean(), n_open[m].mean(), t_open[m].mean(), n_exp[m].mean(), t_exp[m].mean(), t_next[m].mean()))
