@@ -212,9 +212,6 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   // current four are being evaluated out of LDS (coordinates only: the index, w, is
   // not needed before the final re-scan).  A missing cell / point is +inf: never a minimum.
   float pre[4][3];
-  uint32_t gmask[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) gmask[r] = (g == r) ? 0xFFFFFFFFu : 0u;
   auto fetch = [&](const uint32_t (&cells)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -236,8 +233,9 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   // evaluates the four cells currently staged in this wave's LDS buffer: lane group g takes cell g
   auto process = [&](const uint32_t (&cells)[4]) {
     const float4 *Tg = T + g * kGrpPitch;
-    // this lane group's cell (bit masks: a select chain over g gets turned into a scratch-memory table)
-    const uint32_t mycell = (cells[0] & gmask[0]) | (cells[1] & gmask[1]) | (cells[2] & gmask[2]) | (cells[3] & gmask[3]);
+    // this lane group's cell (bit masks: any select chain over the group number gets turned into a scratch-memory table)
+    const uint32_t mycell = (cells[0] & (0u - (uint32_t)(g == 0))) | (cells[1] & (0u - (uint32_t)(g == 1))) |
+                            (cells[2] & (0u - (uint32_t)(g == 2))) | (cells[3] & (0u - (uint32_t)(g == 3)));
 #pragma unroll 1
     for (int s = 0; s < 64; s += kSub) {
       float m[NQ];
@@ -618,10 +616,11 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   (void)st_entry; (void)st_stage; (void)st_adv; (void)st_proc; (void)st_reval; (void)st_begin; (void)st_loopend;
 }
 
-// One kernel per (queries per set, waves per set); all compiled for 4 waves per SIMD (<= 128 VGPRs:
-// measured, 4, 5 and 6 resident waves run equally fast).
+// One kernel per (queries per set, waves per set), compiled for 5 waves per SIMD (<= 96 VGPRs).  A single
+// launch runs equally fast with 4, 5 or 6 resident waves (it is bound by its tail), but with the scan
+// pairs of a step overlapping on several streams the chip stays full and residency pays (~3 %).
 #ifndef MVR_CULL_WAVES
-#define MVR_CULL_WAVES 4
+#define MVR_CULL_WAVES 5
 #endif
 #ifdef MVR_CULL_WAVES_MAX          // experiments: cap the residency as well
 #define MVR_CULL_WAVES_ATTR MVR_CULL_WAVES, MVR_CULL_WAVES_MAX
@@ -634,7 +633,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       const float4 *__restrict__ thi, const float4 *__restrict__ cbox, const float4 *__restrict__ sbox,                \
       uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals
 template <bool FMA, int Q, int W>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(MVR_CULL_WAVES_ATTR))) nn_cull_kernel(MVR_CULL_ARGS)
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? MVR_CULL_WAVES : 3))) nn_cull_kernel(MVR_CULL_ARGS)
 {
   nn_cull_body<FMA, Q, W>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, cbox, sbox, n_tiles, cap2, keys, evals);
 }

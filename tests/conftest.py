@@ -42,6 +42,10 @@ def gpu(mvr, request):
     """A GPU context; -m gpu tests fail loudly (no skip, no fallback) without one.
     Every parity test runs against both exact search kernels: the spatially
     culled one (default: 2 waves share a query set; also 1 and 4) and the brute-force one."""
+    # torch (used by the ring tests for streams / the edge table) initialises its HIP state FIRST, as in bench.py:
+    # one full run hung for minutes at the first torch use after dozens of library streams already existed
+    import torch
+    torch.cuda.init()
     ctx = mvr.Context(0)
     ctx.tune(nn_mode=0 if request.param == "brute" else 1)
     if request.param.startswith("culled_w"):
