@@ -187,6 +187,27 @@ int  mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src_slots, co
                              const size_t *q_count, const double origin[3],
                              mvr_pair_moments2_t *out, double *dev_out);
 
+/* ---- target sharding over ranks (sequential mode, registrator.cpp:563-577, is loop-carried and does not
+ * shard by pair: the growing TARGET is split by points, every rank holds the full source).  A target slot
+ * can be a shard: mvr_cloud_set_global_base / mvr_cloud_append_range record which GLOBAL point numbers its
+ * local points carry.  One ICP iteration over G ranks is then
+ *   mvr_nn_forward_keys        -> dev_keys[Ns] signed 64-bit (d2 bits << 32 | GLOBAL target index; INT64_MAX = none)
+ *   all-reduce MIN over ranks    (RCCL ncclInt64/ncclMin: d2 >= 0, so signed order = (d2, index) order and
+ *                                 ties go to the lowest global index -- the single-GPU rule)
+ *   mvr_pair_moments2_from_keys -> this rank's share of the sums: reciprocal check, acceptance and raw
+ *                                 second moments of the matches whose target point it OWNS (32 doubles,
+ *                                 [31] = sum of d2), device output
+ *   all-reduce SUM of the 32 doubles; then the usual host solve (mvr_moments_from_moments2 +
+ *   mvr_umeyama_from_moments).  multi-view-registration_amd/seq.py is that loop. */
+int  mvr_cloud_set_global_base(mvr_ctx *ctx, int slot, size_t global_begin);
+int  mvr_cloud_append_range(mvr_ctx *ctx, int dst_slot, int src_slot, size_t src_begin, size_t count,
+                            size_t global_begin);
+int  mvr_nn_forward_keys(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_dist, int fma_dist,
+                         long long *dev_keys);
+int  mvr_pair_moments2_from_keys(mvr_ctx *ctx, int src_slot, int tgt_slot, const long long *dev_keys,
+                                 double max_dist, int reciprocal, int fma_dist, const double origin[3],
+                                 double *dev_out);
+
 /* raw second moments of caller-supplied correspondences (lum.setCorrespondences,
  * registrator.cpp:650): query[k] indexes src_slot, match[k] indexes tgt_slot. */
 int  mvr_pair_moments2_from_corr(mvr_ctx *ctx, int src_slot, int tgt_slot, const int32_t *query,

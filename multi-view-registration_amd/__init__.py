@@ -112,6 +112,10 @@ SIGNATURES = {
     "mvr_cloud_reserve": (C.c_int, [_vp, C.c_int, _sz]),
     "mvr_cloud_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
     "mvr_cloud_append": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mvr_cloud_set_global_base": (C.c_int, [_vp, C.c_int, _sz]),
+    "mvr_cloud_append_range": (C.c_int, [_vp, C.c_int, C.c_int, _sz, _sz, _sz]),
+    "mvr_nn_forward_keys": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
+    "mvr_pair_moments2_from_keys": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.c_int, _dp, _vp]),
     "mvr_cloud_clear": (C.c_int, [_vp, C.c_int]),
     "mvr_cloud_transform": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "mvr_cloud_transform_f32": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
@@ -397,6 +401,22 @@ class Context:
         idx, d2 = np.empty(n, np.uint32), np.empty(n, np.float32)
         _chk(_lib.mvr_nn(self._h, q_slot, t_slot, int(fma), _p(idx, C.c_uint32), _p(d2, C.c_float)), self._h)
         return idx, d2
+
+    # ---- target sharding over ranks (sequential mode): see seq.py
+    def set_global_base(self, slot, global_begin):
+        _chk(_lib.mvr_cloud_set_global_base(self._h, slot, int(global_begin)), self._h)
+
+    def append_range(self, dst, src, src_begin, count, global_begin):
+        _chk(_lib.mvr_cloud_append_range(self._h, dst, src, int(src_begin), int(count), int(global_begin)), self._h)
+
+    def nn_forward_keys(self, s, t, max_dist, dev_ptr, fma=False):
+        """forward NN of slot s in the (shard) slot t -> Ns signed 64-bit keys with GLOBAL target indices at dev_ptr"""
+        _chk(_lib.mvr_nn_forward_keys(self._h, s, t, float(max_dist), int(fma), _vp(dev_ptr)), self._h)
+
+    def pair_moments2_from_keys(self, s, t, keys_dev_ptr, max_dist, origin, out_dev_ptr, reciprocal=True, fma=False):
+        o = np.ascontiguousarray(origin, np.float64)
+        _chk(_lib.mvr_pair_moments2_from_keys(self._h, s, t, _vp(keys_dev_ptr), float(max_dist), int(reciprocal), int(fma),
+                                              _p(o, C.c_double), _vp(out_dev_ptr)), self._h)
 
     def correspondences(self, s, t, max_dist, reciprocal=True, fma=False):
         n = self.size(s)

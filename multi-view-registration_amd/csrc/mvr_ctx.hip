@@ -138,52 +138,67 @@ float cap_from_max2(double max2)
 // Leaves keys[], slot[], rkeys[] ready for pass1.
 struct SearchPlan { const uint32_t *qperm = nullptr; const uint32_t *tinv = nullptr; };
 
-int run_search(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool reciprocal, bool fma,
-               double *evals, SearchPlan *plan)
+// forward pass: keys[i] = (d2, LOCAL target index) of source query i (kKeyInit beyond the cap / no target)
+int search_forward(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool fma, double *evals, SearchPlan *plan)
 {
   const size_t ns = src.n, nt = tgt.n;
   const double max2 = max_dist * max_dist;
-  const bool cull = c->nn_mode != 0;
   *plan = SearchPlan();
   if (int rc = ensure(c, c->keys, c->keys_cap, ns)) return rc;
   if (int rc = ensure(c, c->match, c->match_cap, ns)) return rc;
-  if (cull && ns > 0 && nt > 0) {
+  if (c->nn_mode != 0 && ns > 0 && nt > 0) {
     if (int rc = ensure_index(c, src)) return rc;
     if (int rc = ensure_index(c, tgt)) return rc;
     plan->qperm = src.order->perm;
     plan->tinv = tgt.order->inv;
     // keys are written (not min-combined) by exactly one wave per query
-    if (int rc = launch_nn_cull(c, src, qb, qn, nullptr, nullptr, tgt, cap_from_max2(max2), fma, c->keys)) return rc;
-    if (reciprocal && qn > 0) {
-      const size_t nl = std::min(qn, nt);
-      if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
-      if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
-      if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
-      if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
-      if (int rc = launch_mark_sorted(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags, c->list, c->count,
-                                      c->slot)) return rc;
-      // reverse pass: queries = distinct matched targets (Morton order), searched in the WHOLE source
-      if (int rc = launch_nn_cull(c, tgt, 0, nl, c->list, c->count, src, cap_from_max2(max2), fma, c->rkeys)) return rc;
-    }
-    (void)evals;
-    return MVR_OK;
+    return launch_nn_cull(c, src, qb, qn, nullptr, nullptr, tgt, cap_from_max2(max2), fma, c->keys);
   }
   if (int rc = launch_fill_u64(c, c->keys + qb, qn, kKeyInit)) return rc;
   if (int rc = launch_nn(c, src.pts, qb, qn, nullptr, nullptr, tgt.pts, nt, fma, c->keys)) return rc;
   if (evals) *evals += (double)qn * (double)nt;
-  if (reciprocal && nt > 0 && qn > 0) {
-    const size_t nl = std::min(qn, nt);
-    if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
-    if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
-    if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
-    MVR_HIP_TRY(c, hipMemsetAsync(c->slot, 0xFF, nt * sizeof(uint32_t), c->stream));
-    MVR_HIP_TRY(c, hipMemsetAsync(c->count, 0, sizeof(uint32_t), c->stream));
-    if (int rc = launch_mark(c, c->keys, qb, qn, max2, c->slot, c->list, c->count)) return rc;
-    if (int rc = launch_fill_u64(c, c->rkeys, nl, kKeyInit)) return rc;
-    // reverse pass: queries = distinct matched targets, searched in the WHOLE source
-    if (int rc = launch_nn(c, tgt.pts, 0, nl, c->list, c->count, src.pts, ns, fma, c->rkeys)) return rc;
-  }
   return MVR_OK;
+}
+
+// reciprocal pass on the keys in c->keys (from search_forward, or imported after a reduction over ranks):
+// the distinct matched targets are searched in the WHOLE source.  Leaves slot[], rkeys[] ready for pass1.
+int search_reciprocal(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool fma, const SearchPlan *plan)
+{
+  const size_t ns = src.n, nt = tgt.n;
+  const double max2 = max_dist * max_dist;
+  if (nt == 0 || qn == 0) return MVR_OK;
+  const size_t nl = std::min(qn, nt);
+  if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
+  if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
+  if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
+  if (c->nn_mode != 0 && ns > 0) {
+    if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
+    if (int rc = launch_mark_sorted(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags, c->list, c->count,
+                                    c->slot)) return rc;
+    // queries = distinct matched targets (Hilbert order)
+    return launch_nn_cull(c, tgt, 0, nl, c->list, c->count, src, cap_from_max2(max2), fma, c->rkeys);
+  }
+  MVR_HIP_TRY(c, hipMemsetAsync(c->slot, 0xFF, nt * sizeof(uint32_t), c->stream));
+  MVR_HIP_TRY(c, hipMemsetAsync(c->count, 0, sizeof(uint32_t), c->stream));
+  if (int rc = launch_mark(c, c->keys, qb, qn, max2, c->slot, c->list, c->count)) return rc;
+  if (int rc = launch_fill_u64(c, c->rkeys, nl, kKeyInit)) return rc;
+  return launch_nn(c, tgt.pts, 0, nl, c->list, c->count, src.pts, ns, fma, c->rkeys);
+}
+
+int run_search(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool reciprocal, bool fma,
+               double *evals, SearchPlan *plan)
+{
+  if (int rc = search_forward(c, src, tgt, qb, qn, max_dist, fma, evals, plan)) return rc;
+  if (reciprocal && src.n > 0) { if (int rc = search_reciprocal(c, src, tgt, qb, qn, max_dist, fma, plan)) return rc; }
+  return MVR_OK;
+}
+
+SegTable seg_table(const Cloud &cl)
+{
+  SegTable st;
+  st.n = (uint32_t)cl.segs.size();
+  for (uint32_t k = 0; k < st.n; ++k) { st.lb[k] = cl.segs[k].local_begin; st.cnt[k] = cl.segs[k].count; st.gb[k] = cl.segs[k].global_begin; }
+  return st;
 }
 
 int read_moments(Ctx *c, size_t n_doubles)
@@ -323,6 +338,7 @@ API int mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, siz
   Cloud &cl = c->slots[slot];
   cl.n = 0;
   cl.has_normals = false;
+  cl.segs.clear();
   new_point_set(c, cl);
   if (int rc = cloud_reserve(c, cl, n, false)) return rc;
   if (n) {
@@ -435,6 +451,7 @@ API int mvr_cloud_clear(mvr_ctx *ctx, int slot)
   Ctx *c = CTX(ctx);
   c->slots[slot].n = 0;
   c->slots[slot].has_normals = false;
+  c->slots[slot].segs.clear();
   new_point_set(c, c->slots[slot]);
   return MVR_OK;
 }
@@ -454,6 +471,7 @@ API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
   }
   d.n = s.n;
   inherit_point_set(d, s);
+  d.segs = s.segs;
   d.has_normals = false;
   if (s.has_normals && s.n) {
     if (int rc = ensure(c, d.nrm, d.nrm_cap, s.n)) return rc;
@@ -470,6 +488,12 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   Cloud &d = c->slots[dst];
   const size_t add = c->slots[src].n;         // read before a self-append grows it
+  if (!d.segs.empty()) {                       // a shard: the appended points continue its global numbering
+    uint32_t gend = 0;
+    for (const Seg &sg : d.segs) gend = std::max(gend, sg.global_begin + sg.count);
+    if ((int)d.segs.size() >= kMaxSegs) return set_error(c, MVR_E_ARG, "too many segments in a sharded cloud");
+    d.segs.push_back(Seg{(uint32_t)d.n, (uint32_t)add, gend});
+  }
   if (int rc = cloud_reserve(c, d, d.n + add, true)) return rc;
   const Cloud &s = c->slots[src];
   if (add) {
@@ -505,7 +529,7 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
   if (int rc = launch_transform_f64(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
-  if (dst != src) inherit_point_set(c->slots[dst], c->slots[src]);
+  if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
   c->slots[dst].coords_valid = false;
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
@@ -554,7 +578,7 @@ API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16
   if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
   if (int rc = launch_transform_f32(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
-  if (dst != src) inherit_point_set(c->slots[dst], c->slots[src]);
+  if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
   c->slots[dst].coords_valid = false;
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
@@ -665,7 +689,7 @@ static int moments2_impl(Ctx *c, int ss, int ts, double max_dist, int reciprocal
   if (qn > s.n - qb) qn = s.n - qb;
   SearchPlan plan;
   if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, qb, qn, nullptr, &plan)) return rc;
-  return launch_moments2(c, s.pts, t.pts, c->match, plan.qperm, qb, qn, origin, dev_out);
+  return launch_moments2(c, s.pts, t.pts, c->match, c->keys, plan.qperm, qb, qn, origin, dev_out);
 }
 
 API int mvr_pair_moments2_dev(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb,
@@ -761,6 +785,70 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
   return MVR_OK;
 }
 
+// ---- target sharding over ranks (sequential mode): forward keys out, reduced keys in ----
+API int mvr_nn_forward_keys(mvr_ctx *ctx, int ss, int ts, double max_dist, int fma, long long *dev_keys)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !dev_keys) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &s = c->slots[ss], &t = c->slots[ts];
+  if (s.n == 0) return MVR_OK;
+  SearchPlan plan;
+  if (int rc = search_forward(c, s, t, 0, s.n, max_dist, fma != 0, nullptr, &plan)) return rc;
+  return launch_export_keys(c, c->keys, s.n, seg_table(t), dev_keys);
+}
+
+API int mvr_pair_moments2_from_keys(mvr_ctx *ctx, int ss, int ts, const long long *dev_keys, double max_dist, int reciprocal,
+                                    int fma, const double origin[3], double *dev_out)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !dev_keys || !origin || !dev_out) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &s = c->slots[ss], &t = c->slots[ts];
+  SearchPlan plan;
+  if (int rc = ensure(c, c->keys, c->keys_cap, s.n)) return rc;
+  if (int rc = ensure(c, c->match, c->match_cap, s.n)) return rc;
+  if (c->nn_mode != 0 && s.n > 0 && t.n > 0) {
+    if (int rc = ensure_index(c, s)) return rc;
+    if (int rc = ensure_index(c, t)) return rc;
+    plan.qperm = s.order->perm; plan.tinv = t.order->inv;
+  }
+  if (int rc = launch_import_keys(c, dev_keys, s.n, seg_table(t), c->keys)) return rc;
+  if (reciprocal && s.n > 0) { if (int rc = search_reciprocal(c, s, t, 0, s.n, max_dist, fma != 0, &plan)) return rc; }
+  if (int rc = launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, c->count, plan.qperm, plan.tinv, 0, s.n,
+                            max_dist * max_dist, reciprocal != 0 && t.n > 0, c->match, c->moments)) return rc;
+  return launch_moments2(c, s.pts, t.pts, c->match, c->keys, plan.qperm, 0, s.n, origin, dev_out);
+}
+
+API int mvr_cloud_set_global_base(mvr_ctx *ctx, int slot, size_t global_begin)
+{
+  if (!ctx || !slot_ok(slot)) return MVR_E_ARG;
+  Cloud &cl = CTX(ctx)->slots[slot];
+  if (cl.n > 0xFFFFFFF0ull || global_begin + cl.n > 0xFFFFFFF0ull) return MVR_E_ARG;
+  cl.segs.assign(1, Seg{0u, (uint32_t)cl.n, (uint32_t)global_begin});
+  return MVR_OK;
+}
+
+API int mvr_cloud_append_range(mvr_ctx *ctx, int dst, int src, size_t src_begin, size_t count, size_t global_begin)
+{
+  if (!ctx || !slot_ok(dst) || !slot_ok(src) || dst == src) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  Cloud &d = c->slots[dst];
+  const Cloud &s = c->slots[src];
+  if (src_begin > s.n || count > s.n - src_begin) return set_error(c, MVR_E_ARG, "append range outside the source cloud");
+  if (d.n + count > 0xFFFFFFF0ull || global_begin + count > 0xFFFFFFF0ull) return MVR_E_ARG;
+  if (d.segs.empty() && d.n) d.segs.assign(1, Seg{0u, (uint32_t)d.n, 0u});      // what was there keeps its own numbering
+  if ((int)d.segs.size() >= kMaxSegs) return set_error(c, MVR_E_ARG, "too many segments in a sharded cloud");
+  if (int rc = cloud_reserve(c, d, d.n + count, true)) return rc;
+  if (count) MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts + src_begin, count * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+  d.segs.push_back(Seg{(uint32_t)d.n, (uint32_t)count, (uint32_t)global_begin});
+  d.n += count;
+  d.has_normals = false;
+  new_point_set(c, d);
+  return MVR_OK;
+}
+
 API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t *query, const int32_t *match,
                                     size_t m, const double origin[3], mvr_pair_moments2_t *out)
 {
@@ -780,7 +868,7 @@ API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t 
   if (int rc = ensure(c, c->match, c->match_cap, s.n)) return rc;
   MVR_HIP_TRY(c, hipMemcpyAsync(c->match, hm.data(), s.n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));     // hm goes out of scope
-  if (int rc = launch_moments2(c, s.pts, t.pts, c->match, nullptr, 0, s.n, origin, c->moments)) return rc;
+  if (int rc = launch_moments2(c, s.pts, t.pts, c->match, nullptr, nullptr, 0, s.n, origin, c->moments)) return rc;
   if (int rc = read_moments(c, 32)) return rc;
   std::memcpy(out, c->h_moments, sizeof *out);
   return MVR_OK;

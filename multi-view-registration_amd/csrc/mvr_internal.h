@@ -30,6 +30,13 @@ struct Order {
 // every lane moves one point with a single 16-byte access (dwordx4).
 // For the culled search it also carries a Morton-ordered copy (w = bits of the
 // original index) and one AABB per 256-point tile of that copy.
+// A cloud may be a SHARD of a larger (distributed) cloud: segment k says that local points
+// [local_begin, local_begin + count) are global points [global_begin, global_begin + count).
+// No segments = the cloud is its own global numbering.
+struct Seg { uint32_t local_begin, count, global_begin; };
+constexpr int kMaxSegs = 64;
+struct SegTable { uint32_t n; uint32_t lb[kMaxSegs], cnt[kMaxSegs], gb[kMaxSegs]; };
+
 struct Cloud {
   float4 *pts = nullptr;
   size_t n = 0;
@@ -44,6 +51,7 @@ struct Cloud {
   // optional unit normals {nx,ny,nz,0} (point-to-plane extension, K10)
   float4 *nrm = nullptr; size_t nrm_cap = 0;
   bool has_normals = false;
+  std::vector<Seg> segs;               // global numbering of a shard (target sharding over ranks)
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;      // "no neighbour" index
@@ -197,6 +205,10 @@ int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_
                        uint32_t *count, uint32_t *slot);
 
 int launch_fill_u64(Ctx *c, nnkey_t *p, size_t n, nnkey_t v);
+// keys with LOCAL target indices <-> signed 64-bit keys with GLOBAL target indices (what a MIN all-reduce over
+// ranks combines; "no neighbour" = INT64_MAX).  import keeps only the matches this shard owns.
+int launch_export_keys(Ctx *c, const nnkey_t *keys, size_t n, const SegTable &st, long long *out);
+int launch_import_keys(Ctx *c, const long long *in, size_t n, const SegTable &st, nnkey_t *keys);
 int launch_mark(Ctx *c, const nnkey_t *keys, size_t q_begin, size_t q_count, double max2,
                 uint32_t *slot, uint32_t *list, uint32_t *count);
 // The per-query kernels walk positions [q_begin, q_begin+q_count) and take the
@@ -210,7 +222,7 @@ int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *ke
 int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
                  size_t q_begin, size_t q_count, double *moments);
 // raw second moments about `origin` into out[0..31] (device pointer)
-int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
+int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const nnkey_t *keys, const uint32_t *qperm,
                     size_t q_begin, size_t q_count, const double origin[3], double *out);
 // K10 (extension): point-to-plane normal equations over the accepted pairs:
 // out[0..20] = upper triangle of sum a a^T (a = [p x n, n]), out[21..26] = sum a*d,

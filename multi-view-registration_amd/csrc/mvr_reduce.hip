@@ -110,6 +110,38 @@ __global__ void transform_f64_kernel(const float4 *__restrict__ in, float4 *__re
   out[i] = o;
 }
 
+// ---- target sharding over ranks: local <-> global target indices inside the u64 NN keys ----
+// out = signed keys a MIN all-reduce can combine: (d2 bits << 32) | GLOBAL index, INT64_MAX for "none"
+// (d2 >= 0, so the sign bit is clear and signed order = (d2, index) order)
+__global__ void export_keys_kernel(const nnkey_t *__restrict__ keys, size_t n, SegTable st, long long *__restrict__ out)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const nnkey_t k = keys[i];
+  uint32_t j = (uint32_t)k;
+  if (j == kNone || (k >> 63)) { out[i] = 0x7FFFFFFFFFFFFFFFll; return; }
+  for (uint32_t s = 0; s < st.n; ++s)
+    if (j >= st.lb[s] && j - st.lb[s] < st.cnt[s]) { j = st.gb[s] + (j - st.lb[s]); break; }
+  out[i] = (long long)((k & 0xFFFFFFFF00000000ull) | j);
+}
+
+// the reduced keys back into this shard's terms: a match this shard owns becomes a local index,
+// everything else "none" -- so every correspondence is processed by exactly one rank
+__global__ void import_keys_kernel(const long long *__restrict__ in, size_t n, SegTable st, nnkey_t *__restrict__ keys)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = (unsigned long long)in[i];
+  const uint32_t j = (uint32_t)k;
+  nnkey_t o = kKeyInit;
+  if (k != 0x7FFFFFFFFFFFFFFFull && j != kNone) {
+    if (st.n == 0) o = k;
+    for (uint32_t s = 0; s < st.n; ++s)
+      if (j >= st.gb[s] && j - st.gb[s] < st.cnt[s]) { o = (k & 0xFFFFFFFF00000000ull) | (st.lb[s] + (j - st.gb[s])); break; }
+  }
+  keys[i] = o;
+}
+
 // up to kBatchClouds clouds in one launch (blockIdx.y = cloud): the per-view kernels of a global iteration
 // are a few microseconds each, so a dozen separate launches cost more than the work
 __global__ void transform_f64_batch_kernel(XformBatch b)
@@ -279,12 +311,12 @@ struct Vec3d { double x, y, z; };
 
 __global__ void __launch_bounds__(kRT)
 moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const int32_t *__restrict__ match,
-                const uint32_t *__restrict__ qperm, size_t q_begin, size_t q_count, Vec3d o,
+                const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ qperm, size_t q_begin, size_t q_count, Vec3d o,
                 double *__restrict__ partials)
 {
-  double acc[28];
+  double acc[29];       // [28] = sum of the correspondences' d2 (the f32 values the search found), when keys are given
 #pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  for (int k = 0; k < 29; ++k) acc[k] = 0.0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
     const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
@@ -301,21 +333,22 @@ moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, 
     acc[19] += px * qx; acc[20] += px * qy; acc[21] += px * qz;
     acc[22] += py * qx; acc[23] += py * qy; acc[24] += py * qz;
     acc[25] += pz * qx; acc[26] += pz * qy; acc[27] += pz * qz;
+    if (keys) acc[28] += (double)__uint_as_float((uint32_t)(keys[i] >> 32));
   }
-  block_partials<28>(acc, partials);
+  block_partials<29>(acc, partials);
 }
 
-// out (32 doubles): [0] n, [1..3] origin, [4..6] sp, [7..9] sq, [10..15] spp, [16..21] sqq, [22..30] spq, [31] 0
+// out (32 doubles): [0] n, [1..3] origin, [4..6] sp, [7..9] sq, [10..15] spp, [16..21] sqq, [22..30] spq, [31] sum d2 (or 0)
 __global__ void __launch_bounds__(kRT) moments2_final_kernel(const double *__restrict__ partials, int rows, Vec3d o,
                                                               double *__restrict__ out)
 {
-  __shared__ double lds[28];
-  double s[28];
-  sum_rows<28>(partials, rows, s, lds);
+  __shared__ double lds[29];
+  double s[29];
+  sum_rows<29>(partials, rows, s, lds);
   if (threadIdx.x == 0) {
     out[0] = s[0]; out[1] = o.x; out[2] = o.y; out[3] = o.z;
     for (int k = 1; k < 28; ++k) out[3 + k] = s[k];
-    out[31] = 0.0;
+    out[31] = s[28];
   }
 }
 
@@ -474,6 +507,22 @@ int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float
   return MVR_OK;
 }
 
+int launch_export_keys(Ctx *c, const nnkey_t *keys, size_t n, const SegTable &st, long long *out)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, keys, n, st, out);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_import_keys(Ctx *c, const long long *in, size_t n, const SegTable &st, nnkey_t *keys)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(import_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, in, n, st, keys);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
 int launch_unpack_xyz(Ctx *c, const float *packed, float4 *out, size_t n)
 {
   if (n == 0) return MVR_OK;
@@ -538,14 +587,14 @@ int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *ma
   return MVR_OK;
 }
 
-int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
+int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const nnkey_t *keys, const uint32_t *qperm,
                     size_t q_begin, size_t q_count, const double origin[3], double *out)
 {
   const int blocks = reduce_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   Vec3d o{origin[0], origin[1], origin[2]};
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
-  hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, qperm, q_begin, q_count,
+  hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, keys, qperm, q_begin, q_count,
                      o, c->partials);
   hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
   MVR_HIP_TRY(c, hipGetLastError());
