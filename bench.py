@@ -274,6 +274,19 @@ def main():
                                          "exact NN built per pair, reciprocal filter, Umeyama), oracle/mvr_oracle.c, "
                                          "1 thread, %.1f s" % (nq // N, passes, V, dt),
                                "host_cpus": os.cpu_count()}
+        # courtesy upper bound: the same searches with OpenMP over the queries; the reference is single-threaded
+        threads = max(1, min(16, os.cpu_count() or 1))         # a 1-GPU box's CPU share
+        t0 = time.perf_counter()
+        nq = 0
+        while time.perf_counter() - t0 < 5.0:
+            for s, t in reg.edges:
+                c = orc.correspondences_mt(clouds[s], clouds[t], args.max_dist, threads, reciprocal=True, fma=bool(args.fma))
+                orc.umeyama(clouds[s], clouds[t], c)
+                nq += len(clouds[s])
+        dt = time.perf_counter() - t0
+        out["cpu_baseline_openmp"] = {"value": nq / dt, "unit": "correspondences/s", "cores": threads, "kind": "port",
+                                      "sample": "%d ring pairs, kd-trees built serially, per-query searches on %d OpenMP threads, %.1f s"
+                                                % (nq // N, threads, dt)}
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

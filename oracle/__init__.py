@@ -72,6 +72,8 @@ def lib():
         L.orc_correspondences.restype = C.c_size_t
         L.orc_correspondences.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_double,
                                           C.c_int, C.c_int, C.c_int, vp]
+        L.orc_correspondences_mt.restype = C.c_size_t
+        L.orc_correspondences_mt.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, vp]
         L.orc_umeyama.restype = C.c_int
         L.orc_umeyama.argtypes = [fp, fp, vp, C.c_size_t, fp, dp]
         L.orc_umeyama_from_moments.argtypes = [dp, dp, dp, fp, dp]
@@ -179,6 +181,15 @@ def correspondences(src, tgt, max_dist, reciprocal=True, fma=False, kdtree=True)
     m = lib().orc_correspondences(_p(src, C.c_float), len(src), _p(tgt, C.c_float), len(tgt),
                                   float(max_dist), int(reciprocal), int(fma), int(kdtree),
                                   out.ctypes.data)
+    return out[:m].copy()
+
+
+def correspondences_mt(src, tgt, max_dist, threads, reciprocal=True, fma=False):
+    """kd-tree correspondences with the per-query searches on `threads` OpenMP threads (same output)."""
+    src, tgt = _pts(src), _pts(tgt)
+    out = np.empty(max(len(src), 1), CORR_DTYPE)
+    m = lib().orc_correspondences_mt(_p(src, C.c_float), len(src), _p(tgt, C.c_float), len(tgt), float(max_dist),
+                                     int(reciprocal), int(fma), int(threads), out.ctypes.data)
     return out[:m].copy()
 
 

@@ -325,6 +325,38 @@ API size_t orc_correspondences(const float *src, size_t ns, const float *tgt, si
   return m;
 }
 
+/* The same correspondences with the per-query searches spread over `threads` OpenMP threads -- a courtesy
+ * CPU baseline ("OpenMP over queries on all host cores, core count printed"); the reference
+ * itself is single-threaded.  Output identical to orc_correspondences (kd-tree), in index order. */
+API size_t orc_correspondences_mt(const float *src, size_t ns, const float *tgt, size_t nt, double max_dist,
+                                  int reciprocal, int fma, int threads, orc_corr *out)
+{
+  const double max2 = max_dist * max_dist;
+  if (threads < 1) threads = 1;
+  kdtree *kt = kd_build(tgt, nt), *ks = reciprocal ? kd_build(src, ns) : NULL;
+  int32_t *mj = (int32_t *)malloc((ns ? ns : 1) * sizeof(int32_t));
+  float *md = (float *)malloc((ns ? ns : 1) * sizeof(float));
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(threads)
+  for (long long ii = 0; ii < (long long)ns; ++ii) {
+    const size_t i = (size_t)ii;
+    uint32_t j, i2; float d, dr;
+    mj[i] = -1;
+    kd_nn(kt, src + 4 * i, fma, &j, &d);
+    if (j == UINT32_MAX || (double)d > max2) continue;
+    if (reciprocal) {
+      kd_nn(ks, tgt + 4 * (size_t)j, fma, &i2, &dr);
+      if ((double)dr > max2 || i2 != (uint32_t)i) continue;
+    }
+    mj[i] = (int32_t)j; md[i] = d;
+  }
+  size_t m = 0;
+  for (size_t i = 0; i < ns; ++i)
+    if (mj[i] >= 0) { out[m].query = (int32_t)i; out[m].match = mj[i]; out[m].dist2 = md[i]; ++m; }
+  free(mj); free(md);
+  kd_free(kt); kd_free(ks);
+  return m;
+}
+
 /* ------------------------------------------------------------------- SVD 3x3 */
 
 static double det3(const double M[9])

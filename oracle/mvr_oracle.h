@@ -84,6 +84,9 @@ void   orc_nn_kdtree(const float *q, size_t nq, const float *t, size_t nt, int f
 size_t orc_correspondences(const float *src, size_t ns, const float *tgt, size_t nt,
                            double max_dist, int reciprocal, int fma, int use_kdtree,
                            orc_corr *out);
+/* multi-threaded (OpenMP over queries) kd-tree variant: same output; a courtesy CPU baseline */
+size_t orc_correspondences_mt(const float *src, size_t ns, const float *tgt, size_t nt, double max_dist,
+                              int reciprocal, int fma, int threads, orc_corr *out);
 
 /* a6: TransformationEstimationSVD (Umeyama, no scaling). Returns 0, or -1
  * when m < 3.  mom (may be NULL) receives the 20 moments:

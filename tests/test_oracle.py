@@ -325,3 +325,15 @@ def test_p2plane_kat_recovers_small_motion(orc, mvr):
     d = ((moved - tgt[:, :3]) * nrm[:, :3]).sum(1)
     assert np.abs(d).max() < 2e-2
     assert orc.p2plane(src, tgt, nrm, corr[:2])[0] is None
+
+
+def test_multithreaded_correspondences_equal_single_thread(orc):
+    """orc_correspondences_mt (OpenMP over queries, the courtesy CPU baseline of bench.py) == the serial kd-tree path."""
+    rng = np.random.default_rng(31)
+    src = np.ones((6000, 4), np.float32); src[:, :3] = rng.standard_normal((6000, 3)) * 5 + [0, 0, 900]
+    tgt = np.ones((7000, 4), np.float32); tgt[:, :3] = rng.standard_normal((7000, 3)) * 5 + [0, 0, 900]
+    for rec in (True, False):
+        a = orc.correspondences(src, tgt, 0.8, reciprocal=rec, kdtree=True)
+        for th in (1, 3, 8):
+            b = orc.correspondences_mt(src, tgt, 0.8, th, reciprocal=rec)
+            assert np.array_equal(a, b)
