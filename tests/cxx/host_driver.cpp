@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <string>
 
+#include "mvr/io.hpp"
 #include "mvr/registrator.hpp"
 
 using namespace mvr;
@@ -70,8 +71,60 @@ int main(int argc, char **argv)
   reg3.setAxisNormal(ax[0], ax[1] * 0.99, ax[2] * 1.02);
   for (int v = 0; v < V; ++v) model.views[v].setRegisterState(true);   // poses from `reg` above = exact
   reg3.refineAxis(0);
-  std::printf("\"refined\":[%.9g,%.9g,%.9g,%.9g,%.9g,%.9g]", reg3.getPivotPoint()[0], reg3.getPivotPoint()[1], reg3.getPivotPoint()[2],
+  std::printf("\"refined\":[%.9g,%.9g,%.9g,%.9g,%.9g,%.9g],", reg3.getPivotPoint()[0], reg3.getPivotPoint()[1], reg3.getPivotPoint()[2],
               reg3.getAxisNormal()[0], reg3.getAxisNormal()[1], reg3.getAxisNormal()[2]);
+
+  // ---- PCD / points.asc (mvr/io.hpp): a deterministic rich cloud through all three encodings and back
+  io::RichCloud cloud(1037);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)(st >> 8) / 16777216.0f; };
+  for (size_t i = 0; i < cloud.size(); ++i) {
+    io::RichPoint &p = cloud[i];
+    p.x = 200.f * rnd() - 100.f; p.y = 200.f * rnd() - 100.f; p.z = 900.f + 50.f * rnd();
+    p.r = (uint8_t)(255 * rnd()); p.g = (uint8_t)(i & 255); p.b = (uint8_t)((i * 7) & 255);
+    p.normal_x = rnd(); p.normal_y = rnd(); p.normal_z = rnd(); p.curvature = 0.01f * rnd();
+    if (i >= 500) { p.normal_x = 0.f; p.normal_y = 0.f; p.normal_z = 1.f; p.curvature = 0.f; }   // long runs: LZF back references
+  }
+  const char *names[3] = {"ascii", "binary", "compressed"};
+  std::printf("\"pcd\":{");
+  for (int m = 0; m < 3; ++m) {
+    const std::string fn = dir + "/cloud_" + names[m] + ".pcd";
+    const bool saved = io::savePCDFile(fn, cloud, (io::PcdMode)m);
+    io::RichCloud back;
+    const bool loaded = io::loadPCDFile(fn, back);
+    bool same = loaded && back.size() == cloud.size();
+    for (size_t i = 0; same && i < cloud.size(); ++i)
+      same = std::memcmp(&back[i].x, &cloud[i].x, 12) == 0 && back[i].r == cloud[i].r && back[i].g == cloud[i].g && back[i].b == cloud[i].b &&
+             back[i].normal_x == cloud[i].normal_x && back[i].normal_y == cloud[i].normal_y && back[i].normal_z == cloud[i].normal_z &&
+             back[i].curvature == cloud[i].curvature;
+    std::printf("\"%s\":[%d,%d,%d],", names[m], (int)saved, (int)loaded, (int)same);
+  }
+  {
+    // a file another writer could have produced: different field order, f64 coordinates, u8 extra field, CRLF header
+    const std::string fn = dir + "/foreign.pcd";
+    FILE *f = std::fopen(fn.c_str(), "wb");
+    std::fprintf(f, "# foreign\r\nVERSION .7\r\nFIELDS label z y x\r\nSIZE 1 8 8 8\r\nTYPE U F F F\r\nCOUNT 1 1 1 1\r\nWIDTH 3\r\nHEIGHT 1\r\nPOINTS 3\r\nDATA binary\n");
+    for (int i = 0; i < 3; ++i) { uint8_t l = (uint8_t)i; double v[3] = {30.0 + i, 20.0 + i, 10.0 + i}; std::fwrite(&l, 1, 1, f); std::fwrite(v, 8, 3, f); }
+    std::fclose(f);
+    io::RichCloud back;
+    const bool ok = io::loadPCDFile(fn, back);
+    std::printf("\"foreign\":[%d,%zu,%.9g,%.9g,%.9g],", (int)ok, back.size(), ok ? back[2].x : 0.f, ok ? back[2].y : 0.f, ok ? back[2].z : 0.f);
+    // truncated payload / no xyz / missing file -> false, cloud untouched
+    io::RichCloud keep(2);
+    const std::string tr = dir + "/truncated.pcd";
+    { std::ifstream in((dir + "/cloud_compressed.pcd").c_str(), std::ios::binary); std::string all((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+      std::ofstream o(tr.c_str(), std::ios::binary); o.write(all.data(), (std::streamsize)(all.size() * 2 / 3)); }
+    const bool t1 = io::loadPCDFile(tr, keep);
+    const std::string nx = dir + "/noxyz.pcd";
+    { FILE *g = std::fopen(nx.c_str(), "w"); std::fprintf(g, "VERSION .7\nFIELDS a b\nSIZE 4 4\nTYPE F F\nCOUNT 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA ascii\n1 2\n"); std::fclose(g); }
+    const bool t2 = io::loadPCDFile(nx, keep), t3 = io::loadPCDFile(dir + "/nope.pcd", keep);
+    std::printf("\"rejects\":[%d,%d,%d,%zu],", (int)t1, (int)t2, (int)t3, keep.size());
+  }
+  std::printf("\"asc\":%d,", (int)io::savePointsASC(dir + "/points.asc", cloud));
+  std::printf("\"path\":\"%s\"},", io::pointsFilename("/data/ws", 7, 3).c_str());
+  PointCloud<PointXYZ> xyz;
+  io::toXYZ(cloud, xyz);
+  std::printf("\"xyz\":[%zu,%.9g,%.9g]", xyz.size(), xyz.points[5].x, xyz.points[5].data[3]);
   std::printf("}\n");
   return 0;
 }

@@ -81,3 +81,41 @@ def test_refine_axis_recovers_the_turntable(host):
     assert abs(abs(ax @ a) - 1) < 1e-6                      # axis direction recovered
     off = piv - PIV
     assert np.linalg.norm(off - (off @ a) * a) < 1e-2       # pivot back on the true axis line
+
+
+def test_pcd_round_trips_and_rejects(host):
+    out, d = host
+    for mode in ("ascii", "binary", "compressed"):
+        assert out["pcd"][mode] == [1, 1, 1], mode                  # saved, loaded, identical (ascii prints %.9g: exact for f32)
+    assert out["pcd"]["foreign"][:2] == [1, 3] and out["pcd"]["foreign"][2:] == [12.0, 22.0, 32.0]      # field order z y x, f64, extra u8 field
+    assert out["pcd"]["rejects"] == [0, 0, 0, 2]                    # truncated payload, no x y z, missing file; cloud untouched
+    assert out["pcd"]["path"] == "/data/ws/points/object_00007/view_03/points.pcd"
+    assert out["xyz"][0] == 1037 and out["xyz"][2] == 1.0           # data[3] = 1 (pcl::PointXYZ padding)
+
+
+def test_pcd_bytes_against_independent_reader(host):
+    """The three files, decoded by a reader written separately from the format description (tests/pcd_py.py): same header
+    vocabulary PCL uses, same values in every encoding, binary_compressed is field-major behind {u32 csize, u32 usize}."""
+    import pcd_py
+    out, d = host
+    recs = {}
+    for mode in ("ascii", "binary", "compressed"):
+        hdr, rec = pcd_py.read_pcd(os.path.join(d, "cloud_%s.pcd" % mode))
+        assert hdr["FIELDS"] == ["x", "y", "z", "rgb", "normal_x", "normal_y", "normal_z", "curvature"]
+        assert hdr["SIZE"] == ["4"] * 8 and hdr["TYPE"] == ["F"] * 8 and hdr["WIDTH"] == ["1037"] and hdr["HEIGHT"] == ["1"]
+        assert hdr["VIEWPOINT"] == ["0", "0", "0", "1", "0", "0", "0"] and hdr["VERSION"] == ["0.7"]
+        recs[mode] = rec
+    for f in ("x", "y", "z", "normal_x", "normal_y", "normal_z", "curvature"):
+        assert np.array_equal(recs["binary"][f], recs["compressed"][f])
+        assert np.array_equal(recs["binary"][f], recs["ascii"][f])
+    rgb = recs["binary"]["rgb"].view(np.uint32)
+    assert np.array_equal(rgb, recs["compressed"]["rgb"].view(np.uint32))
+    assert np.array_equal((rgb >> 8) & 255, np.arange(1037) & 255) and np.array_equal(rgb & 255, (np.arange(1037) * 7) & 255)
+    assert (rgb >> 24).max() == 0
+    # the compressed file really is compressed (smooth fields), and smaller than the binary one
+    assert os.path.getsize(os.path.join(d, "cloud_compressed.pcd")) < os.path.getsize(os.path.join(d, "cloud_binary.pcd"))
+    # points.asc: "%f %f %f %d %d %d"
+    lines = open(os.path.join(d, "points.asc")).read().strip().split("\n")
+    assert out["pcd"]["asc"] == 1 and len(lines) == 1037
+    x, y, z, r, g, b = lines[5].split()
+    assert abs(float(x) - recs["binary"]["x"][5]) < 1e-6 and len(x.split(".")[1]) == 6 and int(g) == 5 and int(b) == 35
