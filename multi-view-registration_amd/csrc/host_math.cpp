@@ -187,6 +187,59 @@ int solve_dense(int n, double *A, double *b)
   return MVR_OK;
 }
 
+// Symmetric positive definite systems (the LUM normal equations G x = B are one unless the graph is
+// degenerate): right-looking Cholesky U^T U on a scratch copy of the upper triangle.  Every inner loop is
+// an axpy over a contiguous row segment (vectorisable without re-associating sums), rows are only as long
+// as their last non-zero and zero multipliers are skipped, so the block-banded matrix of a ring of views
+// costs O(n b^2) instead of O(n^3).  Falls back to the pivoted elimination (solve_dense) when a pivot is
+// not safely positive.
+int solve_spd(int n, double *A, double *b)
+{
+  static thread_local std::vector<double> U;          // scratch, reused: only [j, end[j]) of a row is ever valid
+  static thread_local std::vector<int> end;           // one past the last non-zero of row j (upper part)
+  if (U.size() < (size_t)n * n) U.resize((size_t)n * n);
+  if (end.size() < (size_t)n) end.resize((size_t)n);
+  double amax = 0.0;
+  for (int j = 0; j < n; ++j) {
+    amax = std::max(amax, std::fabs(A[(size_t)j * n + j]));
+    int e = j + 1;
+    for (int k = n - 1; k > j; --k) if (A[(size_t)j * n + k] != 0.0) { e = k + 1; break; }
+    std::memcpy(&U[(size_t)j * n + j], &A[(size_t)j * n + j], (size_t)(e - j) * sizeof(double));
+    end[j] = e;
+  }
+  bool ok = amax > 0.0;
+  for (int j = 0; j < n && ok; ++j) {
+    double *Uj = &U[(size_t)j * n];
+    const double d = Uj[j];
+    if (!(d > 1e-13 * amax)) { ok = false; break; }
+    const double ujj = std::sqrt(d), inv = 1.0 / ujj;
+    const int ej = end[j];
+    Uj[j] = ujj;
+    for (int k = j + 1; k < ej; ++k) Uj[k] *= inv;
+    for (int i = j + 1; i < ej; ++i) {
+      const double f = Uj[i];
+      if (f == 0.0) continue;
+      double *Ui = &U[(size_t)i * n];
+      if (end[i] < ej) { std::memset(Ui + end[i], 0, (size_t)(ej - end[i]) * sizeof(double)); end[i] = ej; }   // fill-in
+      for (int k = i; k < ej; ++k) Ui[k] -= f * Uj[k];
+    }
+  }
+  if (!ok) return solve_dense(n, A, b);
+  for (int i = 0; i < n; ++i) {                       // U^T y = b, column-oriented: axpy over row i of U
+    const double y = b[i] / U[(size_t)i * n + i];
+    b[i] = y;
+    const double *Ui = &U[(size_t)i * n];
+    for (int k = i + 1; k < end[i]; ++k) b[k] -= Ui[k] * y;
+  }
+  for (int i = n - 1; i >= 0; --i) {                  // U x = y
+    const double *Ui = &U[(size_t)i * n];
+    double s = b[i];
+    for (int k = i + 1; k < end[i]; ++k) s -= Ui[k] * b[k];
+    b[i] = s / Ui[i];
+  }
+  return MVR_OK;
+}
+
 }  // namespace mvr
 
 using namespace mvr;
@@ -342,6 +395,16 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   for (int e = 0; e < ne; ++e) if (es[e] < 0 || es[e] >= n || et[e] < 0 || et[e] >= n) return MVR_E_ARG;
   const int dim = 6 * (n - 1);
   std::vector<double> G((size_t)dim * dim), B(dim), cinv((size_t)ne * 36), cinvd((size_t)ne * 6);
+  // edge between an (unordered) vertex pair, looked up once: first as (s, t), then as (t, s)
+  std::vector<int> eidx((size_t)n * n, -1);
+  std::vector<char> efwd((size_t)n * n, 0);
+  for (int vi = 0; vi < n; ++vi)
+    for (int vj = 0; vj < n; ++vj) {
+      int e = -1; bool fwd = false;
+      for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vi && et[k] == vj) { e = k; fwd = true; }
+      for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vj && et[k] == vi) e = k;
+      eidx[(size_t)vi * n + vj] = e; efwd[(size_t)vi * n + vj] = fwd;
+    }
   int it = 0;
   for (; it < max_iterations; ++it) {
     for (int e = 0; e < ne; ++e) {
@@ -358,9 +421,8 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     std::fill(G.begin(), G.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
     for (int vi = 1; vi < n; ++vi)
       for (int vj = 0; vj < n; ++vj) {
-        int e = -1; bool fwd = false;
-        for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vi && et[k] == vj) { e = k; fwd = true; }
-        for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vj && et[k] == vi) e = k;
+        const int e = eidx[(size_t)vi * n + vj];
+        const bool fwd = efwd[(size_t)vi * n + vj] != 0;
         if (e < 0) continue;
         for (int r = 0; r < 6; ++r)
           for (int c = 0; c < 6; ++c) {
@@ -369,7 +431,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
           }
         for (int r = 0; r < 6; ++r) B[6 * (vi - 1) + r] += (fwd ? 1.0 : -1.0) * cinvd[6 * e + r];
       }
-    if (solve_dense(dim, G.data(), B.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
+    if (solve_spd(dim, G.data(), B.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
     double sum = 0.0;
     for (int vi = 1; vi < n; ++vi) {
       double inc[36], incinv[36], dp[6], nrm = 0.0;
