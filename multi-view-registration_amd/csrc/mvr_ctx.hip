@@ -688,8 +688,10 @@ static int moments2_impl(Ctx *c, int ss, int ts, double max_dist, int reciprocal
   if (qb > s.n) qb = s.n;
   if (qn > s.n - qb) qn = s.n - qb;
   SearchPlan plan;
-  if (int rc = pair_common(c, ss, ts, max_dist, reciprocal, fma, qb, qn, nullptr, &plan)) return rc;
-  return launch_moments2(c, s.pts, t.pts, c->match, c->keys, plan.qperm, qb, qn, origin, dev_out);
+  Cloud &sc = c->slots[ss], &tc = c->slots[ts];
+  if (int rc = run_search(c, sc, tc, qb, qn, max_dist, reciprocal != 0, fma != 0, nullptr, &plan)) return rc;
+  return launch_accept_moments2(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, plan.qperm, plan.tinv, qb, qn, max_dist * max_dist,
+                                reciprocal != 0 && t.n > 0, origin, dev_out);
 }
 
 API int mvr_pair_moments2_dev(mvr_ctx *ctx, int ss, int ts, double max_dist, int reciprocal, int fma, size_t qb,
@@ -815,9 +817,8 @@ API int mvr_pair_moments2_from_keys(mvr_ctx *ctx, int ss, int ts, const long lon
   }
   if (int rc = launch_import_keys(c, dev_keys, s.n, seg_table(t), c->keys)) return rc;
   if (reciprocal && s.n > 0) { if (int rc = search_reciprocal(c, s, t, 0, s.n, max_dist, fma != 0, &plan)) return rc; }
-  if (int rc = launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, c->count, plan.qperm, plan.tinv, 0, s.n,
-                            max_dist * max_dist, reciprocal != 0 && t.n > 0, c->match, c->moments)) return rc;
-  return launch_moments2(c, s.pts, t.pts, c->match, c->keys, plan.qperm, 0, s.n, origin, dev_out);
+  return launch_accept_moments2(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, plan.qperm, plan.tinv, 0, s.n, max_dist * max_dist,
+                                reciprocal != 0 && t.n > 0, origin, dev_out);
 }
 
 API int mvr_cloud_set_global_base(mvr_ctx *ctx, int slot, size_t global_begin)

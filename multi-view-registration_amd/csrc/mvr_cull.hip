@@ -653,7 +653,8 @@ int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const
   if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
   const int W = (c->cull_w == 1 || c->cull_w == 4) ? c->cull_w : 2;          // waves sharing one query set (measured best: 2)
   const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (W cooperating waves) per query set
-  MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+  // region A (this launch's evaluations) is only read back by the profiler
+  if (c->prof) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
 #ifdef MVR_TRACE
   MVR_HIP_TRY(c, hipMemsetAsync(c->evals + 2 * kEvalRegion, 0, kTraceRec * kTraceBlocks * sizeof(unsigned long long), c->stream));
 #endif

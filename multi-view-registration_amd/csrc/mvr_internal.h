@@ -222,6 +222,9 @@ int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *ke
 int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
                  size_t q_begin, size_t q_count, double *moments);
 // raw second moments about `origin` into out[0..31] (device pointer)
+int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys, const nnkey_t *rkeys,
+                           const uint32_t *slot, const uint32_t *qperm, const uint32_t *tinv, size_t q_begin, size_t q_count,
+                           double max2, bool reciprocal, const double origin[3], double *out);
 int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const nnkey_t *keys, const uint32_t *qperm,
                     size_t q_begin, size_t q_count, const double origin[3], double *out);
 // K10 (extension): point-to-plane normal equations over the accepted pairs:

@@ -338,6 +338,47 @@ moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, 
   block_partials<29>(acc, partials);
 }
 
+// K5 + K8 in one pass for the global mode: the reciprocal filter of pass1_kernel and the sums of
+// moments2_kernel (same acceptance, same accumulation order, so the same bits), without the centroid
+// reduction, its final kernel and the match[] round trip that only the two-pass covariance needs.
+__global__ void __launch_bounds__(kRT)
+accept_moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const nnkey_t *__restrict__ keys,
+                       const nnkey_t *__restrict__ rkeys, const uint32_t *__restrict__ slot, const uint32_t *__restrict__ qperm,
+                       const uint32_t *__restrict__ tinv, size_t q_begin, size_t q_count, double max2, int reciprocal, Vec3d o,
+                       double *__restrict__ partials)
+{
+  double acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
+    const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
+    const nnkey_t key = keys[i];
+    const uint32_t j = (uint32_t)key;
+    const float d2 = __uint_as_float((uint32_t)(key >> 32));
+    bool ok = (j != kNone) && !((double)d2 > max2);
+    if (ok && reciprocal) {
+      const nnkey_t rk = rkeys[slot[tinv ? tinv[j] : j]];
+      const float dr = __uint_as_float((uint32_t)(rk >> 32));
+      ok = ((uint32_t)rk == (uint32_t)i) && !((double)dr > max2);
+    }
+    if (!ok) continue;
+    const float4 p4 = src[i], q4 = tgt[j];
+    const double px = (double)p4.x - o.x, py = (double)p4.y - o.y, pz = (double)p4.z - o.z;
+    const double qx = (double)q4.x - o.x, qy = (double)q4.y - o.y, qz = (double)q4.z - o.z;
+    acc[0] += 1.0;
+    acc[1] += px; acc[2] += py; acc[3] += pz;
+    acc[4] += qx; acc[5] += qy; acc[6] += qz;
+    acc[7] += px * px; acc[8] += px * py; acc[9] += px * pz; acc[10] += py * py; acc[11] += py * pz; acc[12] += pz * pz;
+    acc[13] += qx * qx; acc[14] += qx * qy; acc[15] += qx * qz; acc[16] += qy * qy; acc[17] += qy * qz; acc[18] += qz * qz;
+    acc[19] += px * qx; acc[20] += px * qy; acc[21] += px * qz;
+    acc[22] += py * qx; acc[23] += py * qy; acc[24] += py * qz;
+    acc[25] += pz * qx; acc[26] += pz * qy; acc[27] += pz * qz;
+    acc[28] += (double)d2;
+  }
+  block_partials<29>(acc, partials);
+}
+
 // out (32 doubles): [0] n, [1..3] origin, [4..6] sp, [7..9] sq, [10..15] spp, [16..21] sqq, [22..30] spq, [31] sum d2 (or 0)
 __global__ void __launch_bounds__(kRT) moments2_final_kernel(const double *__restrict__ partials, int rows, Vec3d o,
                                                               double *__restrict__ out)
@@ -596,6 +637,21 @@ int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t 
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
   hipLaunchKernelGGL(moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, keys, qperm, q_begin, q_count,
                      o, c->partials);
+  hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys, const nnkey_t *rkeys,
+                           const uint32_t *slot, const uint32_t *qperm, const uint32_t *tinv, size_t q_begin, size_t q_count,
+                           double max2, bool reciprocal, const double origin[3], double *out)
+{
+  const int blocks = reduce_blocks(c, q_count);
+  if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
+  Vec3d o{origin[0], origin[1], origin[2]};
+  ProfScope ps(c, MVR_K_REDUCE, 40.0 * (double)q_count);
+  hipLaunchKernelGGL(accept_moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, keys, rkeys, slot, qperm, tinv,
+                     q_begin, q_count, max2, reciprocal ? 1 : 0, o, c->partials);
   hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
