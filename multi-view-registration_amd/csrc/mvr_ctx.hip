@@ -70,6 +70,15 @@ int prof_drain(Ctx *c)
       w->prof_launches[f] = 0; w->prof_ms[f] = 0.0; w->prof_work[f] = 0.0;
     }
   }
+  if (c->prof_totals && c->evals) {      // level 2: the culled kernel's evaluations of this context since the last drain
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t h[kEvalRegion];
+    MVR_HIP_TRY(c, hipMemcpy(h, c->evals, sizeof h, hipMemcpyDeviceToHost));
+    double s = 0.0;
+    for (int k = 0; k < kEvalShards; ++k) s += (double)h[(size_t)k * kEvalStride];
+    c->prof_work[MVR_K_NN] += s;
+    MVR_HIP_TRY(c, hipMemset(c->evals, 0, sizeof h));
+  }
   if (c->recs.empty()) return MVR_OK;
   MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (auto &r : c->recs) {
@@ -727,7 +736,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->prof = c->prof; w->prof_mask = c->prof_mask;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -1074,9 +1083,11 @@ API int mvr_prof_enable(mvr_ctx *ctx, int on)
 {
   if (!ctx) return MVR_E_ARG;
   Ctx *c = CTX(ctx);
-  if (!on) { if (int rc = prof_drain(c)) return rc; }
+  if (int rc = prof_drain(c)) return rc;                    // settle what the previous mode collected
   c->prof = on != 0;
   c->prof_mask = (on == 2) ? (1u << MVR_K_NN) : ~0u;       // 2: time the search kernels only (cheapest)
+  c->prof_totals = on == 2;
+  for (Ctx *w : c->workers) { w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals; w->prof_totals = c->prof_totals; }
   return MVR_OK;
 }
 

@@ -653,13 +653,15 @@ int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const
   if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
   const int W = (c->cull_w == 1 || c->cull_w == 4) ? c->cull_w : 2;          // waves sharing one query set (measured best: 2)
   const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (W cooperating waves) per query set
-  // region A (this launch's evaluations) is only read back by the profiler
-  if (c->prof) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+  // region A (evaluations) is only read back by the profiler: per launch at level 1 (cleared here, copied out
+  // after the launch), as a running total at level 2 (cleared when profiling starts, read once at the end)
+  const bool per_launch = c->prof && !c->prof_totals;
+  if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
 #ifdef MVR_TRACE
   MVR_HIP_TRY(c, hipMemsetAsync(c->evals + 2 * kEvalRegion, 0, kTraceRec * kTraceBlocks * sizeof(unsigned long long), c->stream));
 #endif
-  ProfScope ps(c, MVR_K_NN, c->evals, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, (double)q_count * (double)t.n,
-               kEvalShards);
+  ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0,
+               per_launch ? (double)q_count * (double)t.n : 0.0, per_launch ? kEvalShards : 0);
 #define MVR_LAUNCH_CULL(F, QQ, WW)                                                                                       \
   hipLaunchKernelGGL((nn_cull_kernel<F, QQ, WW>), dim3(blocks), dim3(64 * WW), 0, c->stream, q.sorted, (uint32_t)q_begin, \
                      (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, t.cbox, t.sbox, n_tiles,   \

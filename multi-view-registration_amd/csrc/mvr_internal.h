@@ -124,6 +124,7 @@ struct Ctx {
   // instrumentation
   bool prof = false;
   unsigned prof_mask = ~0u;                           // families that are timed (bit f = family f)
+  bool prof_totals = false;                           // level 2: culled evaluations accumulate in region A, read once at drain
   std::vector<hipEvent_t> event_pool;                 // timing events are recycled, not re-created per launch
   std::vector<ProfRec> recs;
   uint64_t *h_counts = nullptr;                       // pinned: device counters copied per profiled launch
