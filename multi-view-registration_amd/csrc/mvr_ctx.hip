@@ -263,6 +263,7 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete c; return MVR_E_HIP; }
   c->n_cu = prop.multiProcessorCount; c->clock_mhz = prop.clockRate / 1000; c->name = prop.gcnArchName;
   if (const char *m = std::getenv("MVR_NN_MODE")) c->nn_mode = std::atoi(m);   // 0 brute force, 1 culled (default)
+  if (const char *m = std::getenv("MVR_CULL_Q")) c->cull_q = std::atoi(m);     // 64-query groups per set: 1, 2 (0 = auto)
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }

@@ -124,7 +124,10 @@ class RingLUM:
         table = b.edge_rows(self.segments, self.edges, self.max_dist, self.origin)
         t1 = time.perf_counter()              # everything enqueued (asynchronous)
         if self.all_reduce is not None:
-            self.all_reduce(table)            # per-pair sums/residuals of all ranks -> every rank
+            import contextlib
+            # the collective must be ordered after the library's kernels: issue it on the backend's stream
+            with getattr(b, "_on_stream", contextlib.nullcontext)():
+                self.all_reduce(table)        # per-pair sums/residuals of all ranks -> every rank
         rows = b.to_host(table)
         t2 = time.perf_counter()              # GPU drained, table on the host
         # host: per-pair rigid solve (3x3 SVD on the moments) + residuals, LUM graph
