@@ -294,3 +294,36 @@ def test_point_to_plane_extension(gpu, orc, mvr):
     gpu.upload(4, tgt)
     with pytest.raises(mvr.MvrError):
         gpu.icp_align(1, 4, 2, mvr.icp_params(point_to_plane=True))
+
+
+def test_one_million_point_pair_properties(gpu, mvr):
+    """BASELINE configs[4] point count (1M per scan): too big for the oracle in a test, so size-independent properties --
+    a cloud's NN in itself is the identity at d2 = 0, reciprocal correspondences are a one-to-one matching that is
+    symmetric under a role swap, every accepted pair is within max_dist, and the raw moments of the pair equal the
+    moments recomputed on the host from the correspondence list (the culled kernel takes its 128-query path here)."""
+    if gpu.mode in ("culled_w1", "culled_w4"):
+        pytest.skip("one wave-count variant is enough at this size")
+    n = 1_000_000
+    sp = mvr.synth_params(36, 4)
+    tgt, raw = mvr.synth_view(sp, 0, n), mvr.synth_view(sp, 1, n)
+    piv, ax = mvr.synth_prior(sp)
+    gpu.upload(0, tgt); gpu.upload(1, raw)
+    gpu.transform(1, 1, mvr.axis_rotation(piv, ax, mvr.turntable_angle(1, 36)))
+    src = gpu.download(1)
+    if gpu.mode != "brute":                         # 1e12 evaluations per search: the culled kernel only
+        si, sd = gpu.nn(0, 0)
+        assert np.array_equal(si, np.arange(n, dtype=np.uint32)) and np.all(sd == 0)
+    q, m, d = gpu.correspondences(1, 0, 4.0)
+    assert len(q) > 100000 and len(np.unique(m)) == len(m) and np.all(np.diff(q) > 0)
+    assert np.all(d <= np.float32(16.0))
+    dd = ((src[q, :3].astype(np.float32) - tgt[m, :3].astype(np.float32)) ** 2)
+    assert np.array_equal(bits(((dd[:, 0] + dd[:, 1]) + dd[:, 2]).astype(np.float32)), bits(d))     # d2 = (dx2 + dy2) + dz2, rounded per op
+    q2, m2, _ = gpu.correspondences(0, 1, 4.0)
+    assert set(zip(q.tolist(), m.tolist())) == set(zip(m2.tolist(), q2.tolist()))
+    origin = np.array(sp.pivot)
+    mom = gpu.pair_moments2(1, 0, 4.0, origin)
+    p = src[q, :3].astype(np.float64) - origin
+    t = tgt[m, :3].astype(np.float64) - origin
+    assert mom.n == len(q)
+    assert np.allclose(np.ctypeslib.as_array(mom.sp), p.sum(0), rtol=1e-10) and np.allclose(np.ctypeslib.as_array(mom.sq), t.sum(0), rtol=1e-10)
+    assert np.allclose(np.ctypeslib.as_array(mom.spq).reshape(3, 3), p.T @ t, rtol=1e-9)
