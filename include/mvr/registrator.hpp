@@ -60,6 +60,21 @@ class ScanCloud {
   }
   void initRotation(const Registrator &r);        // point_cloud.cpp:400-413
 
+  // point_cloud.cpp:423-465: drop the connected components (points linked when <= triangle_length apart -- the
+  // reference's short Delaunay edges give the same components) with fewer than segment_threshold points; the
+  // survivors are stored component after component, as the reference's denoised_cloud.  Returns the noise count.
+  size_t denoise(int segment_threshold, double triangle_length)
+  {
+    Device &d = Device::instance();
+    SlotGuard s;
+    const size_t before = points.size();
+    d.upload(s.s, points);
+    size_t kept = 0, comps = 0;
+    d.check(mvr_cloud_denoise(d.ctx(), s.s, segment_threshold, triangle_length, &kept, &comps, nullptr), "mvr_cloud_denoise");
+    d.download(s.s, points);
+    return before - kept;
+  }
+
   // point_cloud.cpp:305-326 / :328-347 -- `transformation.txt`: the column-vector
   // 4x4 printed row by row (matrix(j,i), i outer), "%lf " per element, one row per
   // line.  6 decimals: poses round-trip to 1e-6 only.

@@ -124,6 +124,14 @@ int  mvr_cloud_copy(mvr_ctx *ctx, int dst_slot, int src_slot);
 /* `*target += transformed_source` (registrator.cpp:576, :833, :982). */
 int  mvr_cloud_append(mvr_ctx *ctx, int dst_slot, int src_slot);
 int  mvr_cloud_clear(mvr_ctx *ctx, int slot);
+/* PointCloud::denoise(segment_threshold, triangle_length) (mvr/src/point_cloud.cpp:423-465): link the points
+ * whose distance is <= triangle_length (the same connected components as the reference's Delaunay edges of that
+ * length: the Euclidean MST is a subgraph of the Delaunay triangulation), drop the components with fewer than
+ * segment_threshold points; the cloud in `slot` is replaced by the kept points, component after component (ordered
+ * by their smallest point index), points in index order -- the reference's output order.  kept_index (optional,
+ * host, capacity = old size) receives the original indices of the kept points. */
+int  mvr_cloud_denoise(mvr_ctx *ctx, int slot, int segment_threshold, double triangle_length,
+                       size_t *n_kept, size_t *n_components, uint32_t *kept_index);
 /* PointCloud::getTransformedPoints (point_cloud.cpp:290-303): f32 points times
  * the f64 pose (osg::Matrixd::preMult incl. the w divide), rounded to f32.
  * dst_slot may equal src_slot. */

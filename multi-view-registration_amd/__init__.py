@@ -112,6 +112,7 @@ SIGNATURES = {
     "mvr_cloud_reserve": (C.c_int, [_vp, C.c_int, _sz]),
     "mvr_cloud_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
     "mvr_cloud_append": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "mvr_cloud_denoise": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _u32p]),
     "mvr_cloud_set_global_base": (C.c_int, [_vp, C.c_int, _sz]),
     "mvr_cloud_append_range": (C.c_int, [_vp, C.c_int, C.c_int, _sz, _sz, _sz]),
     "mvr_nn_forward_keys": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
@@ -401,6 +402,15 @@ class Context:
         idx, d2 = np.empty(n, np.uint32), np.empty(n, np.float32)
         _chk(_lib.mvr_nn(self._h, q_slot, t_slot, int(fma), _p(idx, C.c_uint32), _p(d2, C.c_float)), self._h)
         return idx, d2
+
+    def denoise(self, slot, segment_threshold=10, triangle_length=2.5):
+        """PointCloud::denoise in place.  Returns (kept original indices in output order, number of components)."""
+        n = self.size(slot)
+        idx = np.empty(max(n, 1), np.uint32)
+        kept, comps = C.c_size_t(), C.c_size_t()
+        _chk(_lib.mvr_cloud_denoise(self._h, slot, int(segment_threshold), float(triangle_length), C.byref(kept), C.byref(comps),
+                                    _p(idx, C.c_uint32)), self._h)
+        return idx[:kept.value].copy(), comps.value
 
     # ---- target sharding over ranks (sequential mode): see seq.py
     def set_global_base(self, slot, global_begin):

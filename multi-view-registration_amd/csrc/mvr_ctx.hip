@@ -466,6 +466,15 @@ API int mvr_cloud_clear(mvr_ctx *ctx, int slot)
   return MVR_OK;
 }
 
+API int mvr_cloud_denoise(mvr_ctx *ctx, int slot, int segment_threshold, double triangle_length, size_t *n_kept,
+                          size_t *n_components, uint32_t *kept_index)
+{
+  if (!ctx || !slot_ok(slot)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  return denoise_cloud(c, c->slots[slot], segment_threshold, triangle_length, n_kept, n_components, kept_index);
+}
+
 API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
 {
   if (!ctx || !slot_ok(dst) || !slot_ok(src)) return MVR_E_ARG;

@@ -205,6 +205,9 @@ int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_
                        double max2, const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list,
                        uint32_t *count, uint32_t *slot);
 
+// PointCloud::denoise (mvr_denoise.hip): the cloud is replaced by its kept points, in the reference's output order
+int denoise_cloud(Ctx *c, Cloud &cl, int segment_threshold, double triangle_length, size_t *n_kept, size_t *n_components,
+                  uint32_t *host_index);
 int launch_fill_u64(Ctx *c, nnkey_t *p, size_t n, nnkey_t v);
 // keys with LOCAL target indices <-> signed 64-bit keys with GLOBAL target indices (what a MIN all-reduce over
 // ranks combines; "no neighbour" = INT64_MAX).  import keeps only the matches this shard owns.

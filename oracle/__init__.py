@@ -74,6 +74,8 @@ def lib():
                                           C.c_int, C.c_int, C.c_int, vp]
         L.orc_correspondences_mt.restype = C.c_size_t
         L.orc_correspondences_mt.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_denoise.restype = C.c_size_t
+        L.orc_denoise.argtypes = [fp, C.c_size_t, C.c_int, C.c_double, u32p, u32p, C.POINTER(C.c_size_t)]
         L.orc_umeyama.restype = C.c_int
         L.orc_umeyama.argtypes = [fp, fp, vp, C.c_size_t, fp, dp]
         L.orc_umeyama_from_moments.argtypes = [dp, dp, dp, fp, dp]
@@ -191,6 +193,17 @@ def correspondences_mt(src, tgt, max_dist, threads, reciprocal=True, fma=False):
     m = lib().orc_correspondences_mt(_p(src, C.c_float), len(src), _p(tgt, C.c_float), len(tgt), float(max_dist),
                                      int(reciprocal), int(fma), int(threads), out.ctypes.data)
     return out[:m].copy()
+
+
+def denoise(pts, segment_threshold=10, triangle_length=2.5):
+    """PointCloud::denoise: returns (kept original indices in output order, label per point, number of components)."""
+    pts = _pts(pts)
+    out = np.empty(max(len(pts), 1), np.uint32)
+    lab = np.empty(max(len(pts), 1), np.uint32)
+    nc = C.c_size_t()
+    k = lib().orc_denoise(_p(pts, C.c_float), len(pts), int(segment_threshold), float(triangle_length),
+                          _p(out, C.c_uint32), _p(lab, C.c_uint32), C.byref(nc))
+    return out[:k].copy(), lab[:len(pts)].copy(), nc.value
 
 
 def umeyama(src, tgt, corr):

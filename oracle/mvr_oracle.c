@@ -357,6 +357,81 @@ API size_t orc_correspondences_mt(const float *src, size_t ns, const float *tgt,
   return m;
 }
 
+/* --------------------------------------------------------------------- denoise */
+static uint32_t uf_find(uint32_t *parent, uint32_t i)
+{
+  while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }
+  return i;
+}
+
+static int cmp_u64(const void *a, const void *b)
+{
+  const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+API size_t orc_denoise(const float *pts, size_t n, int segment_threshold, double triangle_length,
+                       uint32_t *out_index, uint32_t *label, size_t *n_components)
+{
+  if (n_components) *n_components = 0;
+  if (n == 0) return 0;
+  uint32_t *parent = (uint32_t *)malloc(n * sizeof(uint32_t));
+  for (size_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+  /* uniform grid with cells >= r: all pairs within r lie in the 27 neighbouring cells */
+  double lo[3] = { DBL_MAX, DBL_MAX, DBL_MAX }, hi[3] = { -DBL_MAX, -DBL_MAX, -DBL_MAX };
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { const double v = pts[4 * i + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
+  double h = triangle_length > 0 ? triangle_length : 1e-30;
+  for (int k = 0; k < 3; ++k) if ((hi[k] - lo[k]) / h > 1000000.0) h = (hi[k] - lo[k]) / 1000000.0;
+  /* sort (cell key, index) */
+  uint64_t *keyidx = (uint64_t *)malloc(n * 2 * sizeof(uint64_t));
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t c[3];
+    for (int k = 0; k < 3; ++k) c[k] = (uint64_t)((pts[4 * i + k] - lo[k]) / h);
+    keyidx[2 * i] = (c[2] << 42) | (c[1] << 21) | c[0];
+    keyidx[2 * i + 1] = i;
+  }
+  qsort(keyidx, n, 2 * sizeof(uint64_t), cmp_u64);
+  for (size_t a = 0; a < n; ++a) {
+    const uint64_t ka = keyidx[2 * a];
+    const size_t i = (size_t)keyidx[2 * a + 1];
+    const int64_t cx = (int64_t)(ka & 0x1FFFFF), cy = (int64_t)((ka >> 21) & 0x1FFFFF), cz = (int64_t)(ka >> 42);
+    for (int64_t dz = -1; dz <= 1; ++dz)
+      for (int64_t dy = -1; dy <= 1; ++dy) {
+        if (cz + dz < 0 || cy + dy < 0) continue;
+        const int64_t x0 = cx > 0 ? cx - 1 : 0;
+        const uint64_t k0 = ((uint64_t)(cz + dz) << 42) | ((uint64_t)(cy + dy) << 21) | (uint64_t)x0;
+        const uint64_t k1 = ((uint64_t)(cz + dz) << 42) | ((uint64_t)(cy + dy) << 21) | (uint64_t)(cx + 1);
+        /* lower bound of k0 */
+        size_t lo_i = 0, hi_i = n;
+        while (lo_i < hi_i) { const size_t mid = (lo_i + hi_i) / 2; if (keyidx[2 * mid] < k0) lo_i = mid + 1; else hi_i = mid; }
+        for (size_t b = lo_i; b < n && keyidx[2 * b] <= k1; ++b) {
+          const size_t j = (size_t)keyidx[2 * b + 1];
+          if (j >= i) continue;
+          const double dx = (double)pts[4 * i] - (double)pts[4 * j], dyy = (double)pts[4 * i + 1] - (double)pts[4 * j + 1],
+                       dzz = (double)pts[4 * i + 2] - (double)pts[4 * j + 2];
+          if (sqrt(dx * dx + dyy * dyy + dzz * dzz) > triangle_length) continue;   /* point_cloud.cpp:490-491 */
+          uint32_t ra = uf_find(parent, (uint32_t)i), rb = uf_find(parent, (uint32_t)j);
+          if (ra != rb) { if (ra < rb) parent[rb] = ra; else parent[ra] = rb; }      /* root = smallest index */
+        }
+      }
+  }
+  uint32_t *size = (uint32_t *)calloc(n, sizeof(uint32_t));
+  for (size_t i = 0; i < n; ++i) { const uint32_t r = uf_find(parent, (uint32_t)i); parent[i] = r; ++size[r]; if (label) label[i] = r; }
+  size_t ncomp = 0, kept = 0;
+  /* components in the order of their smallest index (boost::connected_components numbering), members ascending */
+  uint64_t *order = (uint64_t *)malloc(n * sizeof(uint64_t));
+  for (size_t i = 0; i < n; ++i) { if (parent[i] == i) ++ncomp; order[i] = ((uint64_t)parent[i] << 32) | (uint64_t)i; }
+  qsort(order, n, sizeof(uint64_t), cmp_u64);
+  for (size_t k = 0; k < n; ++k) {
+    const uint32_t i = (uint32_t)order[k], r = (uint32_t)(order[k] >> 32);
+    if ((int64_t)size[r] >= (int64_t)segment_threshold) out_index[kept++] = i;
+  }
+  if (n_components) *n_components = ncomp;
+  free(order); free(size); free(keyidx); free(parent);
+  return kept;
+}
+
 /* ------------------------------------------------------------------- SVD 3x3 */
 
 static double det3(const double M[9])

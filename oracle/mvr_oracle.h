@@ -146,6 +146,18 @@ int    orc_lum_compute(int n, const float *const *clouds, int ne, const int *es,
                        const int *et, const orc_corr *const *corr, const size_t *ncorr,
                        int max_iterations, double convergence_threshold, double *poses);
 
+/* PointCloud::denoise (mvr/src/point_cloud.cpp:423-465, graph from :467-500).  The reference
+ * links the points by the Delaunay edges no longer than triangle_length (sqrt of the squared distance, in double,
+ * `> threshold -> skip`), takes connected components (boost: numbered by their smallest point index) and keeps the
+ * components with at least segment_threshold points, component after component, points in index order.
+ * Restated WITHOUT a triangulation: the Euclidean minimum spanning tree is a subgraph of the Delaunay triangulation,
+ * so two points are joined by Delaunay edges <= r exactly when they are joined in the graph of ALL pairs <= r --
+ * the components are identical (points in general position; exact duplicates, which CGAL collapses into one vertex,
+ * are simply members of their component here).  out_index receives the original indices of the kept points in output
+ * order; label (optional, n entries) the smallest index of each point's component.  Returns the number kept. */
+size_t orc_denoise(const float *pts, size_t n, int segment_threshold, double triangle_length,
+                   uint32_t *out_index, uint32_t *label, size_t *n_components);
+
 /* dense solve helpers (exposed for tests) */
 int    orc_solve_dense(int n, double *A /*row-major, destroyed*/, double *b /*in: rhs, out: x*/);
 int    orc_invert6(const double A[36], double Ainv[36]);

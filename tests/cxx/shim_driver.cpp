@@ -4,7 +4,7 @@
 // to compare with the oracle-based restatement of the same driver loops.
 //
 // usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
-//   mode: seq | lum | lumdev | auto | err | api
+//   mode: seq | lum | lumdev | denoise | auto | err | api
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +68,15 @@ int main(int argc, char **argv)
       std::printf("\"lum_ncorr\":[");
       for (size_t i = 0; i < reg.lum_ncorr.size(); ++i) std::printf("%d%s", reg.lum_ncorr[i], i + 1 < reg.lum_ncorr.size() ? "," : "");
       std::printf("],");
+    } else if (mode == "denoise") {
+      // scan 0 plus far-away outliers (one per 40 points), then PointCloud::denoise(10, 2.5)
+      ScanCloud &pc = model.views[0];
+      const size_t n0 = pc.points.size();
+      for (size_t k = 0; k < n0 / 40; ++k) pc.points.push_back(PointXYZ(1000.f + 7.f * (float)k, -500.f, 2000.f + 3.f * (float)(k % 11)));
+      const size_t noise = pc.denoise(10, 2.5);
+      double sx = 0, sy = 0, sz = 0;
+      for (size_t i = 0; i < pc.points.size(); ++i) { sx += pc.points.points[i].x; sy += pc.points.points[i].y; sz += pc.points.points[i].z; }
+      std::printf("\"noise\":%zu,\"kept\":%zu,\"sum\":[%.17g,%.17g,%.17g],", noise, pc.points.size(), sx, sy, sz);
     } else if (mode == "auto") {
       reg.automaticRegistration(0, 1000, repeat, max_d, 50.0);
     } else if (mode == "err") {

@@ -107,6 +107,21 @@ def test_registration_lum_device_resident(driver, mvr, orc):
     assert_poses(out["poses"], [np.array(p).reshape(4, 4) for p in ref["poses"]], rot=2e-5, trans=2e-3)
 
 
+def test_scan_cloud_denoise(driver, mvr, orc):
+    """ScanCloud::denoise (point_cloud.cpp:423-465 through the shim) == the oracle on the same cloud."""
+    V, N = 2, 6000
+    out, _ = run(driver, "denoise", V, N, 4.0, 1, 3)
+    sp = mvr.synth_params(V, 3)
+    scan = mvr.synth_view(sp, 0, N)
+    extra = np.ones((N // 40, 4), np.float32)
+    k = np.arange(N // 40, dtype=np.float32)
+    extra[:, 0] = np.float32(1000.0) + np.float32(7.0) * k; extra[:, 1] = -500.0; extra[:, 2] = np.float32(2000.0) + np.float32(3.0) * (k.astype(np.int64) % 11).astype(np.float32)
+    pts = np.concatenate([scan, extra])
+    keep, _, _ = orc.denoise(pts, 10, 2.5)
+    assert out["kept"] == len(keep) and out["noise"] == len(pts) - len(keep) and out["noise"] >= N // 40
+    assert np.allclose(out["sum"], pts[keep, :3].astype(np.float64).sum(0), rtol=1e-12)
+
+
 def test_compute_error_pairs(driver, mvr, orc):
     """registrator.cpp:466-515: ring pairs + (0, V-1), reciprocal correspondences."""
     V, N, max_d = 12, 2500, 6.0

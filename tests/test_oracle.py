@@ -337,3 +337,51 @@ def test_multithreaded_correspondences_equal_single_thread(orc):
         for th in (1, 3, 8):
             b = orc.correspondences_mt(src, tgt, 0.8, th, reciprocal=rec)
             assert np.array_equal(a, b)
+
+
+def noisy_surface(rng, n, outliers, clusters=()):
+    """a dense sheet (one big component at r = 2.5), isolated outliers and a few small far-away clusters"""
+    sheet = np.c_[rng.uniform(0, 60, (n, 2)), 900 + rng.normal(0, 0.1, n)]
+    far = rng.uniform(-200, 200, (outliers, 3)) + [0, 0, 1500]
+    parts = [sheet, far]
+    for k, m in enumerate(clusters):
+        parts.append(rng.normal(0, 0.3, (m, 3)) + [300 + 40 * k, -100, 700])
+    p = np.concatenate(parts)
+    p = p[rng.permutation(len(p))]
+    out = np.ones((len(p), 4), np.float32); out[:, :3] = p
+    return out
+
+
+def test_denoise_equals_radius_graph_components_scipy(orc):
+    """The oracle's denoise against an independent construction: scipy's cKDTree.query_pairs(r) edges +
+    scipy.sparse.csgraph.connected_components, then the reference's rule (keep components >= threshold, ordered by
+    their smallest index, members ascending) -- and, on a small cloud, against the Delaunay construction itself
+    (scipy.spatial.Delaunay edges <= r), which is what the reference builds with CGAL."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(77)
+    for n, outliers, clusters, thr, r in ((4000, 60, (9, 10, 25), 10, 2.5), (1500, 10, (3, 12), 4, 1.0), (300, 5, (), 1, 2.5)):
+        pts = noisy_surface(rng, n, outliers, clusters)
+        keep, lab, ncomp = orc.denoise(pts, thr, r)
+        pairs = cKDTree(pts[:, :3].astype(np.float64)).query_pairs(r, output_type="ndarray")
+        d = np.sqrt(((pts[pairs[:, 0], :3].astype(np.float64) - pts[pairs[:, 1], :3].astype(np.float64)) ** 2).sum(1))
+        pairs = pairs[d <= r]
+        g = coo_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(len(pts), len(pts)))
+        nc, cl = connected_components(g, directed=False)
+        assert nc == ncomp
+        first = np.full(nc, len(pts)); np.minimum.at(first, cl, np.arange(len(pts)))
+        assert np.array_equal(lab, first[cl])                         # label = smallest index of the component
+        sizes = np.bincount(cl)
+        exp = np.array(sorted(np.nonzero(sizes[cl] >= thr)[0], key=lambda i: (first[cl[i]], i)), np.uint32)
+        assert np.array_equal(keep, exp)
+    # Delaunay edges <= r give the same components (EMST is a subgraph of the Delaunay triangulation)
+    pts = noisy_surface(rng, 800, 20, (6, 11))
+    keep, lab, ncomp = orc.denoise(pts, 10, 2.5)
+    tri = Delaunay(pts[:, :3].astype(np.float64))
+    e = np.concatenate([tri.simplices[:, [a, b]] for a in range(4) for b in range(a + 1, 4)])
+    d = np.sqrt(((pts[e[:, 0], :3].astype(np.float64) - pts[e[:, 1], :3].astype(np.float64)) ** 2).sum(1))
+    e = e[d <= 2.5]
+    nc, cl = connected_components(coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(len(pts), len(pts))), directed=False)
+    first = np.full(nc, len(pts)); np.minimum.at(first, cl, np.arange(len(pts)))
+    assert nc == ncomp and np.array_equal(lab, first[cl])

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""tools/denoise_bench.py -- PointCloud::denoise on one 200k-point scan + 2 % outliers: GPU (mvr_cloud_denoise) vs the
+CPU oracle, same input, same output (checked).  Prints one JSON line."""
+import importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+mvr = importlib.import_module("multi-view-registration_amd")
+import oracle as orc      # checker / CPU baseline only
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+rng = np.random.default_rng(43)
+sp = mvr.synth_params(12, 2)
+scan = mvr.synth_view(sp, 3, n)
+noise = np.ones((n // 50, 4), np.float32); noise[:, :3] = rng.uniform(-150, 150, (n // 50, 3)) + np.array(sp.pivot)
+pts = np.concatenate([scan, noise])[rng.permutation(n + n // 50)]
+with mvr.Context(0) as ctx:
+    times = []
+    for rep in range(6):
+        ctx.upload(0, pts); ctx.sync()
+        t0 = time.perf_counter()
+        keep, ncomp = ctx.denoise(0, 10, 2.5)
+        times.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    okeep, _, oncomp = orc.denoise(pts, 10, 2.5)
+    cpu = time.perf_counter() - t0
+    assert np.array_equal(keep, okeep) and ncomp == oncomp
+    print(json.dumps(dict(points=len(pts), kept=int(len(keep)), components=int(ncomp), gpu_ms=1e3 * float(np.median(times[1:])),
+                          gpu_ms_first_call=1e3 * times[0], cpu_oracle_ms=1e3 * cpu, points_per_s_gpu=len(pts) / float(np.median(times[1:])),
+                          note="GPU time includes 12 scratch hipMalloc/hipFree, two radix sorts, the union-find pass and the D2H of the kept index list")))
