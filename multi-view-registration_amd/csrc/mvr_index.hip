@@ -1,26 +1,18 @@
 // csrc/mvr_index.hip -- spatial index for the exact culled nearest-neighbour search (gfx950);
 // the search kernel itself lives in mvr_cull.hip.
 //
-// Same results as the brute-force kernel of mvr_nn.hip (bit-identical d2,
-// lowest ORIGINAL index on ties) with O(N * k) instead of O(N^2) distance
-// evaluations -- the GPU-native counterpart of the kd-tree the reference gets
-// from PCL/FLANN (tree_->nearestKSearch inside icp.align, registrator.cpp:569,
-// and inside determineReciprocalCorrespondences, :502/:649):
-//  * every cloud keeps a Morton-ordered copy of its points (w = bits of the
-//    original index) and one AABB per 256-point tile of that copy.  The order
-//    belongs to the point SET and is shared by all posed copies of a scan, so
-//    it is sorted once (hipCUB radix sort on 30-bit codes); after a rigid
-//    motion only coordinates and AABBs are refreshed.  The order affects speed
-//    only: AABBs are always computed from the current coordinates.
-//  * one WAVE is one worker: 64*Q Morton-consecutive queries in registers, a
-//    wave-private LDS buffer for the target tile, no workgroup barrier
-//    anywhere.  The wave first visits the tiles whose box overlaps its own
-//    query box, then every remaining tile whose box distance does not exceed
-//    the wave's current worst best-distance U (a __shfl wave max-reduction
-//    after every tile).  A tile is skipped only if lb*(1-1e-5) > U, so any
-//    point that could win or tie is still evaluated: results stay exact.
-//  * inside a tile the inner loop is the brute-force one (min3 tracking per
-//    32-target sub-tile, index recovered by one re-scan at the end).
+// The GPU-native counterpart of the kd-tree the reference gets from PCL/FLANN (tree_->nearestKSearch
+// inside icp.align, registrator.cpp:569, and inside determineReciprocalCorrespondences, :502/:649):
+//  * every cloud keeps a Hilbert-ordered copy of its points (w = bits of the original index).  The
+//    ORDER belongs to the point set and is shared by all posed copies of a scan, so it is built once
+//    (bbox -> 30-bit Hilbert codes -> hipCUB radix sort -> perm / inv);
+//  * three levels of AABBs over that order, always computed from the CURRENT coordinates (the order
+//    only affects speed): one box per 64-point cell (cbox, a 128-byte record per tile), one per
+//    256-point tile (tlo / thi), one per 64 consecutive tiles (sbox);
+//  * after a rigid motion only the sorted copy and the boxes are refreshed: two launches for all the
+//    views of a global iteration (refresh_sorted_kernel / super_box_kernel, blockIdx.y = cloud);
+//  * the reciprocal glue of the culled mode: flag matched targets in sorted space, ordered compaction
+//    (hipCUB DeviceSelect) into the query list of the reverse search.
 // Compiled with -ffp-contract=off.
 #include <hipcub/hipcub.hpp>
 
