@@ -145,7 +145,9 @@ float cap_from_max2(double max2)
 // indices in brute-force mode: either way the ranges [0,n) partition the
 // queries, and every per-pair sum is additive over such a partition).
 // Leaves keys[], slot[], rkeys[] ready for pass1.
-struct SearchPlan { const uint32_t *qperm = nullptr; const uint32_t *tinv = nullptr; };
+// qperm / tinv: the culled mode's orderings; slot / count: the brute-force mode's compacted reverse queries
+// (the culled mode searches the flagged targets in place: reverse keys are indexed by sorted target position)
+struct SearchPlan { const uint32_t *qperm = nullptr; const uint32_t *tinv = nullptr; const uint32_t *slot = nullptr; const uint32_t *count = nullptr; };
 
 // forward pass: keys[i] = (d2, LOCAL target index) of source query i (kKeyInit beyond the cap / no target)
 int search_forward(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool fma, double *evals, SearchPlan *plan)
@@ -161,7 +163,7 @@ int search_forward(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double 
     plan->qperm = src.order->perm;
     plan->tinv = tgt.order->inv;
     // keys are written (not min-combined) by exactly one wave per query
-    return launch_nn_cull(c, src, qb, qn, nullptr, nullptr, tgt, cap_from_max2(max2), fma, c->keys);
+    return launch_nn_cull(c, src, qb, qn, nullptr, tgt, cap_from_max2(max2), fma, c->keys);
   }
   if (int rc = launch_fill_u64(c, c->keys + qb, qn, kKeyInit)) return rc;
   if (int rc = launch_nn(c, src.pts, qb, qn, nullptr, nullptr, tgt.pts, nt, fma, c->keys)) return rc;
@@ -171,22 +173,24 @@ int search_forward(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double 
 
 // reciprocal pass on the keys in c->keys (from search_forward, or imported after a reduction over ranks):
 // the distinct matched targets are searched in the WHOLE source.  Leaves slot[], rkeys[] ready for pass1.
-int search_reciprocal(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool fma, const SearchPlan *plan)
+int search_reciprocal(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, double max_dist, bool fma, SearchPlan *plan)
 {
   const size_t ns = src.n, nt = tgt.n;
   const double max2 = max_dist * max_dist;
+  plan->slot = plan->count = nullptr;
   if (nt == 0 || qn == 0) return MVR_OK;
+  if (c->nn_mode != 0 && ns > 0) {
+    // matched targets are flagged in sorted space and searched IN PLACE (no compaction): rkeys[sorted position]
+    if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nt)) return rc;
+    if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
+    if (int rc = launch_flag_matched(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags)) return rc;
+    return launch_nn_cull(c, tgt, 0, nt, c->flags, src, cap_from_max2(max2), fma, c->rkeys);
+  }
   const size_t nl = std::min(qn, nt);
   if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
   if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
   if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
-  if (c->nn_mode != 0 && ns > 0) {
-    if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
-    if (int rc = launch_mark_sorted(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags, c->list, c->count,
-                                    c->slot)) return rc;
-    // queries = distinct matched targets (Hilbert order)
-    return launch_nn_cull(c, tgt, 0, nl, c->list, c->count, src, cap_from_max2(max2), fma, c->rkeys);
-  }
+  plan->slot = c->slot; plan->count = c->count;
   MVR_HIP_TRY(c, hipMemsetAsync(c->slot, 0xFF, nt * sizeof(uint32_t), c->stream));
   MVR_HIP_TRY(c, hipMemsetAsync(c->count, 0, sizeof(uint32_t), c->stream));
   if (int rc = launch_mark(c, c->keys, qb, qn, max2, c->slot, c->list, c->count)) return rc;
@@ -621,7 +625,7 @@ API int mvr_nn(mvr_ctx *ctx, int qs, int ts, int fma, uint32_t *idx, float *d2)
   if (c->nn_mode != 0 && t.n > 0) {
     if (int rc = ensure_index(c, q)) return rc;
     if (int rc = ensure_index(c, t)) return rc;
-    if (int rc = launch_nn_cull(c, q, 0, q.n, nullptr, nullptr, t, INFINITY, fma != 0, c->keys)) return rc;
+    if (int rc = launch_nn_cull(c, q, 0, q.n, nullptr, t, INFINITY, fma != 0, c->keys)) return rc;
   } else {
     if (int rc = launch_nn(c, q.pts, 0, q.n, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
   }
@@ -645,7 +649,7 @@ static int pair_common(Ctx *c, int ss, int ts, double max_dist, int reciprocal, 
 {
   Cloud &s = c->slots[ss], &t = c->slots[ts];
   if (int rc = run_search(c, s, t, qb, qn, max_dist, reciprocal != 0, fma != 0, evals, plan)) return rc;
-  return launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, c->count, plan->qperm, plan->tinv, qb, qn,
+  return launch_pass1(c, s.pts, t.pts, c->keys, c->rkeys, plan->slot, plan->count, plan->qperm, plan->tinv, qb, qn,
                       max_dist * max_dist, reciprocal != 0 && t.n > 0, c->match, c->moments);
 }
 
@@ -709,7 +713,7 @@ static int moments2_impl(Ctx *c, int ss, int ts, double max_dist, int reciprocal
   SearchPlan plan;
   Cloud &sc = c->slots[ss], &tc = c->slots[ts];
   if (int rc = run_search(c, sc, tc, qb, qn, max_dist, reciprocal != 0, fma != 0, nullptr, &plan)) return rc;
-  return launch_accept_moments2(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, plan.qperm, plan.tinv, qb, qn, max_dist * max_dist,
+  return launch_accept_moments2(c, s.pts, t.pts, c->keys, c->rkeys, plan.slot, plan.qperm, plan.tinv, qb, qn, max_dist * max_dist,
                                 reciprocal != 0 && t.n > 0, origin, dev_out);
 }
 
@@ -836,7 +840,7 @@ API int mvr_pair_moments2_from_keys(mvr_ctx *ctx, int ss, int ts, const long lon
   }
   if (int rc = launch_import_keys(c, dev_keys, s.n, seg_table(t), c->keys)) return rc;
   if (reciprocal && s.n > 0) { if (int rc = search_reciprocal(c, s, t, 0, s.n, max_dist, fma != 0, &plan)) return rc; }
-  return launch_accept_moments2(c, s.pts, t.pts, c->keys, c->rkeys, c->slot, plan.qperm, plan.tinv, 0, s.n, max_dist * max_dist,
+  return launch_accept_moments2(c, s.pts, t.pts, c->keys, c->rkeys, plan.slot, plan.qperm, plan.tinv, 0, s.n, max_dist * max_dist,
                                 reciprocal != 0 && t.n > 0, origin, dev_out);
 }
 
@@ -926,7 +930,7 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     double ev = 0.0;
     SearchPlan plan;
     if (int rc = run_search(c, cur, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev, &plan)) return rc;
-    if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, c->slot, c->count, plan.qperm, plan.tinv, 0, ns,
+    if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, plan.slot, plan.count, plan.qperm, plan.tinv, 0, ns,
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
     if (p->point_to_plane) {
@@ -1011,7 +1015,7 @@ API int mvr_fitness(mvr_ctx *ctx, int is, int ts, const float T[16], double max_
     if (int rc = ensure_index(c, tmp)) return rc;
     if (int rc = ensure_index(c, t)) return rc;
     if (!c->slots[is].order) c->slots[is].order = tmp.order;     // keep the sort for the next call
-    if (int rc = launch_nn_cull(c, tmp, 0, ns, nullptr, nullptr, t, cap_from_max2(max_range), fma != 0, c->keys)) return rc;
+    if (int rc = launch_nn_cull(c, tmp, 0, ns, nullptr, t, cap_from_max2(max_range), fma != 0, c->keys)) return rc;
   } else {
     if (int rc = launch_nn(c, tmp.pts, 0, ns, nullptr, nullptr, t.pts, t.n, fma != 0, c->keys)) return rc;
   }

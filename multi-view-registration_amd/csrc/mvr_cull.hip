@@ -110,8 +110,8 @@ __device__ __forceinline__ float lane_value(float v, int lane_uniform)     // v 
 
 template <bool FMA, int Q, int W>
 __device__ __forceinline__ void
-nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,
-               const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
+nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint8_t *__restrict__ qflags,
+               const float4 *__restrict__ ts, uint32_t nt,
                const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
                const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys,
                unsigned long long *__restrict__ evals)
@@ -145,7 +145,11 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   if (evals && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(evals + kEvalRegion + 15, st_rt0);
 #endif
   float4 *T = lds[wv];
-  const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
+  // Queries = sorted positions [q_begin, q_begin + q_count) of the query cloud.  With qflags only the positions
+  // whose flag is set are real queries -- the reverse search runs over the matched targets IN PLACE, no compaction:
+  // matched targets cluster, so most blocks are either well filled or leave at once.  Key slot: the query's original
+  // index (w) without flags, its sorted position with flags.
+  const uint32_t nq = q_count;
   const uint32_t b_begin = blockIdx.x * NB;
   if (b_begin >= nq) return;                      // block-uniform
 
@@ -170,20 +174,43 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   };
   load_block_boxes(0);
 
-  // query q of this lane = position b_begin + 16 q + l16 (the same in all 4 groups);
-  // positions past the end repeat the block's first query (a duplicate changes no bound)
+  // query q of this lane = position b_begin + 16 q + l16 (the same in all 4 groups); slots that hold no real
+  // query (past the end, or not flagged) repeat a real one of the block (a duplicate changes no bound)
   float qx[NQ], qy[NQ], qz[NQ], best[NQ];
   uint32_t bsub[NQ];
+  bool real[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const uint32_t pos = b_begin + q * 16 + l16;
+    real[q] = pos < nq && (!qflags || qflags[q_begin + pos] != 0);
+    const float4 p = qs[q_begin + (pos < nq ? pos : b_begin)];
+    qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
+    best[q] = __builtin_inff(); bsub[q] = kNone;
+  }
+  uint32_t nvalid = NB;
+  if (qflags || b_begin + NB > nq) {             // block-uniform
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    bool have = false;
+    nvalid = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const unsigned long long m = __ballot(real[q]) & 0xFFFFull;       // every lane group holds the same slots
+      nvalid += (uint32_t)__popcll(m);
+      if (!have && m) {
+        const int l = __ffsll((long long)m) - 1;
+        rx = lane_value(qx[q], l); ry = lane_value(qy[q], l); rz = lane_value(qz[q], l);
+        have = true;
+      }
+    }
+    if (!have) return;                            // nothing to search here: all waves of the block agree, before the barrier
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) if (!real[q]) { qx[q] = rx; qy[q] = ry; qz[q] = rz; }
+  }
   float qlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, qhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    uint32_t pos = b_begin + q * 16 + l16;
-    pos = pos < nq ? pos : b_begin;
-    const float4 p = qs[qlist ? qlist[pos] : (q_begin + pos)];
-    qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
-    best[q] = __builtin_inff(); bsub[q] = kNone;
-    qlo[0] = fminf(qlo[0], p.x); qlo[1] = fminf(qlo[1], p.y); qlo[2] = fminf(qlo[2], p.z);
-    qhi[0] = fmaxf(qhi[0], p.x); qhi[1] = fmaxf(qhi[1], p.y); qhi[2] = fmaxf(qhi[2], p.z);
+    qlo[0] = fminf(qlo[0], qx[q]); qlo[1] = fminf(qlo[1], qy[q]); qlo[2] = fminf(qlo[2], qz[q]);
+    qhi[0] = fmaxf(qhi[0], qx[q]); qhi[1] = fmaxf(qhi[1], qy[q]); qhi[2] = fmaxf(qhi[2], qz[q]);
   }
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1)
@@ -498,7 +525,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const uint32_t pos = b_begin + (uint32_t)((wv + j * W) * 16 + l16), rpos = pos < nq ? pos : b_begin;
-    fq[j] = qs[qlist ? qlist[rpos] : (q_begin + rpos)];         // this query's coordinates (and its original index)
+    fq[j] = qs[q_begin + rpos];                                 // this query's coordinates (and its original index)
   }
   __syncthreads();
   nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [4 W][NB]: (d2 bits, sub-tile)
@@ -561,15 +588,14 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       }
       o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
       o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
-      if (g == 0 && pos < nq) {
-        const uint32_t ord = qlist ? pos : __float_as_uint(fq[j].w);     // key slot: list position / original index
+      if (g == 0 && pos < nq && (!qflags || qflags[q_begin + pos] != 0)) {
+        const uint32_t ord = qflags ? pos : __float_as_uint(fq[j].w);    // key slot: sorted position / original index
         keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
       }
     }
   }
   MVR_MARK(7);
   if (evals && lane == 0) {
-    const uint32_t nvalid = min(nq - b_begin, (uint32_t)NB);
     const unsigned long long e = (unsigned long long)cells_done * 64ull * nvalid;
     // sharded counters: one 128-byte line per shard, or thousands of waves serialise on one address
     unsigned long long *a = evals + (size_t)(blockIdx.x & (kEvalShards - 1)) * kEvalStride;
@@ -627,53 +653,77 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 #else
 #define MVR_CULL_WAVES_ATTR MVR_CULL_WAVES
 #endif
-#define MVR_CULL_ARGS                                                                                                  \
-  const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint32_t *__restrict__ qlist,               \
-      const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt, const float4 *__restrict__ tlo, \
-      const float4 *__restrict__ thi, const float4 *__restrict__ cbox, const float4 *__restrict__ sbox,                \
-      uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, unsigned long long *__restrict__ evals
+// blockIdx.y = scan pair: the searches of all pairs of a global iteration are ONE launch (the arguments of
+// up to kBatchPairs pairs travel by value), so the chip is filled by the union of their query sets and the
+// tail of one pair's search is covered by the others.
 template <bool FMA, int Q, int W>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? MVR_CULL_WAVES : 3))) nn_cull_kernel(MVR_CULL_ARGS)
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? MVR_CULL_WAVES : 3)))
+nn_cull_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
 {
-  nn_cull_body<FMA, Q, W>(qs, q_begin, q_count, qlist, qcount, ts, nt, tlo, thi, cbox, sbox, n_tiles, cap2, keys, evals);
+  const CullPair &a = batch.p[blockIdx.y];
+  nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
+                          a.keys, evals);
 }
-#undef MVR_CULL_ARGS
 
 }  // namespace
 
-int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint32_t *qlist,
-                   const uint32_t *qcount, const Cloud &t, float cap2, bool fma, nnkey_t *keys)
+int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma)
+{
+  for (int base = 0; base < n_pairs; base += kBatchPairs) {
+    CullBatch batch;
+    const int m = std::min(kBatchPairs, n_pairs - base);
+    size_t qmax = 0; double upper = 0.0;
+    for (int k = 0; k < kBatchPairs; ++k) {
+      batch.p[k] = k < m ? pairs[base + k] : CullPair{};
+      if (k < m && batch.p[k].nt == 0) batch.p[k].q_count = 0;
+      qmax = std::max(qmax, (size_t)batch.p[k].q_count);
+      upper += (double)batch.p[k].q_count * (double)batch.p[k].nt;
+    }
+    batch.cap2 = cap2;
+    if (qmax == 0) continue;
+    // measured (tools/cull_sweep.sh): the kernel is bound by its longest serial tile chain, so small query
+    // sets win until there are far more sets than the chip holds at once
+    int Q = (qmax <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
+    if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
+    const int W = (c->cull_w == 1 || c->cull_w == 4) ? c->cull_w : 2;          // waves sharing one query set (measured best: 2)
+    const dim3 grid((unsigned)((qmax + 64 * Q - 1) / (64 * Q)), (unsigned)m);   // one block (W cooperating waves) per query set
+    // region A (evaluations) is only read back by the profiler: per launch at level 1 (cleared here, copied out
+    // after the launch), as a running total at level 2 (cleared when profiling starts, read once at the end)
+    const bool per_launch = c->prof && !c->prof_totals;
+    if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+#ifdef MVR_TRACE
+    MVR_HIP_TRY(c, hipMemsetAsync(c->evals + 2 * kEvalRegion, 0, kTraceRec * kTraceBlocks * sizeof(unsigned long long), c->stream));
+#endif
+    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0,
+                 per_launch ? upper : 0.0, per_launch ? kEvalShards : 0);
+#define MVR_LAUNCH_CULL(F, QQ, WW) hipLaunchKernelGGL((nn_cull_kernel<F, QQ, WW>), grid, dim3(64 * WW), 0, c->stream, batch, c->evals)
+#define MVR_LAUNCH_CULL_W(F, QQ)                                                                  \
+  do { if (W == 1) MVR_LAUNCH_CULL(F, QQ, 1); else if (W == 2) MVR_LAUNCH_CULL(F, QQ, 2); else MVR_LAUNCH_CULL(F, QQ, 4); } while (0)
+    if (fma) { if (Q == 2) MVR_LAUNCH_CULL_W(true, 2); else MVR_LAUNCH_CULL_W(true, 1); }
+    else     { if (Q == 2) MVR_LAUNCH_CULL_W(false, 2); else MVR_LAUNCH_CULL_W(false, 1); }
+#undef MVR_LAUNCH_CULL_W
+#undef MVR_LAUNCH_CULL
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
+}
+
+int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
+                   bool fma, nnkey_t *keys)
 {
   if (q_count == 0 || t.n == 0) return MVR_OK;
   if (q.n > 0xFFFFFFF0ull || t.n > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
-  const uint32_t n_tiles = (uint32_t)((t.n + kCullTile - 1) / kCullTile);
-  // measured (tools/cull_sweep.sh): the kernel is bound by its longest serial tile chain, so small query
-  // sets win until there are far more sets than the chip holds at once
-  int Q = (q_count <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
-  if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
-  const int W = (c->cull_w == 1 || c->cull_w == 4) ? c->cull_w : 2;          // waves sharing one query set (measured best: 2)
-  const unsigned blocks = (unsigned)((q_count + 64 * Q - 1) / (64 * Q));   // one block (W cooperating waves) per query set
-  // region A (evaluations) is only read back by the profiler: per launch at level 1 (cleared here, copied out
-  // after the launch), as a running total at level 2 (cleared when profiling starts, read once at the end)
-  const bool per_launch = c->prof && !c->prof_totals;
-  if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
-#ifdef MVR_TRACE
-  MVR_HIP_TRY(c, hipMemsetAsync(c->evals + 2 * kEvalRegion, 0, kTraceRec * kTraceBlocks * sizeof(unsigned long long), c->stream));
-#endif
-  ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0,
-               per_launch ? (double)q_count * (double)t.n : 0.0, per_launch ? kEvalShards : 0);
-#define MVR_LAUNCH_CULL(F, QQ, WW)                                                                                       \
-  hipLaunchKernelGGL((nn_cull_kernel<F, QQ, WW>), dim3(blocks), dim3(64 * WW), 0, c->stream, q.sorted, (uint32_t)q_begin, \
-                     (uint32_t)q_count, qlist, qcount, t.sorted, (uint32_t)t.n, t.tlo, t.thi, t.cbox, t.sbox, n_tiles,   \
-                     cap2, keys, c->evals)
-#define MVR_LAUNCH_CULL_W(F, QQ)                                                                  \
-  do { if (W == 1) MVR_LAUNCH_CULL(F, QQ, 1); else if (W == 2) MVR_LAUNCH_CULL(F, QQ, 2); else MVR_LAUNCH_CULL(F, QQ, 4); } while (0)
-  if (fma) { if (Q == 2) MVR_LAUNCH_CULL_W(true, 2); else MVR_LAUNCH_CULL_W(true, 1); }
-  else     { if (Q == 2) MVR_LAUNCH_CULL_W(false, 2); else MVR_LAUNCH_CULL_W(false, 1); }
-#undef MVR_LAUNCH_CULL_W
-#undef MVR_LAUNCH_CULL
-  MVR_HIP_TRY(c, hipGetLastError());
-  return MVR_OK;
+  const CullPair one = make_cull_pair(q, q_begin, q_count, qflags, t, keys);
+  return launch_nn_cull_batch(c, &one, 1, cap2, fma);
+}
+
+CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys)
+{
+  CullPair p;
+  p.qs = q.sorted; p.ts = t.sorted; p.tlo = t.tlo; p.thi = t.thi; p.cbox = t.cbox; p.sbox = t.sbox; p.qflags = qflags; p.keys = keys;
+  p.q_begin = (uint32_t)q_begin; p.q_count = (uint32_t)q_count; p.nt = (uint32_t)t.n;
+  p.n_tiles = (uint32_t)((t.n + kCullTile - 1) / kCullTile);
+  return p;
 }
 
 }  // namespace mvr

@@ -214,13 +214,6 @@ __global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint
   flags[tinv[j]] = 1;          // same value from every writer
 }
 
-__global__ void scatter_slot_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, size_t cap,
-                                    uint32_t *__restrict__ slot)
-{
-  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < cap && p < *count) slot[list[p]] = (uint32_t)p;
-}
-
 int ensure_cub(Ctx *c, size_t bytes)
 {
   if (c->cub_cap >= bytes) return MVR_OK;
@@ -376,23 +369,14 @@ int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
   return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
 }
 
-int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
-                       const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *slot)
+int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
+                        const uint32_t *tinv, size_t nt, uint8_t *flags)
 {
   if (q_count == 0 || nt == 0) return MVR_OK;
-  ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count + 2.0 * (double)nt);
+  ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count + 1.0 * (double)nt);
   MVR_HIP_TRY(c, hipMemsetAsync(flags, 0, nt, c->stream));
   hipLaunchKernelGGL(flag_matched_kernel, dim3((unsigned)((q_count + 255) / 256)), dim3(256), 0, c->stream, keys, qperm,
                      q_begin, q_count, max2, tinv, flags);
-  // ordered compaction: list = sorted positions of the matched targets, in Morton order
-  hipcub::CountingInputIterator<uint32_t> it(0);
-  size_t bytes = 0;
-  MVR_HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, it, flags, list, count, (int)nt, c->stream));
-  if (int rc = ensure_cub(c, bytes)) return rc;
-  MVR_HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->cub_tmp, bytes, it, flags, list, count, (int)nt, c->stream));
-  const size_t cap = std::min(q_count, nt);
-  hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream, list, count, cap,
-                     slot);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }

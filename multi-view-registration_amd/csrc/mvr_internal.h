@@ -194,16 +194,25 @@ int launch_nn(Ctx *c, const float4 *q, size_t q_begin, size_t q_count, const uin
 int ensure_index(Ctx *c, Cloud &cl);
 void new_point_set(Ctx *c, Cloud &cl);                 // after upload / append / clear
 void inherit_point_set(Cloud &dst, const Cloud &src);  // after copy / transform
-// culled exact NN.  Queries: sorted positions [q_begin, q_begin+q_count) of the
-// query cloud (key ordinal = ORIGINAL index of the query), or sorted positions
-// qlist[p] for p < *qcount (key ordinal = p).  cap2: distances above it are not
-// needed (+inf = unbounded).
-int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint32_t *qlist,
-                   const uint32_t *qcount, const Cloud &t, float cap2, bool fma, nnkey_t *keys);
-// culled-mode reciprocal glue: flag matched targets (sorted space), ordered list, slot positions
-int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count,
-                       double max2, const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list,
-                       uint32_t *count, uint32_t *slot);
+// culled exact NN.  Queries: sorted positions [q_begin, q_begin+q_count) of the query cloud; key ordinal = ORIGINAL
+// index of the query, or -- with qflags (one byte per sorted position, only flagged positions are searched) -- the
+// sorted position.  cap2: distances above it are not needed (+inf = unbounded).  The batch form runs the searches
+// of several scan pairs in ONE launch (blockIdx.y = pair).
+constexpr int kBatchPairs = 16;
+struct CullPair {
+  const float4 *qs = nullptr, *ts = nullptr, *tlo = nullptr, *thi = nullptr, *cbox = nullptr, *sbox = nullptr;
+  const uint8_t *qflags = nullptr;
+  nnkey_t *keys = nullptr;
+  uint32_t q_begin = 0, q_count = 0, nt = 0, n_tiles = 0;
+};
+struct CullBatch { CullPair p[kBatchPairs]; float cap2; };
+CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys);
+int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);
+int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
+                   bool fma, nnkey_t *keys);
+// culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)
+int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
+                        const uint32_t *tinv, size_t nt, uint8_t *flags);
 
 // PointCloud::denoise (mvr_denoise.hip): the cloud is replaced by its kept points, in the reference's output order
 int denoise_cloud(Ctx *c, Cloud &cl, int segment_threshold, double triangle_length, size_t *n_kept, size_t *n_components,

@@ -236,7 +236,8 @@ pass1_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, con
     bool ok = (j != kNone) && !((double)d2 > max2);
     if (ok && reciprocal) {
       // App. A.2: NN of t_j in the source must be i itself, within max_dist
-      const nnkey_t rk = rkeys[slot[tinv ? tinv[j] : j]];
+      const uint32_t tj = tinv ? tinv[j] : j;
+      const nnkey_t rk = rkeys[slot ? slot[tj] : tj];        // compacted list (brute force) or in place (culled)
       const float dr = __uint_as_float((uint32_t)(rk >> 32));
       ok = ((uint32_t)rk == (uint32_t)i) && !((double)dr > max2);
     }
@@ -358,7 +359,8 @@ accept_moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict_
     const float d2 = __uint_as_float((uint32_t)(key >> 32));
     bool ok = (j != kNone) && !((double)d2 > max2);
     if (ok && reciprocal) {
-      const nnkey_t rk = rkeys[slot[tinv ? tinv[j] : j]];
+      const uint32_t tj = tinv ? tinv[j] : j;
+      const nnkey_t rk = rkeys[slot ? slot[tj] : tj];        // compacted list (brute force) or in place (culled)
       const float dr = __uint_as_float((uint32_t)(rk >> 32));
       ok = ((uint32_t)rk == (uint32_t)i) && !((double)dr > max2);
     }
