@@ -269,6 +269,7 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   if (const char *m = std::getenv("MVR_NN_MODE")) c->nn_mode = std::atoi(m);   // 0 brute force, 1 culled (default)
   if (const char *m = std::getenv("MVR_CULL_Q")) c->cull_q = std::atoi(m);     // 64-query groups per set: 1, 2 (0 = auto)
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
+  if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
@@ -307,7 +308,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   for (auto &s : c->slots) cloud_free(s);
   c->orders.clear();
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bflags, c->bpartials};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -757,6 +758,62 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   return MVR_OK;
 }
 
+// All scan pairs of a global pass with ONE launch per stage (culled mode): forward searches, flagging of the
+// matched targets, reverse searches, filter + raw moments, final sums -- 6 launches for V pairs instead of ~10 V
+// on worker streams.  The pairs of one launch fill the chip together, so the tail of one pair's search is covered
+// by the others.  Same results as the one-pair calls, bit for bit.
+static int pair_batch_fused(Ctx *c, int n_pairs, const int *src, const int *dst, double max_dist, int reciprocal, int fma,
+                            const size_t *q_begin, const size_t *q_count, const double origin[3], double *table)
+{
+  std::vector<size_t> off_s((size_t)n_pairs + 1, 0), off_t((size_t)n_pairs + 1, 0), off_p((size_t)n_pairs + 1, 0), qb((size_t)n_pairs), qn((size_t)n_pairs);
+  for (int k = 0; k < n_pairs; ++k) {
+    const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
+    if (s.n > 0xFFFFFFF0ull || t.n > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+    size_t b = q_begin ? q_begin[k] : 0, n = q_count ? q_count[k] : s.n;
+    if (b > s.n) b = s.n;
+    if (n > s.n - b) n = s.n - b;
+    if (t.n == 0) n = 0;
+    qb[k] = b; qn[k] = n;
+    off_s[k + 1] = off_s[k] + s.n; off_t[k + 1] = off_t[k] + t.n;
+    off_p[k + 1] = off_p[k] + (size_t)reduce_blocks_for(c, n) * 29;
+  }
+  if (int rc = ensure(c, c->bkeys, c->bkeys_cap, off_s[n_pairs])) return rc;
+  if (int rc = ensure(c, c->brkeys, c->brkeys_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(c, c->bflags, c->bflags_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(c, c->bpartials, c->bpartials_cap, off_p[n_pairs])) return rc;
+  const double max2 = max_dist * max_dist;
+  const float cap2 = cap_from_max2(max2);
+  std::vector<CullPair> fwd((size_t)n_pairs), rev((size_t)n_pairs);
+  for (int k = 0; k < n_pairs; ++k) {
+    const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
+    fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, c->bkeys + off_s[k]);
+    rev[k] = make_cull_pair(t, 0, qn[k] ? t.n : 0, c->bflags + off_t[k], s, c->brkeys + off_t[k]);
+  }
+  if (int rc = launch_nn_cull_batch(c, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+  const bool recip = reciprocal != 0;
+  if (recip && off_t[n_pairs]) MVR_HIP_TRY(c, hipMemsetAsync(c->bflags, 0, off_t[n_pairs], c->stream));
+  for (int base = 0; base < n_pairs; base += kBatchPairs) {
+    const int m = std::min(kBatchPairs, n_pairs - base);
+    GlueBatch gb;
+    gb.max2 = max2; gb.reciprocal = recip ? 1 : 0;
+    for (int k = 0; k < 3; ++k) gb.origin[k] = origin[k];
+    for (int j = 0; j < m; ++j) {
+      const int k = base + j;
+      const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
+      GluePair &g = gb.p[j];
+      g.src = s.pts; g.tgt = t.pts; g.keys = c->bkeys + off_s[k]; g.rkeys = c->brkeys + off_t[k];
+      g.qperm = (s.order && qn[k]) ? s.order->perm : nullptr; g.tinv = (t.order && qn[k]) ? t.order->inv : nullptr;
+      g.flags = c->bflags + off_t[k];
+      g.partials = c->bpartials + off_p[k]; g.out = table + (size_t)k * 32;
+      g.q_begin = qb[k]; g.q_count = qn[k]; g.blocks = reduce_blocks_for(c, qn[k]);
+    }
+    if (recip) { if (int rc = launch_flag_matched_batch(c, gb, m)) return rc; }
+    if (recip) { if (int rc = launch_nn_cull_batch(c, rev.data() + base, m, cap2, fma != 0)) return rc; }
+    if (int rc = launch_accept_moments2_batch(c, gb, m)) return rc;
+  }
+  return MVR_OK;
+}
+
 API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const int *dst, double max_dist,
                                 int reciprocal, int fma, const size_t *q_begin, const size_t *q_count,
                                 const double origin[3], mvr_pair_moments2_t *out, double *dev_out)
@@ -777,6 +834,16 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     std::vector<Cloud *> used;
     for (int k = 0; k < n_pairs; ++k) { used.push_back(&c->slots[src[k]]); used.push_back(&c->slots[dst[k]]); }
     if (int rc = ensure_index_batch(c, used.data(), (int)used.size())) return rc;      // one refresh launch for all views
+  }
+  if (c->nn_mode != 0 && c->pair_fused) {
+    if (int rc = pair_batch_fused(c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
+    if (out) {
+      std::vector<double> h((size_t)n_pairs * 32);
+      MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (int k = 0; k < n_pairs; ++k) std::memcpy(&out[k], &h[(size_t)k * 32], sizeof(mvr_pair_moments2_t));
+    }
+    return MVR_OK;
   }
   if (!c->ev_fork) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   MVR_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
@@ -1037,6 +1104,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "nn_mode")) c->nn_mode = value;
   else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
+  else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
   else return MVR_E_ARG;
   return MVR_OK;

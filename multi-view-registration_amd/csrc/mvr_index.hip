@@ -214,6 +214,20 @@ __global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint
   flags[tinv[j]] = 1;          // same value from every writer
 }
 
+__global__ void flag_matched_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.y];
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.q_count) return;
+  const size_t i = a.qperm[a.q_begin + k];
+  const nnkey_t key = a.keys[i];
+  const uint32_t j = (uint32_t)key;
+  if (j == kNone) return;
+  const float d2 = __uint_as_float((uint32_t)(key >> 32));
+  if ((double)d2 > b.max2) return;
+  a.flags[a.tinv[j]] = 1;
+}
+
 int ensure_cub(Ctx *c, size_t bytes)
 {
   if (c->cub_cap >= bytes) return MVR_OK;
@@ -367,6 +381,17 @@ int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
     if (stale) todo.push_back(cl);
   }
   return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
+}
+
+int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs)
+{
+  size_t qmax = 0; double work = 0.0;
+  for (int k = 0; k < n_pairs; ++k) { qmax = std::max(qmax, (size_t)b.p[k].q_count); work += 16.0 * (double)b.p[k].q_count; }
+  if (qmax == 0) return MVR_OK;
+  ProfScope ps(c, MVR_K_GLUE, work);
+  hipLaunchKernelGGL(flag_matched_batch_kernel, dim3((unsigned)((qmax + 255) / 256), (unsigned)n_pairs), dim3(256), 0, c->stream, b);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
 }
 
 int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,

@@ -121,6 +121,12 @@ struct Ctx {
   Ctx *parent = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *batch_table = nullptr; size_t batch_cap = 0;   // [pairs][32] staging of mvr_pair_moments2_batch
+  // workspace of the fused batch (culled mode): forward keys of all pairs, reverse keys + flags, per-pair partial rows
+  nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
+  nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
+  uint8_t *bflags = nullptr; size_t bflags_cap = 0;
+  double *bpartials = nullptr; size_t bpartials_cap = 0;
+  int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
   // instrumentation
   bool prof = false;
   unsigned prof_mask = ~0u;                           // families that are timed (bit f = family f)
@@ -210,6 +216,22 @@ CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const ui
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
                    bool fma, nnkey_t *keys);
+// one scan pair of a batched global pass (mvr_pair_moments2_batch, culled mode): everything the glue and the
+// reduction kernels need, by value (blockIdx.y = pair)
+struct GluePair {
+  const float4 *src = nullptr, *tgt = nullptr;            // original-order points
+  const nnkey_t *keys = nullptr, *rkeys = nullptr;        // forward keys [ns] (by original index), reverse keys [nt] (by sorted position)
+  const uint32_t *qperm = nullptr, *tinv = nullptr;
+  uint8_t *flags = nullptr;                               // [nt], sorted target space
+  double *partials = nullptr, *out = nullptr;             // [blocks][29] scratch, 32 doubles result
+  unsigned long long q_begin = 0, q_count = 0;
+  int blocks = 0, pad = 0;
+};
+struct GlueBatch { GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal; };
+int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);
+int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs);
+int reduce_blocks_for(const Ctx *c, size_t n);
+
 // culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)
 int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                         const uint32_t *tinv, size_t nt, uint8_t *flags);

@@ -16,6 +16,8 @@ namespace mvr {
 
 namespace {
 
+struct Vec3d { double x, y, z; };
+
 constexpr int kRT = 256;          // threads per reduction block
 constexpr int kMaxBlocks = 1024;  // partial rows
 
@@ -27,6 +29,25 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // block-wide sums of K per-thread doubles -> row `blockIdx.x` of partials
+template <int K>
+__device__ __forceinline__ void block_partials_at(const double (&acc)[K], double *__restrict__ partials, unsigned row)
+{
+  __shared__ double lds[kRT / 64][K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double s = wave_sum(acc[k]);
+    if (lane == 0) lds[wave][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double s = lds[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kRT / 64; ++w) s += lds[w][threadIdx.x];
+    partials[(size_t)row * K + threadIdx.x] = s;
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void block_partials(const double (&acc)[K], double *__restrict__ partials)
 {
@@ -308,7 +329,6 @@ __global__ void __launch_bounds__(kRT) pass2_final_kernel(const double *__restri
 
 // -------------------------------------------------------------- K8 moments2
 // 28 sums about `origin`: n, p(3), q(3), pp(6), qq(6), pq(9)
-struct Vec3d { double x, y, z; };
 
 __global__ void __launch_bounds__(kRT)
 moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const int32_t *__restrict__ match,
@@ -342,17 +362,19 @@ moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, 
 // K5 + K8 in one pass for the global mode: the reciprocal filter of pass1_kernel and the sums of
 // moments2_kernel (same acceptance, same accumulation order, so the same bits), without the centroid
 // reduction, its final kernel and the match[] round trip that only the two-pass covariance needs.
-__global__ void __launch_bounds__(kRT)
-accept_moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const nnkey_t *__restrict__ keys,
-                       const nnkey_t *__restrict__ rkeys, const uint32_t *__restrict__ slot, const uint32_t *__restrict__ qperm,
-                       const uint32_t *__restrict__ tinv, size_t q_begin, size_t q_count, double max2, int reciprocal, Vec3d o,
-                       double *__restrict__ partials)
+template <class Dummy = void>
+__device__ __forceinline__ void accept_moments2_body(const float4 *__restrict__ src, const float4 *__restrict__ tgt,
+                                                     const nnkey_t *__restrict__ keys, const nnkey_t *__restrict__ rkeys,
+                                                     const uint32_t *__restrict__ slot, const uint32_t *__restrict__ qperm,
+                                                     const uint32_t *__restrict__ tinv, size_t q_begin, size_t q_count, double max2,
+                                                     int reciprocal, Vec3d o, unsigned block, unsigned n_blocks,
+                                                     double *__restrict__ partials)
 {
   double acc[29];
 #pragma unroll
   for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q_count; k += stride) {
+  const size_t stride = (size_t)n_blocks * blockDim.x;
+  for (size_t k = (size_t)block * blockDim.x + threadIdx.x; k < q_count; k += stride) {
     const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
     const nnkey_t key = keys[i];
     const uint32_t j = (uint32_t)key;
@@ -378,7 +400,26 @@ accept_moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict_
     acc[25] += pz * qx; acc[26] += pz * qy; acc[27] += pz * qz;
     acc[28] += (double)d2;
   }
-  block_partials<29>(acc, partials);
+  block_partials_at<29>(acc, partials, block);
+}
+
+__global__ void __launch_bounds__(kRT)
+accept_moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, const nnkey_t *__restrict__ keys,
+                       const nnkey_t *__restrict__ rkeys, const uint32_t *__restrict__ slot, const uint32_t *__restrict__ qperm,
+                       const uint32_t *__restrict__ tinv, size_t q_begin, size_t q_count, double max2, int reciprocal, Vec3d o,
+                       double *__restrict__ partials)
+{
+  accept_moments2_body(src, tgt, keys, rkeys, slot, qperm, tinv, q_begin, q_count, max2, reciprocal, o, blockIdx.x, gridDim.x, partials);
+}
+
+// the same for all scan pairs of a global pass in one launch (blockIdx.y = pair); a pair uses its OWN number of
+// blocks as the grid stride, so its sums are accumulated in exactly the order of the one-pair launch
+__global__ void __launch_bounds__(kRT) accept_moments2_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.y];
+  if ((int)blockIdx.x >= a.blocks) return;
+  accept_moments2_body(a.src, a.tgt, a.keys, a.rkeys, nullptr, a.qperm, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal,
+                       Vec3d{b.origin[0], b.origin[1], b.origin[2]}, blockIdx.x, (unsigned)a.blocks, a.partials);
 }
 
 // out (32 doubles): [0] n, [1..3] origin, [4..6] sp, [7..9] sq, [10..15] spp, [16..21] sqq, [22..30] spq, [31] sum d2 (or 0)
@@ -392,6 +433,19 @@ __global__ void __launch_bounds__(kRT) moments2_final_kernel(const double *__res
     out[0] = s[0]; out[1] = o.x; out[2] = o.y; out[3] = o.z;
     for (int k = 1; k < 28; ++k) out[3 + k] = s[k];
     out[31] = s[28];
+  }
+}
+
+__global__ void __launch_bounds__(kRT) moments2_final_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.x];
+  __shared__ double lds[29];
+  double s[29];
+  sum_rows<29>(a.partials, a.blocks, s, lds);
+  if (threadIdx.x == 0) {
+    a.out[0] = s[0]; a.out[1] = b.origin[0]; a.out[2] = b.origin[1]; a.out[3] = b.origin[2];
+    for (int k = 1; k < 28; ++k) a.out[3 + k] = s[k];
+    a.out[31] = s[28];
   }
 }
 
@@ -655,6 +709,20 @@ int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const n
   hipLaunchKernelGGL(accept_moments2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, keys, rkeys, slot, qperm, tinv,
                      q_begin, q_count, max2, reciprocal ? 1 : 0, o, c->partials);
   hipLaunchKernelGGL(moments2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, o, out);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int reduce_blocks_for(const Ctx *c, size_t n) { return reduce_blocks(c, n); }
+
+int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs)
+{
+  int bmax = 0; double work = 0.0;
+  for (int k = 0; k < n_pairs; ++k) { bmax = std::max(bmax, b.p[k].blocks); work += 40.0 * (double)b.p[k].q_count; }
+  if (bmax == 0) return MVR_OK;
+  ProfScope ps(c, MVR_K_REDUCE, work);
+  hipLaunchKernelGGL(accept_moments2_batch_kernel, dim3((unsigned)bmax, (unsigned)n_pairs), dim3(kRT), 0, c->stream, b);
+  hipLaunchKernelGGL(moments2_final_batch_kernel, dim3((unsigned)n_pairs), dim3(kRT), 0, c->stream, b);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
