@@ -185,9 +185,12 @@ int  mvr_pair_moments2_dev(mvr_ctx *ctx, int src_slot, int tgt_slot, double max_
 /* The whole edge list of one global iteration in one call (the `for` loops over
  * scan pairs of registrator.cpp:482-502 and :640-651): pair k = (src[k], dst[k])
  * with query range q_begin[k], q_count[k] (null arrays: all queries).  The pairs
- * are independent, so they run on `pair_streams` worker HIP streams (mvr_ctx_tune,
- * default 6) forked from and joined back into the context's stream: the tail of
- * one pair's search overlaps the next pair's kernels.  Results are identical to
+ * are independent: with the culled search every stage (forward searches, flagging
+ * of matched targets, reverse searches, filter + raw moments, final sums) is ONE
+ * launch for all pairs (blockIdx.y = pair), six launches in all, so the pairs fill
+ * the chip together; with the brute-force search (or pair_fused = 0) each pair runs
+ * on one of `pair_streams` worker HIP streams forked from and joined back into the
+ * context's stream (mvr_ctx_tune).  Results are identical to
  * n_pairs calls of mvr_pair_moments2.  out (host, [n_pairs]) and/or dev_out
  * (device, [n_pairs][32] doubles, no host synchronisation) receive the sums. */
 int  mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src_slots, const int *tgt_slots,
@@ -281,8 +284,10 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_CO
  * brute-force launch shape: "nn_q" (queries per lane: 2,4,6,8), "nn_sub"
  * (min-tracking sub-tile: 16,32,64), "nn_blocks_per_cu" (1..5); culled kernel:
  * "cull_q" (64-query groups per set: 1,2; 0 = auto), "cull_w" (waves sharing one
- * query set: 1,2,4; also MVR_CULL_W); "pair_streams" (worker streams of
- * mvr_pair_moments2_batch, 1..16; also MVR_PAIR_STREAMS).  Results never depend on them. */
+ * query set: 1,2,4; 0 = by launch size; also MVR_CULL_W); "pair_fused" (1, default: in culled mode
+ * mvr_pair_moments2_batch runs every stage of all pairs as ONE launch; 0: one pair per worker stream;
+ * also MVR_PAIR_FUSED), "pair_streams" (worker streams, 1..16; also MVR_PAIR_STREAMS).
+ * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,
  * running total, max tiles processed by one wave, max tiles tested by one wave} */

@@ -685,8 +685,14 @@ int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2,
     // sets win until there are far more sets than the chip holds at once
     int Q = (qmax <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
     if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
-    const int W = (c->cull_w == 1 || c->cull_w == 4) ? c->cull_w : 2;          // waves sharing one query set (measured best: 2)
     const dim3 grid((unsigned)((qmax + 64 * Q - 1) / (64 * Q)), (unsigned)m);   // one block (W cooperating waves) per query set
+    // waves sharing one query set: a lone search is bound by its longest chain of cells, two waves per set halve
+    // it; a fused batch keeps the chip full whatever the chains are, and one wave per set then does the same work
+    // with fewer, better filled passes (measured on the 12-pair ring: 1.52 ms/step with W = 1, 1.73 with 2, 2.27 with 4)
+    size_t sets = 0;
+    for (int k = 0; k < m; ++k) sets += ((size_t)batch.p[k].q_count + 64 * Q - 1) / (64 * Q);
+    int W = sets >= (size_t)c->n_cu * 40 ? 1 : 2;
+    if (c->cull_w == 1 || c->cull_w == 2 || c->cull_w == 4) W = c->cull_w;      // tuning override
     // region A (evaluations) is only read back by the profiler: per launch at level 1 (cleared here, copied out
     // after the launch), as a running total at level 2 (cleared when profiling starts, read once at the end)
     const bool per_launch = c->prof && !c->prof_totals;

@@ -113,7 +113,7 @@ struct Ctx {
   int nn_q = 8, nn_sub = 32, nn_blocks_per_cu = 2;
   int nn_mode = 1;                                    // 0: brute force, 1: culled (exact, identical results)
   int cull_q = 0;                                     // culled kernel: queries per lane (0 = auto)
-  int cull_w = 2;                                     // culled kernel: waves sharing one query set (1, 2, 4)
+  int cull_w = 0;                                     // culled kernel: waves sharing one query set (1, 2, 4; 0 = by launch size)
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
   // workers: contexts with their own stream and work buffers that BORROW clouds of this
   // context (slots 0/1) so that independent scan pairs run concurrently on the GPU

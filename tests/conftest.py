@@ -37,11 +37,11 @@ def orc():
     return oracle
 
 
-@pytest.fixture(scope="session", params=["culled", "culled_w1", "culled_w4", "brute"])
+@pytest.fixture(scope="session", params=["culled", "culled_w1", "culled_w2", "culled_w4", "brute"])
 def gpu(mvr, request):
     """A GPU context; -m gpu tests fail loudly (no skip, no fallback) without one.
     Every parity test runs against both exact search kernels: the spatially
-    culled one (default: 2 waves share a query set; also 1 and 4) and the brute-force one."""
+    culled one (default: waves per query set chosen by launch size; also forced to 1, 2 and 4) and the brute-force one."""
     # torch (used by the ring tests for streams / the edge table) initialises its HIP state FIRST, as in bench.py:
     # one full run hung for minutes at the first torch use after dozens of library streams already existed
     import torch
