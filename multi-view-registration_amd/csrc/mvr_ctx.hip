@@ -180,9 +180,22 @@ int search_reciprocal(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, doub
   plan->slot = plan->count = nullptr;
   if (nt == 0 || qn == 0) return MVR_OK;
   if (c->nn_mode != 0 && ns > 0) {
+    if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
+    if (nt >= (size_t)std::max(0, c->inplace_ratio) * qn) {
+      // the target is much larger than the set of queries (merged target of the sequential mode): compact the
+      // matched targets into an ordered list first, or most blocks of the reverse launch would find nothing to do
+      const size_t nl = std::min(qn, nt);
+      if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
+      if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
+      if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nl)) return rc;
+      plan->slot = c->slot; plan->count = c->count;
+      if (int rc = launch_mark_sorted(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags, c->list, c->count, c->slot)) return rc;
+      CullPair p = make_cull_pair(tgt, 0, nl, nullptr, src, c->rkeys);
+      p.qlist = c->list; p.qcount = c->count;
+      return launch_nn_cull_batch(c, &p, 1, cap_from_max2(max2), fma);
+    }
     // matched targets are flagged in sorted space and searched IN PLACE (no compaction): rkeys[sorted position]
     if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nt)) return rc;
-    if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
     if (int rc = launch_flag_matched(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags)) return rc;
     return launch_nn_cull(c, tgt, 0, nt, c->flags, src, cap_from_max2(max2), fma, c->rkeys);
   }
@@ -269,6 +282,7 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   if (const char *m = std::getenv("MVR_NN_MODE")) c->nn_mode = std::atoi(m);   // 0 brute force, 1 culled (default)
   if (const char *m = std::getenv("MVR_CULL_Q")) c->cull_q = std::atoi(m);     // 64-query groups per set: 1, 2 (0 = auto)
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
+  if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -1105,6 +1119,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
+  else if (!std::strcmp(key, "inplace_ratio")) c->inplace_ratio = value;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
   else return MVR_E_ARG;
   return MVR_OK;

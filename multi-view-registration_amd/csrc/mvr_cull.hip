@@ -111,7 +111,7 @@ __device__ __forceinline__ float lane_value(float v, int lane_uniform)     // v 
 template <bool FMA, int Q, int W>
 __device__ __forceinline__ void
 nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint8_t *__restrict__ qflags,
-               const float4 *__restrict__ ts, uint32_t nt,
+               const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
                const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
                const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys,
                unsigned long long *__restrict__ evals)
@@ -148,8 +148,10 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   // Queries = sorted positions [q_begin, q_begin + q_count) of the query cloud.  With qflags only the positions
   // whose flag is set are real queries -- the reverse search runs over the matched targets IN PLACE, no compaction:
   // matched targets cluster, so most blocks are either well filled or leave at once.  Key slot: the query's original
-  // index (w) without flags, its sorted position with flags.
-  const uint32_t nq = q_count;
+  // index (w) without flags, its sorted position with flags.  With qlist the queries are the sorted positions
+  // qlist[p], p < *qcount (compacted matched targets: the form used when the target is much larger than the set of
+  // queries, e.g. the merged target of the sequential mode); key slot = p.
+  const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
   const uint32_t b_begin = blockIdx.x * NB;
   if (b_begin >= nq) return;                      // block-uniform
 
@@ -183,7 +185,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   for (int q = 0; q < NQ; ++q) {
     const uint32_t pos = b_begin + q * 16 + l16;
     real[q] = pos < nq && (!qflags || qflags[q_begin + pos] != 0);
-    const float4 p = qs[q_begin + (pos < nq ? pos : b_begin)];
+    const uint32_t at = pos < nq ? pos : b_begin;
+    const float4 p = qs[qlist ? qlist[at] : (q_begin + at)];
     qx[q] = p.x; qy[q] = p.y; qz[q] = p.z;
     best[q] = __builtin_inff(); bsub[q] = kNone;
   }
@@ -525,7 +528,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const uint32_t pos = b_begin + (uint32_t)((wv + j * W) * 16 + l16), rpos = pos < nq ? pos : b_begin;
-    fq[j] = qs[q_begin + rpos];                                 // this query's coordinates (and its original index)
+    fq[j] = qs[qlist ? qlist[rpos] : (q_begin + rpos)];         // this query's coordinates (and its original index)
   }
   __syncthreads();
   nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [4 W][NB]: (d2 bits, sub-tile)
@@ -589,7 +592,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
       o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
       if (g == 0 && pos < nq && (!qflags || qflags[q_begin + pos] != 0)) {
-        const uint32_t ord = qflags ? pos : __float_as_uint(fq[j].w);    // key slot: sorted position / original index
+        const uint32_t ord = (qflags || qlist) ? pos : __float_as_uint(fq[j].w);    // key slot: sorted / list position, or original index
         keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
       }
     }
@@ -661,7 +664,7 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q =
 nn_cull_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
 {
   const CullPair &a = batch.p[blockIdx.y];
-  nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
+  nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
                           a.keys, evals);
 }
 

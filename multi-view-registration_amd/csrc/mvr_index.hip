@@ -228,6 +228,13 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
   a.flags[a.tinv[j]] = 1;
 }
 
+__global__ void scatter_slot_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, size_t cap,
+                                    uint32_t *__restrict__ slot)
+{
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < cap && p < *count) slot[list[p]] = (uint32_t)p;
+}
+
 int ensure_cub(Ctx *c, size_t bytes)
 {
   if (c->cub_cap >= bytes) return MVR_OK;
@@ -381,6 +388,24 @@ int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
     if (stale) todo.push_back(cl);
   }
   return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
+}
+
+int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
+                       const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *slot)
+{
+  if (q_count == 0 || nt == 0) return MVR_OK;
+  if (int rc = launch_flag_matched(c, keys, qperm, q_begin, q_count, max2, tinv, nt, flags)) return rc;
+  ProfScope ps(c, MVR_K_GLUE, 2.0 * (double)nt);
+  // ordered compaction: list = sorted positions of the matched targets, in Hilbert order
+  hipcub::CountingInputIterator<uint32_t> it(0);
+  size_t bytes = 0;
+  MVR_HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, it, flags, list, count, (int)nt, c->stream));
+  if (int rc = ensure_cub(c, bytes)) return rc;
+  MVR_HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->cub_tmp, bytes, it, flags, list, count, (int)nt, c->stream));
+  const size_t cap = std::min(q_count, nt);
+  hipLaunchKernelGGL(scatter_slot_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream, list, count, cap, slot);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
 }
 
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs)

@@ -126,6 +126,7 @@ struct Ctx {
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint8_t *bflags = nullptr; size_t bflags_cap = 0;
   double *bpartials = nullptr; size_t bpartials_cap = 0;
+  int inplace_ratio = 3;                              // culled reverse search in place (flags) when nt < ratio * queries, else compacted list
   int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
   // instrumentation
   bool prof = false;
@@ -208,6 +209,7 @@ constexpr int kBatchPairs = 16;
 struct CullPair {
   const float4 *qs = nullptr, *ts = nullptr, *tlo = nullptr, *thi = nullptr, *cbox = nullptr, *sbox = nullptr;
   const uint8_t *qflags = nullptr;
+  const uint32_t *qlist = nullptr, *qcount = nullptr;     // compacted queries (sorted positions) and their device count
   nnkey_t *keys = nullptr;
   uint32_t q_begin = 0, q_count = 0, nt = 0, n_tiles = 0;
 };
@@ -232,6 +234,9 @@ int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);
 int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs);
 int reduce_blocks_for(const Ctx *c, size_t n);
 
+// the same flags compacted (ordered) into list[] with count and the inverse slot[] (sorted position -> list position)
+int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
+                       const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *slot);
 // culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)
 int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                         const uint32_t *tinv, size_t nt, uint8_t *flags);
