@@ -322,7 +322,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   for (auto &s : c->slots) cloud_free(s);
   c->orders.clear();
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bflags, c->bpartials};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bflags, c->bpartials, c->blist, c->bslot, c->bchunks};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -795,13 +795,21 @@ static int pair_batch_fused(Ctx *c, int n_pairs, const int *src, const int *dst,
   if (int rc = ensure(c, c->brkeys, c->brkeys_cap, off_t[n_pairs])) return rc;
   if (int rc = ensure(c, c->bflags, c->bflags_cap, off_t[n_pairs])) return rc;
   if (int rc = ensure(c, c->bpartials, c->bpartials_cap, off_p[n_pairs])) return rc;
+  if (int rc = ensure(c, c->blist, c->blist_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(c, c->bslot, c->bslot_cap, off_t[n_pairs])) return rc;
+  std::vector<size_t> off_c((size_t)n_pairs + 1, 0);
+  for (int k = 0; k < n_pairs; ++k) off_c[k + 1] = off_c[k] + (c->slots[dst[k]].n + 255) / 256;
+  if (int rc = ensure(c, c->bchunks, c->bchunks_cap, off_c[n_pairs] + (size_t)n_pairs)) return rc;
+  uint32_t *counts = c->bchunks + off_c[n_pairs];
   const double max2 = max_dist * max_dist;
   const float cap2 = cap_from_max2(max2);
   std::vector<CullPair> fwd((size_t)n_pairs), rev((size_t)n_pairs);
   for (int k = 0; k < n_pairs; ++k) {
     const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
     fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, c->bkeys + off_s[k]);
-    rev[k] = make_cull_pair(t, 0, qn[k] ? t.n : 0, c->bflags + off_t[k], s, c->brkeys + off_t[k]);
+    // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
+    rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, c->brkeys + off_t[k]);
+    rev[k].qlist = c->blist + off_t[k]; rev[k].qcount = counts + k;
   }
   if (int rc = launch_nn_cull_batch(c, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
   const bool recip = reciprocal != 0;
@@ -818,11 +826,16 @@ static int pair_batch_fused(Ctx *c, int n_pairs, const int *src, const int *dst,
       g.src = s.pts; g.tgt = t.pts; g.keys = c->bkeys + off_s[k]; g.rkeys = c->brkeys + off_t[k];
       g.qperm = (s.order && qn[k]) ? s.order->perm : nullptr; g.tinv = (t.order && qn[k]) ? t.order->inv : nullptr;
       g.flags = c->bflags + off_t[k];
+      g.list = c->blist + off_t[k]; g.slot = c->bslot + off_t[k]; g.chunks = c->bchunks + off_c[k]; g.qcount = counts + k;
+      g.nt = qn[k] ? t.n : 0;
       g.partials = c->bpartials + off_p[k]; g.out = table + (size_t)k * 32;
       g.q_begin = qb[k]; g.q_count = qn[k]; g.blocks = reduce_blocks_for(c, qn[k]);
     }
-    if (recip) { if (int rc = launch_flag_matched_batch(c, gb, m)) return rc; }
-    if (recip) { if (int rc = launch_nn_cull_batch(c, rev.data() + base, m, cap2, fma != 0)) return rc; }
+    if (recip) {
+      if (int rc = launch_flag_matched_batch(c, gb, m)) return rc;
+      if (int rc = launch_compact_flags_batch(c, gb, m)) return rc;
+      if (int rc = launch_nn_cull_batch(c, rev.data() + base, m, cap2, fma != 0)) return rc;
+    }
     if (int rc = launch_accept_moments2_batch(c, gb, m)) return rc;
   }
   return MVR_OK;

@@ -228,6 +228,72 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
   a.flags[a.tinv[j]] = 1;
 }
 
+// ---- ordered compaction of the flags of ALL pairs of a batch (blockIdx.y = pair): count per 256-position chunk,
+// exclusive scan of the chunk counts (one block per pair), then every chunk writes its flagged positions in order.
+constexpr int kChunk = 256;
+
+__device__ __forceinline__ unsigned chunk_rank(bool f, unsigned *total)      // rank of this thread among the flagged of its block
+{
+  __shared__ unsigned wsum[kChunk / 64];
+  const unsigned long long m = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wsum[wave] = (unsigned)__popcll(m);
+  __syncthreads();
+  unsigned before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kChunk / 64; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+  *total = all;
+  return before + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(kChunk) count_flags_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.y];
+  const size_t pos = (size_t)blockIdx.x * kChunk + threadIdx.x;
+  if ((size_t)blockIdx.x * kChunk >= a.nt) return;            // block-uniform
+  unsigned total;
+  (void)chunk_rank(pos < a.nt && a.flags[pos] != 0, &total);
+  if (threadIdx.x == 0) a.chunks[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) scan_chunks_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.x];
+  const size_t n = ((size_t)a.nt + kChunk - 1) / kChunk;
+  __shared__ unsigned part[256];
+  __shared__ unsigned carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < n; base += 256) {
+    const size_t i = base + threadIdx.x;
+    const unsigned v = i < n ? a.chunks[i] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                        // Hillis-Steele inclusive scan of 256 values
+      const unsigned add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n) a.chunks[i] = carry + part[threadIdx.x] - v;    // exclusive
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *a.qcount = carry;
+}
+
+__global__ void __launch_bounds__(kChunk) compact_flags_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.y];
+  const size_t pos = (size_t)blockIdx.x * kChunk + threadIdx.x;
+  if ((size_t)blockIdx.x * kChunk >= a.nt) return;            // block-uniform
+  const bool f = pos < a.nt && a.flags[pos] != 0;
+  unsigned total;
+  const unsigned r = chunk_rank(f, &total);
+  if (f) { const unsigned at = a.chunks[blockIdx.x] + r; a.list[at] = (uint32_t)pos; a.slot[pos] = at; }
+}
+
 __global__ void scatter_slot_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, size_t cap,
                                     uint32_t *__restrict__ slot)
 {
@@ -388,6 +454,20 @@ int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
     if (stale) todo.push_back(cl);
   }
   return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
+}
+
+int launch_compact_flags_batch(Ctx *c, const GlueBatch &b, int n_pairs)
+{
+  size_t tmax = 0; double work = 0.0;
+  for (int k = 0; k < n_pairs; ++k) { tmax = std::max(tmax, (size_t)b.p[k].nt); work += 10.0 * (double)b.p[k].nt; }
+  if (tmax == 0) return MVR_OK;
+  ProfScope ps(c, MVR_K_GLUE, work);
+  const dim3 grid((unsigned)((tmax + kChunk - 1) / kChunk), (unsigned)n_pairs);
+  hipLaunchKernelGGL(count_flags_batch_kernel, grid, dim3(kChunk), 0, c->stream, b);
+  hipLaunchKernelGGL(scan_chunks_batch_kernel, dim3((unsigned)n_pairs), dim3(256), 0, c->stream, b);
+  hipLaunchKernelGGL(compact_flags_batch_kernel, grid, dim3(kChunk), 0, c->stream, b);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
 }
 
 int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,

@@ -125,6 +125,9 @@ struct Ctx {
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint8_t *bflags = nullptr; size_t bflags_cap = 0;
+  uint32_t *blist = nullptr; size_t blist_cap = 0;
+  uint32_t *bslot = nullptr; size_t bslot_cap = 0;
+  uint32_t *bchunks = nullptr; size_t bchunks_cap = 0;      // per-chunk counts / offsets, then one count per pair
   double *bpartials = nullptr; size_t bpartials_cap = 0;
   int inplace_ratio = 3;                              // culled reverse search in place (flags) when nt < ratio * queries, else compacted list
   int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
@@ -225,12 +228,16 @@ struct GluePair {
   const nnkey_t *keys = nullptr, *rkeys = nullptr;        // forward keys [ns] (by original index), reverse keys [nt] (by sorted position)
   const uint32_t *qperm = nullptr, *tinv = nullptr;
   uint8_t *flags = nullptr;                               // [nt], sorted target space
+  uint32_t *list = nullptr, *slot = nullptr;              // [<= nt] flagged sorted positions in order; [nt] position -> list index
+  uint32_t *chunks = nullptr, *qcount = nullptr;          // [ceil(nt / 256)] flagged per chunk -> exclusive offsets; number flagged
+  unsigned long long nt = 0;
   double *partials = nullptr, *out = nullptr;             // [blocks][29] scratch, 32 doubles result
   unsigned long long q_begin = 0, q_count = 0;
   int blocks = 0, pad = 0;
 };
 struct GlueBatch { GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal; };
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);
+int launch_compact_flags_batch(Ctx *c, const GlueBatch &b, int n_pairs);      // flags -> ordered list / slot / count, 3 launches for all pairs
 int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs);
 int reduce_blocks_for(const Ctx *c, size_t n);
 

@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(kRT) accept_moments2_batch_kernel(GlueBatch b)
 {
   const GluePair &a = b.p[blockIdx.y];
   if ((int)blockIdx.x >= a.blocks) return;
-  accept_moments2_body(a.src, a.tgt, a.keys, a.rkeys, nullptr, a.qperm, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal,
+  accept_moments2_body(a.src, a.tgt, a.keys, a.rkeys, a.slot, a.qperm, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal,
                        Vec3d{b.origin[0], b.origin[1], b.origin[2]}, blockIdx.x, (unsigned)a.blocks, a.partials);
 }
 
