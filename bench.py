@@ -190,10 +190,10 @@ def main():
             r.update(extra)
         return r
 
-    # Roofline of the dominant kernel.  In the timed region the scan pairs run on concurrent worker
-    # streams, so a launch there shares the chip with its neighbours and its HIP-event duration says
-    # little about the kernel; the same steps are therefore repeated ON ONE STREAM (pair_streams=1,
-    # all kernel families timed) and the launch durations of that pass price the kernel.
+    # Roofline of the dominant kernel: the same steps once more right after the timed region, with every
+    # kernel family timed (per-launch HIP events and evaluation counts) -- the timed region itself only
+    # carries events on the NN launches.  (pair_streams=1: in brute-force mode the pairs would otherwise
+    # overlap on worker streams and a launch's duration would include its neighbours.)
     iso = None
     if world == 1:
         ctx.tune(pair_streams=1)
@@ -223,11 +223,12 @@ def main():
             brute_equiv = bev
             bf = nn_roofline("nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal; one untimed ring pass, one stream)", bl, bms,
                              bev, traffic_of("nn_traffic.json"))
-    kname = "nn_cull_kernel (exact culled 1-NN, fwd + reciprocal)" if culled else "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)"
+    kname = "nn_cull_kernel (exact culled 1-NN; one fused launch per direction for all scan pairs of a step)" if culled else "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)"
     ktraffic = traffic_of("nn_cull_traffic.json" if culled else "nn_traffic.json")
     if iso and iso["nn"][0]:
         il, ims, iev = iso["nn"]
-        extra = {"measured": "isolated: %d steps on one stream right after the timed region (HIP events per launch)" % args.steps,
+        extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; one launch = "
+                             "the searches of all %d scan pairs of a step" % (args.steps, V),
                  "ms_per_step_one_stream_profiled": iso["ms_per_step"]}
         if culled:
             extra["evals_bruteforce_equivalent_per_step"] = brute_equiv
@@ -237,8 +238,7 @@ def main():
         out["roofline"] = nn_roofline(kname, il, ims, iev, ktraffic, extra)
     if nn_launches:      # the same kernel inside the timed region, overlapped with other pairs' kernels
         r = nn_roofline(kname, nn_launches, nn_ms, nn_evals, ktraffic,
-                        {"measured": "timed region: launches overlap on %s worker streams, durations include the time "
-                                     "shared with neighbouring kernels" % os.environ.get("MVR_PAIR_STREAMS", "6")})
+                        {"measured": "timed region (only the NN launches carry HIP events there; evaluations from running totals)"})
         if "roofline" in out:
             out["roofline_timed_region"] = r
         else:
