@@ -470,8 +470,8 @@ class Context:
         _chk(_lib.mvr_cloud_transform_batch(self._h, n, d, s, _p(T, C.c_double)), self._h)
 
     def pair_moments2_batch(self, pairs, max_dist, origin, dev_ptr=None, reciprocal=True, fma=False, ranges=None):
-        """All scan pairs of one global iteration in one call; the pairs run concurrently on the
-        context's worker streams.  pairs: [(src, tgt)]; ranges: [(q_begin, q_count)] or None.
+        """All scan pairs of one global iteration in one call: one launch per stage for all pairs (culled
+        search) or one pair per worker stream (brute force).  pairs: [(src, tgt)]; ranges: [(q_begin, q_count)] or None.
         Returns a list of PairMoments2 (host) or, with dev_ptr (device [n][32] float64), None."""
         n = len(pairs)
         src = (C.c_int * n)(*[int(a) for a, _ in pairs])

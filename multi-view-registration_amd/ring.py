@@ -85,7 +85,7 @@ class HipBackend:
             self.table.zero_()
         if segments:
             # a rank's segments cover consecutive edges: one batched call, rows e0.. of the table;
-            # the library runs the pairs concurrently on its worker streams and joins them back
+            # the library runs every stage of all these pairs as one launch (culled mode) or the pairs on worker streams
             es = [e for e, _, _ in segments]
             assert es == list(range(es[0], es[0] + len(es)))
             self.ctx.pair_moments2_batch([edges[e] for e in es], max_dist, origin, dev_ptr=self.table[es[0]].data_ptr(),
