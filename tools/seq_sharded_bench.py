@@ -24,7 +24,8 @@ def main():
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("MVR_FORCE_DIST") == "1")     # rehearse RCCL with one rank
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" is RCCL on ROCm
@@ -34,17 +35,17 @@ def main():
     piv, ax = mvr.synth_prior(sp)
     poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
     ts = torch.cuda.Stream(device=local)
-    n_parts = world if world > 1 else args.parts
-    parts = [seq.HipPart(scans, device=local, tstream=ts) for _ in range(1 if world > 1 else n_parts)]
+    n_parts = world if use_dist else args.parts
+    parts = [seq.HipPart(scans, device=local, tstream=ts) for _ in range(1 if use_dist else n_parts)]
     rmin = rsum = None
-    if world > 1:
+    if use_dist:
         def rmin(k):
             with torch.cuda.stream(ts):
                 dist.all_reduce(k, op=dist.ReduceOp.MIN)
         def rsum(r):
             with torch.cuda.stream(ts):
                 dist.all_reduce(r, op=dist.ReduceOp.SUM)
-    drv = seq.ShardedSequentialICP(parts, V, N, n_parts, part0=rank if world > 1 else 0, all_reduce_min=rmin, all_reduce_sum=rsum,
+    drv = seq.ShardedSequentialICP(parts, V, N, n_parts, part0=rank if use_dist else 0, all_reduce_min=rmin, all_reduce_sum=rsum,
                                    origin=np.array(sp.pivot))
     params = mvr.icp_params(max_dist=args.max_dist)
     drv.run(poses0, params)                        # warm-up (index builds, allocations)
@@ -58,7 +59,7 @@ def main():
     if rank == 0:
         aligns = len(log)
         print(json.dumps(dict(config="%d views x %d pts, sequential vs growing target, target sharded %d ways (%s)" %
-                              (V, N, n_parts, "one shard per rank, RCCL" if world > 1 else "one process, shards walked serially"),
+                              (V, N, n_parts, "one shard per rank, RCCL" if use_dist else "one process, shards walked serially"),
                               aligns=aligns, ms_per_align=1e3 * dt / aligns, queries_per_s=aligns * N / dt,
                               n_corr=[e["n_corr"] for e in log], iterations=[e["iterations"] for e in log],
                               allreduce_bytes_per_iteration={"keys_min": 8 * N, "moments_sum": 256})))
