@@ -62,11 +62,13 @@ void svd3(const double A[9], double U[9], double S[3], double V[9])
       for (int q = p + 1; q < 3; ++q) {
         double app = 0, aqq = 0, apq = 0;
         for (int r = 0; r < 3; ++r) { app += col[p][r] * col[p][r]; aqq += col[q][r] * col[q][r]; apq += col[p][r] * col[q][r]; }
-        if (apq == 0.0 || std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq)) continue;
+        // columns orthogonal to working precision (|cos| <= 2^-53): rotating further only churns the last bits.
+        // (a tau whose square overflows gives t = 0, the right limit)
+        if (apq * apq <= 1.2e-32 * (app * aqq)) continue;
         any = true;
         const double tau = (aqq - app) / (2.0 * apq);
-        const double t = std::copysign(1.0, tau) / (std::fabs(tau) + std::hypot(1.0, tau));
-        const double cs = 1.0 / std::hypot(1.0, t), sn = cs * t;
+        const double t = std::copysign(1.0, tau) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
         for (int r = 0; r < 3; ++r) {
           const double x = col[p][r], y = col[q][r];
           col[p][r] = cs * x - sn * y; col[q][r] = sn * x + cs * y;
@@ -193,17 +195,21 @@ int solve_dense(int n, double *A, double *b)
 // as their last non-zero and zero multipliers are skipped, so the block-banded matrix of a ring of views
 // costs O(n b^2) instead of O(n^3).  Falls back to the pivoted elimination (solve_dense) when a pivot is
 // not safely positive.
-int solve_spd(int n, double *A, double *b)
+// row_end (optional): one past the last column that can be non-zero in row j of the upper triangle, when the
+// caller knows the structure (saves the scan of the matrix).
+int solve_spd(int n, double *A, double *b, const int *row_end = nullptr)
 {
   static thread_local std::vector<double> U;          // scratch, reused: only [j, end[j]) of a row is ever valid
+  static thread_local std::vector<double> dinv;       // 1 / U[j][j]
   static thread_local std::vector<int> end;           // one past the last non-zero of row j (upper part)
   if (U.size() < (size_t)n * n) U.resize((size_t)n * n);
-  if (end.size() < (size_t)n) end.resize((size_t)n);
+  if (end.size() < (size_t)n) { end.resize((size_t)n); dinv.resize((size_t)n); }
   double amax = 0.0;
   for (int j = 0; j < n; ++j) {
     amax = std::max(amax, std::fabs(A[(size_t)j * n + j]));
     int e = j + 1;
-    for (int k = n - 1; k > j; --k) if (A[(size_t)j * n + k] != 0.0) { e = k + 1; break; }
+    if (row_end) e = std::max(e, std::min(n, row_end[j]));
+    else for (int k = n - 1; k > j; --k) if (A[(size_t)j * n + k] != 0.0) { e = k + 1; break; }
     std::memcpy(&U[(size_t)j * n + j], &A[(size_t)j * n + j], (size_t)(e - j) * sizeof(double));
     end[j] = e;
   }
@@ -214,7 +220,7 @@ int solve_spd(int n, double *A, double *b)
     if (!(d > 1e-13 * amax)) { ok = false; break; }
     const double ujj = std::sqrt(d), inv = 1.0 / ujj;
     const int ej = end[j];
-    Uj[j] = ujj;
+    Uj[j] = ujj; dinv[j] = inv;
     for (int k = j + 1; k < ej; ++k) Uj[k] *= inv;
     for (int i = j + 1; i < ej; ++i) {
       const double f = Uj[i];
@@ -226,7 +232,7 @@ int solve_spd(int n, double *A, double *b)
   }
   if (!ok) return solve_dense(n, A, b);
   for (int i = 0; i < n; ++i) {                       // U^T y = b, column-oriented: axpy over row i of U
-    const double y = b[i] / U[(size_t)i * n + i];
+    const double y = b[i] * dinv[i];                  // (a multiply keeps the divider off the dependent chain)
     b[i] = y;
     const double *Ui = &U[(size_t)i * n];
     for (int k = i + 1; k < end[i]; ++k) b[k] -= Ui[k] * y;
@@ -235,7 +241,7 @@ int solve_spd(int n, double *A, double *b)
     const double *Ui = &U[(size_t)i * n];
     double s = b[i];
     for (int k = i + 1; k < end[i]; ++k) s -= Ui[k] * b[k];
-    b[i] = s / Ui[i];
+    b[i] = s * dinv[i];
   }
   return MVR_OK;
 }
@@ -405,6 +411,13 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
       for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vj && et[k] == vi) e = k;
       eidx[(size_t)vi * n + vj] = e; efwd[(size_t)vi * n + vj] = fwd;
     }
+  // structure of G (the same in every iteration): block row vi - 1 reaches as far as its highest neighbour
+  std::vector<int> row_end((size_t)dim, 0);
+  for (int vi = 1; vi < n; ++vi) {
+    int hi = vi;
+    for (int vj = 1; vj < n; ++vj) if (eidx[(size_t)vi * n + vj] >= 0) hi = std::max(hi, vj);
+    for (int r = 0; r < 6; ++r) row_end[6 * (vi - 1) + r] = 6 * hi;
+  }
   int it = 0;
   for (; it < max_iterations; ++it) {
     for (int e = 0; e < ne; ++e) {
@@ -431,7 +444,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
           }
         for (int r = 0; r < 6; ++r) B[6 * (vi - 1) + r] += (fwd ? 1.0 : -1.0) * cinvd[6 * e + r];
       }
-    if (solve_spd(dim, G.data(), B.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
+    if (solve_spd(dim, G.data(), B.data(), row_end.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
     double sum = 0.0;
     for (int vi = 1; vi < n; ++vi) {
       double inc[36], incinv[36], dp[6], nrm = 0.0;

@@ -520,6 +520,9 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   const unsigned long long st_loopend = MVR_CLK();
   MVR_MARK(5);
 
+#ifdef MVR_SKIP_MERGE         // counter experiments only: no merge, no key output (results are wrong)
+  if (cells_done != 0xFFFFFFFFu) return;
+#endif
   // ---- combine: 4 W partial results per query (W waves x 4 lane groups) meet in LDS (over the tile buffers).
   // The waves share out the 4 Q lane columns (16 queries each): wave wv finishes columns wv, wv + W, ...
   // The queries are re-read before the barrier (their latency hides behind the wait for the slowest wave).
