@@ -192,11 +192,12 @@ def main():
 
     # Roofline of the dominant kernel: the same steps once more right after the timed region, with every
     # kernel family timed (per-launch HIP events and evaluation counts) -- the timed region itself only
-    # carries events on the NN launches.  (pair_streams=1: in brute-force mode the pairs would otherwise
-    # overlap on worker streams and a launch's duration would include its neighbours.)
+    # carries events on the NN launches.  (pair_streams=1 / pair_groups=1: the pairs, or the two groups of
+    # pairs of the fused pass, would otherwise overlap on worker streams and a launch's duration would include
+    # its neighbours.)
     iso = None
     if world == 1:
-        ctx.tune(pair_streams=1)
+        ctx.tune(pair_streams=1, pair_groups=1)
         reset(); step(); reset()
         ctx.prof_reset(); ctx.prof_enable(1)
         barrier(); ti = time.perf_counter()

@@ -286,7 +286,9 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_CO
  * "cull_q" (64-query groups per set: 1,2; 0 = auto), "cull_w" (waves sharing one
  * query set: 1,2,4; 0 = by launch size; also MVR_CULL_W); "pair_fused" (1, default: in culled mode
  * mvr_pair_moments2_batch runs every stage of all pairs as ONE launch; 0: one pair per worker stream;
- * also MVR_PAIR_FUSED), "pair_streams" (worker streams, 1..16; also MVR_PAIR_STREAMS).
+ * also MVR_PAIR_FUSED), "pair_groups" (1..8, default 2: the fused pass runs its pairs in that many groups on
+ * concurrent streams, so one group's small kernels overlap another's searches; also MVR_PAIR_GROUPS),
+ * "pair_streams" (worker streams, 1..16; also MVR_PAIR_STREAMS).
  * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,

@@ -284,6 +284,7 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_PAIR_GROUPS")) c->pair_groups = std::max(1, std::min(8, std::atoi(m)));
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else {
@@ -776,7 +777,8 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
 // matched targets, reverse searches, filter + raw moments, final sums -- 6 launches for V pairs instead of ~10 V
 // on worker streams.  The pairs of one launch fill the chip together, so the tail of one pair's search is covered
 // by the others.  Same results as the one-pair calls, bit for bit.
-static int pair_batch_fused(Ctx *c, int n_pairs, const int *src, const int *dst, double max_dist, int reciprocal, int fma,
+// c owns the clouds; w (c itself, or one of its workers) provides the stream and the work buffers.
+static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const int *dst, double max_dist, int reciprocal, int fma,
                             const size_t *q_begin, const size_t *q_count, const double origin[3], double *table)
 {
   std::vector<size_t> off_s((size_t)n_pairs + 1, 0), off_t((size_t)n_pairs + 1, 0), off_p((size_t)n_pairs + 1, 0), qb((size_t)n_pairs), qn((size_t)n_pairs);
@@ -791,29 +793,30 @@ static int pair_batch_fused(Ctx *c, int n_pairs, const int *src, const int *dst,
     off_s[k + 1] = off_s[k] + s.n; off_t[k + 1] = off_t[k] + t.n;
     off_p[k + 1] = off_p[k] + (size_t)reduce_blocks_for(c, n) * 29;
   }
-  if (int rc = ensure(c, c->bkeys, c->bkeys_cap, off_s[n_pairs])) return rc;
-  if (int rc = ensure(c, c->brkeys, c->brkeys_cap, off_t[n_pairs])) return rc;
-  if (int rc = ensure(c, c->bflags, c->bflags_cap, off_t[n_pairs])) return rc;
-  if (int rc = ensure(c, c->bpartials, c->bpartials_cap, off_p[n_pairs])) return rc;
-  if (int rc = ensure(c, c->blist, c->blist_cap, off_t[n_pairs])) return rc;
-  if (int rc = ensure(c, c->bslot, c->bslot_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(w, w->bkeys, w->bkeys_cap, off_s[n_pairs])) return rc;
+  if (int rc = ensure(w, w->brkeys, w->brkeys_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(w, w->bflags, w->bflags_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(w, w->bpartials, w->bpartials_cap, off_p[n_pairs])) return rc;
+  if (int rc = ensure(w, w->blist, w->blist_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(w, w->bslot, w->bslot_cap, off_t[n_pairs])) return rc;
   std::vector<size_t> off_c((size_t)n_pairs + 1, 0);
   for (int k = 0; k < n_pairs; ++k) off_c[k + 1] = off_c[k] + (c->slots[dst[k]].n + 255) / 256;
-  if (int rc = ensure(c, c->bchunks, c->bchunks_cap, off_c[n_pairs] + (size_t)n_pairs)) return rc;
-  uint32_t *counts = c->bchunks + off_c[n_pairs];
+  if (int rc = ensure(w, w->bchunks, w->bchunks_cap, off_c[n_pairs] + (size_t)n_pairs)) return rc;
+  uint32_t *counts = w->bchunks + off_c[n_pairs];
   const double max2 = max_dist * max_dist;
   const float cap2 = cap_from_max2(max2);
   std::vector<CullPair> fwd((size_t)n_pairs), rev((size_t)n_pairs);
   for (int k = 0; k < n_pairs; ++k) {
     const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
-    fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, c->bkeys + off_s[k]);
+    fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, w->bkeys + off_s[k]);
+    fwd[k].key_by_pos = 1;       // forward keys live in the source's Hilbert order from here on (coalesced for every consumer below)
     // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
-    rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, c->brkeys + off_t[k]);
-    rev[k].qlist = c->blist + off_t[k]; rev[k].qcount = counts + k;
+    rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, w->brkeys + off_t[k]);
+    rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
   }
-  if (int rc = launch_nn_cull_batch(c, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+  if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
   const bool recip = reciprocal != 0;
-  if (recip && off_t[n_pairs]) MVR_HIP_TRY(c, hipMemsetAsync(c->bflags, 0, off_t[n_pairs], c->stream));
+  if (recip && off_t[n_pairs]) MVR_HIP_TRY(w, hipMemsetAsync(w->bflags, 0, off_t[n_pairs], w->stream));
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
     const int m = std::min(kBatchPairs, n_pairs - base);
     GlueBatch gb;
@@ -823,20 +826,21 @@ static int pair_batch_fused(Ctx *c, int n_pairs, const int *src, const int *dst,
       const int k = base + j;
       const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
       GluePair &g = gb.p[j];
-      g.src = s.pts; g.tgt = t.pts; g.keys = c->bkeys + off_s[k]; g.rkeys = c->brkeys + off_t[k];
+      g.src = s.pts; g.tgt = t.pts; g.qs = s.sorted; g.ts = t.sorted; g.by_pos = 1;
+      g.keys = w->bkeys + off_s[k]; g.rkeys = w->brkeys + off_t[k];
       g.qperm = (s.order && qn[k]) ? s.order->perm : nullptr; g.tinv = (t.order && qn[k]) ? t.order->inv : nullptr;
-      g.flags = c->bflags + off_t[k];
-      g.list = c->blist + off_t[k]; g.slot = c->bslot + off_t[k]; g.chunks = c->bchunks + off_c[k]; g.qcount = counts + k;
+      g.flags = w->bflags + off_t[k];
+      g.list = w->blist + off_t[k]; g.slot = w->bslot + off_t[k]; g.chunks = w->bchunks + off_c[k]; g.qcount = counts + k;
       g.nt = qn[k] ? t.n : 0;
-      g.partials = c->bpartials + off_p[k]; g.out = table + (size_t)k * 32;
+      g.partials = w->bpartials + off_p[k]; g.out = table + (size_t)k * 32;
       g.q_begin = qb[k]; g.q_count = qn[k]; g.blocks = reduce_blocks_for(c, qn[k]);
     }
     if (recip) {
-      if (int rc = launch_flag_matched_batch(c, gb, m)) return rc;
-      if (int rc = launch_compact_flags_batch(c, gb, m)) return rc;
-      if (int rc = launch_nn_cull_batch(c, rev.data() + base, m, cap2, fma != 0)) return rc;
+      if (int rc = launch_flag_matched_batch(w, gb, m)) return rc;
+      if (int rc = launch_compact_flags_batch(w, gb, m)) return rc;
+      if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc;
     }
-    if (int rc = launch_accept_moments2_batch(c, gb, m)) return rc;
+    if (int rc = launch_accept_moments2_batch(w, gb, m)) return rc;
   }
   return MVR_OK;
 }
@@ -863,7 +867,41 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     if (int rc = ensure_index_batch(c, used.data(), (int)used.size())) return rc;      // one refresh launch for all views
   }
   if (c->nn_mode != 0 && c->pair_fused) {
-    if (int rc = pair_batch_fused(c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
+    // Optionally in G groups of pairs, group 0 on the caller's stream and the others on worker streams: a group's
+    // glue kernels and the tail of its searches then overlap the other groups' searches.
+    const int G = std::max(1, std::min(c->pair_groups, n_pairs));
+    if (G == 1) {
+      if (int rc = pair_batch_fused(c, c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
+    } else {
+      // waves per query set: decided for the whole pass (the groups share the chip), not per group
+      size_t sets = 0;
+      for (int k = 0; k < n_pairs; ++k) sets += ((q_count ? std::min(q_count[k], c->slots[src[k]].n) : c->slots[src[k]].n) + 63) / 64;
+      const int saved_w = c->cull_w;
+      if (c->cull_w == 0 && sets >= (size_t)c->n_cu * 40) c->cull_w = 1;
+      int status = MVR_OK;
+      if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) status = set_error(c, MVR_E_HIP, "fork event");
+      if (status == MVR_OK && hipEventRecord(c->ev_fork, c->stream) != hipSuccess) status = set_error(c, MVR_E_HIP, "fork");
+      int forked = 0;
+      for (int g = G - 1; g >= 0 && status == MVR_OK; --g) {        // workers first, the caller's own group last
+        const int lo = (int)((long long)n_pairs * g / G), hi = (int)((long long)n_pairs * (g + 1) / G);
+        Ctx *w = c;
+        if (g > 0) {
+          if ((status = get_worker(c, (size_t)(g - 1), &w)) != MVR_OK) break;
+          if (hipStreamWaitEvent(w->stream, c->ev_fork, 0) != hipSuccess) { status = set_error(c, MVR_E_HIP, "fork"); break; }
+          forked = std::max(forked, g);
+        }
+        status = pair_batch_fused(c, w, hi - lo, src + lo, dst + lo, max_dist, reciprocal, fma, q_begin ? q_begin + lo : nullptr,
+                                  q_count ? q_count + lo : nullptr, origin, table + (size_t)lo * 32);
+        if (status != MVR_OK && w != c) c->last_error = w->last_error;
+      }
+      for (int g = 1; g <= forked; ++g) {                            // join, always
+        Ctx *w = c->workers[(size_t)(g - 1)];
+        if (w->ev_join && hipEventRecord(w->ev_join, w->stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, w->ev_join, 0);
+        else (void)hipStreamSynchronize(w->stream);
+      }
+      c->cull_w = saved_w;
+      if (status != MVR_OK) return status;
+    }
     if (out) {
       std::vector<double> h((size_t)n_pairs * 32);
       MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1132,6 +1170,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
+  else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }
   else if (!std::strcmp(key, "inplace_ratio")) c->inplace_ratio = value;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
   else return MVR_E_ARG;

@@ -113,7 +113,7 @@ __device__ __forceinline__ void
 nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, const uint8_t *__restrict__ qflags,
                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
                const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
-               const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys,
+               const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, uint32_t key_by_pos,
                unsigned long long *__restrict__ evals)
 {
   constexpr int NQ = 4 * Q;      // queries per lane
@@ -595,7 +595,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
       o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
       if (g == 0 && pos < nq && (!qflags || qflags[q_begin + pos] != 0)) {
-        const uint32_t ord = (qflags || qlist) ? pos : __float_as_uint(fq[j].w);    // key slot: sorted / list position, or original index
+        // key slot: sorted / list position, or original index (or, on request, the absolute sorted position)
+        const uint32_t ord = (qflags || qlist) ? pos : (key_by_pos ? q_begin + pos : __float_as_uint(fq[j].w));
         keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
       }
     }
@@ -668,7 +669,7 @@ nn_cull_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
 {
   const CullPair &a = batch.p[blockIdx.y];
   nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
-                          a.keys, evals);
+                          a.keys, a.key_by_pos, evals);
 }
 
 }  // namespace

@@ -219,7 +219,7 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
   const GluePair &a = b.p[blockIdx.y];
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.q_count) return;
-  const size_t i = a.qperm[a.q_begin + k];
+  const size_t i = a.by_pos ? (size_t)(a.q_begin + k) : (size_t)a.qperm[a.q_begin + k];      // key slot
   const nnkey_t key = a.keys[i];
   const uint32_t j = (uint32_t)key;
   if (j == kNone) return;

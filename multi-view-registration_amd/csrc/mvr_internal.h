@@ -131,6 +131,7 @@ struct Ctx {
   double *bpartials = nullptr; size_t bpartials_cap = 0;
   int inplace_ratio = 3;                              // culled reverse search in place (flags) when nt < ratio * queries, else compacted list
   int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
+  int pair_groups = 2;                                // fused pass: groups of pairs on concurrent streams (1: a single stream); measured on the 12-pair ring: 1.27 / 1.22 / 1.28 / 1.39 ms per step with 1 / 2 / 3 / 4
   // instrumentation
   bool prof = false;
   unsigned prof_mask = ~0u;                           // families that are timed (bit f = family f)
@@ -215,6 +216,7 @@ struct CullPair {
   const uint32_t *qlist = nullptr, *qcount = nullptr;     // compacted queries (sorted positions) and their device count
   nnkey_t *keys = nullptr;
   uint32_t q_begin = 0, q_count = 0, nt = 0, n_tiles = 0;
+  uint32_t key_by_pos = 0;       // plain queries only: key slot = sorted position (coalesced stores) instead of the original index
 };
 struct CullBatch { CullPair p[kBatchPairs]; float cap2; };
 CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys);
@@ -225,7 +227,8 @@ int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const
 // reduction kernels need, by value (blockIdx.y = pair)
 struct GluePair {
   const float4 *src = nullptr, *tgt = nullptr;            // original-order points
-  const nnkey_t *keys = nullptr, *rkeys = nullptr;        // forward keys [ns] (by original index), reverse keys [nt] (by sorted position)
+  const float4 *qs = nullptr, *ts = nullptr;              // the same points in index (Hilbert) order, w = original index
+  const nnkey_t *keys = nullptr, *rkeys = nullptr;        // forward keys [ns] (by original index, or by sorted position: by_pos), reverse keys [nt] (by sorted position)
   const uint32_t *qperm = nullptr, *tinv = nullptr;
   uint8_t *flags = nullptr;                               // [nt], sorted target space
   uint32_t *list = nullptr, *slot = nullptr;              // [<= nt] flagged sorted positions in order; [nt] position -> list index
@@ -233,7 +236,7 @@ struct GluePair {
   unsigned long long nt = 0;
   double *partials = nullptr, *out = nullptr;             // [blocks][29] scratch, 32 doubles result
   unsigned long long q_begin = 0, q_count = 0;
-  int blocks = 0, pad = 0;
+  int blocks = 0, by_pos = 0;
 };
 struct GlueBatch { GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal; };
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);

@@ -362,7 +362,11 @@ moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, 
 // K5 + K8 in one pass for the global mode: the reciprocal filter of pass1_kernel and the sums of
 // moments2_kernel (same acceptance, same accumulation order, so the same bits), without the centroid
 // reduction, its final kernel and the match[] round trip that only the two-pass covariance needs.
-template <class Dummy = void>
+// BYPOS (the fused global pass): the forward keys are stored by SORTED position and the points are read from
+// the Hilbert-ordered copies (src = sorted source, tgt = sorted target, w = original index), so only the
+// original-index -> position lookup of the match is a random gather; neighbouring queries have neighbouring
+// matches.  Same points, same acceptance, same order of additions as the walk over the original arrays.
+template <bool BYPOS>
 __device__ __forceinline__ void accept_moments2_body(const float4 *__restrict__ src, const float4 *__restrict__ tgt,
                                                      const nnkey_t *__restrict__ keys, const nnkey_t *__restrict__ rkeys,
                                                      const uint32_t *__restrict__ slot, const uint32_t *__restrict__ qperm,
@@ -374,31 +378,86 @@ __device__ __forceinline__ void accept_moments2_body(const float4 *__restrict__ 
 #pragma unroll
   for (int k = 0; k < 29; ++k) acc[k] = 0.0;
   const size_t stride = (size_t)n_blocks * blockDim.x;
-  for (size_t k = (size_t)block * blockDim.x + threadIdx.x; k < q_count; k += stride) {
-    const size_t i = qperm ? (size_t)qperm[q_begin + k] : (q_begin + k);
-    const nnkey_t key = keys[i];
-    const uint32_t j = (uint32_t)key;
-    const float d2 = __uint_as_float((uint32_t)(key >> 32));
-    bool ok = (j != kNone) && !((double)d2 > max2);
-    if (ok && reciprocal) {
-      const uint32_t tj = tinv ? tinv[j] : j;
-      const nnkey_t rk = rkeys[slot ? slot[tj] : tj];        // compacted list (brute force) or in place (culled)
-      const float dr = __uint_as_float((uint32_t)(rk >> 32));
-      ok = ((uint32_t)rk == (uint32_t)i) && !((double)dr > max2);
+  // Every accepted match sits at the end of a chain of dependent gathers (qperm -> key -> tinv -> reverse key ->
+  // the two points), so a thread walks kUn of its queries at once: each stage issues its loads for all of them
+  // before the next stage waits.  The sums are still added in the order k, k + stride, ... (same bits as a
+  // one-at-a-time walk).
+  constexpr int kUn = 4;
+  for (size_t k0 = (size_t)block * blockDim.x + threadIdx.x; k0 < q_count; k0 += kUn * stride) {
+    size_t i[kUn];                 // key slot (BYPOS: sorted position), then the query's original index
+    nnkey_t key[kUn];
+    uint32_t j[kUn], tpos[kUn];    // match: original index, position in tgt[]
+    float d2[kUn];
+    bool ok[kUn];
+    float4 p4[kUn], q4[kUn];
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      const size_t k = k0 + (size_t)u * stride;
+      ok[u] = k < q_count;
+      i[u] = 0;
+      if (ok[u]) i[u] = (!BYPOS && qperm) ? (size_t)qperm[q_begin + k] : (q_begin + k);
     }
-    if (!ok) continue;
-    const float4 p4 = src[i], q4 = tgt[j];
-    const double px = (double)p4.x - o.x, py = (double)p4.y - o.y, pz = (double)p4.z - o.z;
-    const double qx = (double)q4.x - o.x, qy = (double)q4.y - o.y, qz = (double)q4.z - o.z;
-    acc[0] += 1.0;
-    acc[1] += px; acc[2] += py; acc[3] += pz;
-    acc[4] += qx; acc[5] += qy; acc[6] += qz;
-    acc[7] += px * px; acc[8] += px * py; acc[9] += px * pz; acc[10] += py * py; acc[11] += py * pz; acc[12] += pz * pz;
-    acc[13] += qx * qx; acc[14] += qx * qy; acc[15] += qx * qz; acc[16] += qy * qy; acc[17] += qy * qz; acc[18] += qz * qz;
-    acc[19] += px * qx; acc[20] += px * qy; acc[21] += px * qz;
-    acc[22] += py * qx; acc[23] += py * qy; acc[24] += py * qz;
-    acc[25] += pz * qx; acc[26] += pz * qy; acc[27] += pz * qz;
-    acc[28] += (double)d2;
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      key[u] = ~(nnkey_t)0; p4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[u]) { key[u] = keys[i[u]]; if (BYPOS) p4[u] = src[i[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      j[u] = (uint32_t)key[u];
+      d2[u] = __uint_as_float((uint32_t)(key[u] >> 32));
+      ok[u] = ok[u] && (j[u] != kNone) && !((double)d2[u] > max2);
+      if (BYPOS) i[u] = (size_t)__float_as_uint(p4[u].w);
+    }
+    if (BYPOS) {
+#pragma unroll
+      for (int u = 0; u < kUn; ++u) { tpos[u] = 0; if (ok[u]) tpos[u] = tinv[j[u]]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kUn; ++u) tpos[u] = j[u];
+    }
+    if (reciprocal) {
+      uint32_t tj[kUn];
+      nnkey_t rk[kUn];
+      if (BYPOS) {
+#pragma unroll
+        for (int u = 0; u < kUn; ++u) tj[u] = tpos[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < kUn; ++u) { tj[u] = j[u]; if (ok[u] && tinv) tj[u] = tinv[j[u]]; }
+      }
+      if (slot) {                                          // reverse keys by list position (compacted queries); by sorted position otherwise
+#pragma unroll
+        for (int u = 0; u < kUn; ++u) if (ok[u]) tj[u] = slot[tj[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < kUn; ++u) { rk[u] = 0; if (ok[u]) rk[u] = rkeys[tj[u]]; }
+#pragma unroll
+      for (int u = 0; u < kUn; ++u) {
+        const float dr = __uint_as_float((uint32_t)(rk[u] >> 32));
+        ok[u] = ok[u] && ((uint32_t)rk[u] == (uint32_t)i[u]) && !((double)dr > max2);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      q4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[u]) { if (!BYPOS) p4[u] = src[i[u]]; q4[u] = tgt[tpos[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < kUn; ++u) {
+      if (!ok[u]) continue;
+      const double px = (double)p4[u].x - o.x, py = (double)p4[u].y - o.y, pz = (double)p4[u].z - o.z;
+      const double qx = (double)q4[u].x - o.x, qy = (double)q4[u].y - o.y, qz = (double)q4[u].z - o.z;
+      acc[0] += 1.0;
+      acc[1] += px; acc[2] += py; acc[3] += pz;
+      acc[4] += qx; acc[5] += qy; acc[6] += qz;
+      acc[7] += px * px; acc[8] += px * py; acc[9] += px * pz; acc[10] += py * py; acc[11] += py * pz; acc[12] += pz * pz;
+      acc[13] += qx * qx; acc[14] += qx * qy; acc[15] += qx * qz; acc[16] += qy * qy; acc[17] += qy * qz; acc[18] += qz * qz;
+      acc[19] += px * qx; acc[20] += px * qy; acc[21] += px * qz;
+      acc[22] += py * qx; acc[23] += py * qy; acc[24] += py * qz;
+      acc[25] += pz * qx; acc[26] += pz * qy; acc[27] += pz * qz;
+      acc[28] += (double)d2[u];
+    }
   }
   block_partials_at<29>(acc, partials, block);
 }
@@ -409,7 +468,7 @@ accept_moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict_
                        const uint32_t *__restrict__ tinv, size_t q_begin, size_t q_count, double max2, int reciprocal, Vec3d o,
                        double *__restrict__ partials)
 {
-  accept_moments2_body(src, tgt, keys, rkeys, slot, qperm, tinv, q_begin, q_count, max2, reciprocal, o, blockIdx.x, gridDim.x, partials);
+  accept_moments2_body<false>(src, tgt, keys, rkeys, slot, qperm, tinv, q_begin, q_count, max2, reciprocal, o, blockIdx.x, gridDim.x, partials);
 }
 
 // the same for all scan pairs of a global pass in one launch (blockIdx.y = pair); a pair uses its OWN number of
@@ -418,8 +477,13 @@ __global__ void __launch_bounds__(kRT) accept_moments2_batch_kernel(GlueBatch b)
 {
   const GluePair &a = b.p[blockIdx.y];
   if ((int)blockIdx.x >= a.blocks) return;
-  accept_moments2_body(a.src, a.tgt, a.keys, a.rkeys, a.slot, a.qperm, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal,
-                       Vec3d{b.origin[0], b.origin[1], b.origin[2]}, blockIdx.x, (unsigned)a.blocks, a.partials);
+  const Vec3d o{b.origin[0], b.origin[1], b.origin[2]};
+  if (a.by_pos)
+    accept_moments2_body<true>(a.qs, a.ts, a.keys, a.rkeys, a.slot, nullptr, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal, o,
+                               blockIdx.x, (unsigned)a.blocks, a.partials);
+  else
+    accept_moments2_body<false>(a.src, a.tgt, a.keys, a.rkeys, a.slot, a.qperm, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal, o,
+                                blockIdx.x, (unsigned)a.blocks, a.partials);
 }
 
 // out (32 doubles): [0] n, [1..3] origin, [4..6] sp, [7..9] sq, [10..15] spp, [16..21] sqq, [22..30] spq, [31] sum d2 (or 0)

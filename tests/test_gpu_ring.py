@@ -59,7 +59,7 @@ def test_fake_world_partition_sums_to_unsharded(mvr, ring, world):
         be.close()
 
 
-@pytest.mark.parametrize("streams", [1, 3, 6])
+@pytest.mark.parametrize("streams", [1, 3, 4, 6])
 def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
     """mvr_pair_moments2_batch (pairs on concurrent worker streams) returns exactly the sums of
     one mvr_pair_moments2 call per pair, with and without query sub-ranges, whatever the stream count."""
@@ -73,7 +73,8 @@ def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
         gpu.transform(v, V + v, poses0[v])
     pairs = [(v, (v + 1) % V) for v in range(V)] + [(2, 5), (5, 2)]
     ranges = [(0, None), (100, 700), (0, 0), (2000, None), (5, 1), (0, None), (1024, 1024), (3, 2040), (0, None)]
-    gpu.tune(pair_streams=streams, pair_fused=int(streams != 3))      # streams == 3: the worker-stream path also in culled mode
+    # streams == 3: the worker-stream path also in culled mode; the fused pass in 1, 2 (default) or 4 groups of pairs
+    gpu.tune(pair_streams=streams, pair_fused=int(streams != 3), pair_groups={1: 1, 3: 1, 6: 2}.get(streams, 4))
     try:
         for rg in (None, ranges):
             single = [gpu.pair_moments2(s, t, 8.0, origin, q_begin=0 if rg is None else rg[k][0],
@@ -86,7 +87,7 @@ def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
         # an empty batch is a no-op
         assert gpu.pair_moments2_batch([], 8.0, origin) == []
     finally:
-        gpu.tune(pair_streams=6, pair_fused=1)
+        gpu.tune(pair_streams=6, pair_fused=1, pair_groups=2)
 
 
 def test_transform_batch_equals_single_transforms(gpu, mvr):
