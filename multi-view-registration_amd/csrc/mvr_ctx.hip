@@ -181,6 +181,9 @@ int search_reciprocal(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, doub
   if (nt == 0 || qn == 0) return MVR_OK;
   if (c->nn_mode != 0 && ns > 0) {
     if (int rc = ensure(c, c->flags, c->flags_cap, nt)) return rc;
+    // a matched target has a source point at its forward distance: its reverse search starts from that bound
+    if (int rc = ensure(c, c->bound, c->bound_cap, nt)) return rc;
+    if (int rc = launch_seed_bounds(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->bound)) return rc;
     if (nt >= (size_t)std::max(0, c->inplace_ratio) * qn) {
       // the target is much larger than the set of queries (merged target of the sequential mode): compact the
       // matched targets into an ordered list first, or most blocks of the reverse launch would find nothing to do
@@ -191,13 +194,16 @@ int search_reciprocal(Ctx *c, Cloud &src, Cloud &tgt, size_t qb, size_t qn, doub
       plan->slot = c->slot; plan->count = c->count;
       if (int rc = launch_mark_sorted(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags, c->list, c->count, c->slot)) return rc;
       CullPair p = make_cull_pair(tgt, 0, nl, nullptr, src, c->rkeys);
-      p.qlist = c->list; p.qcount = c->count;
+      p.qlist = c->list; p.qcount = c->count; p.qbound = c->bound;
       return launch_nn_cull_batch(c, &p, 1, cap_from_max2(max2), fma);
     }
     // matched targets are flagged in sorted space and searched IN PLACE (no compaction): rkeys[sorted position]
     if (int rc = ensure(c, c->rkeys, c->rkeys_cap, nt)) return rc;
     if (int rc = launch_flag_matched(c, c->keys, plan->qperm, qb, qn, max2, plan->tinv, nt, c->flags)) return rc;
-    return launch_nn_cull(c, tgt, 0, nt, c->flags, src, cap_from_max2(max2), fma, c->rkeys);
+    if (ns > 0xFFFFFFF0ull || nt > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+    CullPair p = make_cull_pair(tgt, 0, nt, c->flags, src, c->rkeys);
+    p.qbound = c->bound;
+    return launch_nn_cull_batch(c, &p, 1, cap_from_max2(max2), fma);
   }
   const size_t nl = std::min(qn, nt);
   if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
@@ -323,7 +329,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   for (auto &s : c->slots) cloud_free(s);
   c->orders.clear();
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bflags, c->bpartials, c->blist, c->bslot, c->bchunks};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->bpartials, c->blist, c->bslot, c->bchunks};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -795,7 +801,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   }
   if (int rc = ensure(w, w->bkeys, w->bkeys_cap, off_s[n_pairs])) return rc;
   if (int rc = ensure(w, w->brkeys, w->brkeys_cap, off_t[n_pairs])) return rc;
-  if (int rc = ensure(w, w->bflags, w->bflags_cap, off_t[n_pairs])) return rc;
+  if (int rc = ensure(w, w->bbound, w->bbound_cap, off_t[n_pairs])) return rc;
   if (int rc = ensure(w, w->bpartials, w->bpartials_cap, off_p[n_pairs])) return rc;
   if (int rc = ensure(w, w->blist, w->blist_cap, off_t[n_pairs])) return rc;
   if (int rc = ensure(w, w->bslot, w->bslot_cap, off_t[n_pairs])) return rc;
@@ -813,10 +819,11 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
     rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, w->brkeys + off_t[k]);
     rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
+    rev[k].qbound = w->bbound + off_t[k];      // a matched target has a source point at the forward distance: its search starts there
   }
   if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
   const bool recip = reciprocal != 0;
-  if (recip && off_t[n_pairs]) MVR_HIP_TRY(w, hipMemsetAsync(w->bflags, 0, off_t[n_pairs], w->stream));
+  if (recip && off_t[n_pairs]) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, off_t[n_pairs] * sizeof(uint32_t), w->stream));
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
     const int m = std::min(kBatchPairs, n_pairs - base);
     GlueBatch gb;
@@ -829,7 +836,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       g.src = s.pts; g.tgt = t.pts; g.qs = s.sorted; g.ts = t.sorted; g.by_pos = 1;
       g.keys = w->bkeys + off_s[k]; g.rkeys = w->brkeys + off_t[k];
       g.qperm = (s.order && qn[k]) ? s.order->perm : nullptr; g.tinv = (t.order && qn[k]) ? t.order->inv : nullptr;
-      g.flags = w->bflags + off_t[k];
+      g.bound = w->bbound + off_t[k];
       g.list = w->blist + off_t[k]; g.slot = w->bslot + off_t[k]; g.chunks = w->bchunks + off_c[k]; g.qcount = counts + k;
       g.nt = qn[k] ? t.n : 0;
       g.partials = w->bpartials + off_p[k]; g.out = table + (size_t)k * 32;

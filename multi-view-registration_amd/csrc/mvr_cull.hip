@@ -114,7 +114,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
                const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
                const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, uint32_t key_by_pos,
-               unsigned long long *__restrict__ evals)
+               const uint32_t *__restrict__ qbound, unsigned long long *__restrict__ evals)
 {
   constexpr int NQ = 4 * Q;      // queries per lane
   constexpr int NB = 64 * Q;     // queries per block
@@ -226,12 +226,22 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     qlo[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qlo[k])));
     qhi[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qhi[k])));
   }
-  for (int i = threadIdx.x; i < NB; i += 64 * W) sbest[i] = 0x7F800000u;   // +inf
+  // the per-query bounds start at +inf, or at a distance the caller KNOWS a point within (qbound: the reverse
+  // search of a matched target starts from the distance of the source point that matched it -- no blind first cells)
+  for (int i = threadIdx.x; i < NB; i += 64 * W) {
+    uint32_t seed = 0x7F800000u;
+    if (qbound) {
+      const uint32_t pos = b_begin + (uint32_t)i, at = pos < nq ? pos : b_begin;
+      const uint32_t v = qbound[qlist ? qlist[at] : (q_begin + at)];
+      if (v < seed) seed = v;       // (~0 = no bound)
+    }
+    sbest[i] = seed;
+  }
   __syncthreads();
   MVR_MARK(0);
 
   float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
-  bool U_stale = false;
+  bool U_stale = qbound != nullptr;       // seeded bounds: U is their maximum, derived when first needed
   uint32_t cells_done = 0, tiles_tested = 0;
 
   auto shared_bound = [&](int j) {
@@ -669,7 +679,7 @@ nn_cull_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
 {
   const CullPair &a = batch.p[blockIdx.y];
   nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
-                          a.keys, a.key_by_pos, evals);
+                          a.keys, a.key_by_pos, a.qbound, evals);
 }
 
 }  // namespace

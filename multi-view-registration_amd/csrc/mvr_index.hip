@@ -214,6 +214,20 @@ __global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint
   flags[tinv[j]] = 1;          // same value from every writer
 }
 
+// bound[sorted target position] = bits of the smallest forward d2 that matched the target (array preset to ~0)
+__global__ void seed_bounds_kernel(const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ qperm, size_t q_begin,
+                                   size_t q_count, double max2, const uint32_t *__restrict__ tinv, uint32_t *__restrict__ bound)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= q_count) return;
+  const size_t i = qperm ? qperm[q_begin + k] : (q_begin + k);
+  const nnkey_t key = keys[i];
+  const uint32_t j = (uint32_t)key;
+  if (j == kNone) return;
+  if ((double)__uint_as_float((uint32_t)(key >> 32)) > max2) return;
+  atomicMin(&bound[tinv[j]], (uint32_t)(key >> 32));
+}
+
 __global__ void flag_matched_batch_kernel(GlueBatch b)
 {
   const GluePair &a = b.p[blockIdx.y];
@@ -225,7 +239,9 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
   if (j == kNone) return;
   const float d2 = __uint_as_float((uint32_t)(key >> 32));
   if ((double)d2 > b.max2) return;
-  a.flags[a.tinv[j]] = 1;
+  // the reverse search of that target may start from this distance: the point that matched it is that close
+  if (a.bound) atomicMin(&a.bound[a.tinv[j]], (uint32_t)(key >> 32));
+  else a.flags[a.tinv[j]] = 1;
 }
 
 // ---- ordered compaction of the flags of ALL pairs of a batch (blockIdx.y = pair): count per 256-position chunk,
@@ -252,7 +268,7 @@ __global__ void __launch_bounds__(kChunk) count_flags_batch_kernel(GlueBatch b)
   const size_t pos = (size_t)blockIdx.x * kChunk + threadIdx.x;
   if ((size_t)blockIdx.x * kChunk >= a.nt) return;            // block-uniform
   unsigned total;
-  (void)chunk_rank(pos < a.nt && a.flags[pos] != 0, &total);
+  (void)chunk_rank(pos < a.nt && (a.bound ? a.bound[pos] != 0xFFFFFFFFu : a.flags[pos] != 0), &total);
   if (threadIdx.x == 0) a.chunks[blockIdx.x] = total;
 }
 
@@ -288,7 +304,7 @@ __global__ void __launch_bounds__(kChunk) compact_flags_batch_kernel(GlueBatch b
   const GluePair &a = b.p[blockIdx.y];
   const size_t pos = (size_t)blockIdx.x * kChunk + threadIdx.x;
   if ((size_t)blockIdx.x * kChunk >= a.nt) return;            // block-uniform
-  const bool f = pos < a.nt && a.flags[pos] != 0;
+  const bool f = pos < a.nt && (a.bound ? a.bound[pos] != 0xFFFFFFFFu : a.flags[pos] != 0);
   unsigned total;
   const unsigned r = chunk_rank(f, &total);
   if (f) { const unsigned at = a.chunks[blockIdx.x] + r; a.list[at] = (uint32_t)pos; a.slot[pos] = at; }
@@ -495,6 +511,18 @@ int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs)
   if (qmax == 0) return MVR_OK;
   ProfScope ps(c, MVR_K_GLUE, work);
   hipLaunchKernelGGL(flag_matched_batch_kernel, dim3((unsigned)((qmax + 255) / 256), (unsigned)n_pairs), dim3(256), 0, c->stream, b);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
+                       const uint32_t *tinv, size_t nt, uint32_t *bound)
+{
+  if (q_count == 0 || nt == 0) return MVR_OK;
+  ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count + 4.0 * (double)nt);
+  MVR_HIP_TRY(c, hipMemsetAsync(bound, 0xFF, nt * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(seed_bounds_kernel, dim3((unsigned)((q_count + 255) / 256)), dim3(256), 0, c->stream, keys, qperm, q_begin,
+                     q_count, max2, tinv, bound);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
