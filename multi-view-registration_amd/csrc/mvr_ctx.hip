@@ -290,6 +290,7 @@ API int mvr_ctx_create_on_stream(mvr_ctx **out, int device_id, void *hip_stream)
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_POSED_REFRESH")) c->posed_refresh = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PAIR_GROUPS")) c->pair_groups = std::max(1, std::min(8, std::atoi(m)));
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -611,6 +612,20 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     c->slots[dst[k]].coords_valid = false;
     c->slots[dst[k]].has_normals = false;
   }
+  if (c->nn_mode != 0 && c->posed_refresh) {
+    // culled search: the posed copies are about to be searched -- bring their index up to date here, from the
+    // sources' sorted copies (read in order) instead of a gather through the permutation at the first search
+    std::vector<Cloud *> d, s; std::vector<double> Ts;
+    for (int k = 0; k < count; ++k) {
+      if (!in[k] || dst[k] == src[k]) continue;
+      bool again = false;                                   // a slot written twice keeps its LAST pose: leave it to the lazy path
+      for (int j = 0; j < count; ++j) again |= (j != k && dst[j] == dst[k]);
+      for (int j = 0; j < count; ++j) again |= (dst[j] == src[k]);          // ... and so does a source that is also written
+      if (again) continue;
+      d.push_back(&c->slots[dst[k]]); s.push_back(&c->slots[src[k]]); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+    }
+    if (!d.empty()) { if (int rc = refresh_posed_batch(c, (int)d.size(), d.data(), s.data(), Ts.data())) return rc; }
+  }
   return MVR_OK;
 }
 
@@ -784,8 +799,10 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
 // on worker streams.  The pairs of one launch fill the chip together, so the tail of one pair's search is covered
 // by the others.  Same results as the one-pair calls, bit for bit.
 // c owns the clouds; w (c itself, or one of its workers) provides the stream and the work buffers.
+// phases: bit 0 = the forward searches, bit 1 = everything after them (so that the forward launches of several
+// groups can all be enqueued before any group's long tail of small launches).
 static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const int *dst, double max_dist, int reciprocal, int fma,
-                            const size_t *q_begin, const size_t *q_count, const double origin[3], double *table)
+                            const size_t *q_begin, const size_t *q_count, const double origin[3], double *table, int phases = 3)
 {
   std::vector<size_t> off_s((size_t)n_pairs + 1, 0), off_t((size_t)n_pairs + 1, 0), off_p((size_t)n_pairs + 1, 0), qb((size_t)n_pairs), qn((size_t)n_pairs);
   for (int k = 0; k < n_pairs; ++k) {
@@ -821,7 +838,8 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
     rev[k].qbound = w->bbound + off_t[k];      // a matched target has a source point at the forward distance: its search starts there
   }
-  if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+  if (phases & 1) { if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc; }
+  if (!(phases & 2)) return MVR_OK;
   const bool recip = reciprocal != 0;
   if (recip && off_t[n_pairs]) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, off_t[n_pairs] * sizeof(uint32_t), w->stream));
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
@@ -889,18 +907,21 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
       if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) status = set_error(c, MVR_E_HIP, "fork event");
       if (status == MVR_OK && hipEventRecord(c->ev_fork, c->stream) != hipSuccess) status = set_error(c, MVR_E_HIP, "fork");
       int forked = 0;
-      for (int g = G - 1; g >= 0 && status == MVR_OK; --g) {        // workers first, the caller's own group last
-        const int lo = (int)((long long)n_pairs * g / G), hi = (int)((long long)n_pairs * (g + 1) / G);
-        Ctx *w = c;
-        if (g > 0) {
-          if ((status = get_worker(c, (size_t)(g - 1), &w)) != MVR_OK) break;
-          if (hipStreamWaitEvent(w->stream, c->ev_fork, 0) != hipSuccess) { status = set_error(c, MVR_E_HIP, "fork"); break; }
-          forked = std::max(forked, g);
+      for (int phase = 1; phase <= 2; ++phase)                      // all forward searches first, then each group's remaining stages
+        for (int g = G - 1; g >= 0 && status == MVR_OK; --g) {      // workers first, the caller's own group last
+          const int lo = (int)((long long)n_pairs * g / G), hi = (int)((long long)n_pairs * (g + 1) / G);
+          Ctx *w = c;
+          if (g > 0) {
+            if ((status = get_worker(c, (size_t)(g - 1), &w)) != MVR_OK) break;
+            if (phase == 1) {
+              if (hipStreamWaitEvent(w->stream, c->ev_fork, 0) != hipSuccess) { status = set_error(c, MVR_E_HIP, "fork"); break; }
+              forked = std::max(forked, g);
+            }
+          }
+          status = pair_batch_fused(c, w, hi - lo, src + lo, dst + lo, max_dist, reciprocal, fma, q_begin ? q_begin + lo : nullptr,
+                                    q_count ? q_count + lo : nullptr, origin, table + (size_t)lo * 32, phase);
+          if (status != MVR_OK && w != c) c->last_error = w->last_error;
         }
-        status = pair_batch_fused(c, w, hi - lo, src + lo, dst + lo, max_dist, reciprocal, fma, q_begin ? q_begin + lo : nullptr,
-                                  q_count ? q_count + lo : nullptr, origin, table + (size_t)lo * 32);
-        if (status != MVR_OK && w != c) c->last_error = w->last_error;
-      }
       for (int g = 1; g <= forked; ++g) {                            // join, always
         Ctx *w = c->workers[(size_t)(g - 1)];
         if (w->ev_join && hipEventRecord(w->ev_join, w->stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, w->ev_join, 0);
@@ -1177,6 +1198,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
+  else if (!std::strcmp(key, "posed_refresh")) c->posed_refresh = value != 0;
   else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }
   else if (!std::strcmp(key, "inplace_ratio")) c->inplace_ratio = value;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);

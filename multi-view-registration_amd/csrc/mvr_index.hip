@@ -17,6 +17,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "mvr_internal.h"
@@ -133,6 +134,7 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
   const int cloud = blockIdx.y;
   const float4 *__restrict__ pts = rb.pts[cloud];
   const uint32_t *__restrict__ perm = rb.perm[cloud];
+  const float4 *__restrict__ from = rb.from[cloud];
   const size_t n = rb.n[cloud];
   float4 *__restrict__ sorted = rb.sorted[cloud], *__restrict__ tlo = rb.tlo[cloud], *__restrict__ thi = rb.thi[cloud],
          *__restrict__ cbox = rb.cbox[cloud];
@@ -146,9 +148,16 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};     // an empty cell is never needed
     const size_t k = base + r * 64 + lane;
     if (k < n) {
-      const uint32_t o = perm[k];
-      float4 v = pts[o];
-      v.w = __uint_as_float(o);
+      float4 v;
+      if (from) {                     // posed copy of an indexed cloud: pose its sorted copy, in order
+        const float4 p = from[k];
+        v = pose_point_f64(rb.T[cloud], p);
+        v.w = p.w;
+      } else {
+        const uint32_t o = perm[k];
+        v = pts[o];
+        v.w = __uint_as_float(o);
+      }
       sorted[k] = v;
       lo[0] = hi[0] = v.x; lo[1] = hi[1] = v.y; lo[2] = hi[2] = v.z;
     }
@@ -427,7 +436,8 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
   return MVR_OK;
 }
 
-static int refresh_batch(Ctx *c, Cloud *const *clouds, int count)
+// from / T: optional, per cloud (see RefreshBatch)
+static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *const *from = nullptr, const double *T = nullptr)
 {
   for (int base = 0; base < count; base += kBatchClouds) {
     RefreshBatch rb;
@@ -435,6 +445,8 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count)
     size_t tmax = 0; double work = 0.0;
     for (int k = 0; k < kBatchClouds; ++k) {
       Cloud *cl = k < m ? clouds[base + k] : nullptr;
+      rb.from[k] = (cl && from) ? from[base + k] : nullptr;
+      if (rb.from[k]) std::memcpy(rb.T[k].m, T + (size_t)(base + k) * 16, sizeof rb.T[k].m);
       rb.pts[k] = cl ? cl->pts : nullptr; rb.perm[k] = cl ? cl->order->perm : nullptr; rb.n[k] = cl ? cl->n : 0;
       rb.sorted[k] = cl ? cl->sorted : nullptr; rb.tlo[k] = cl ? cl->tlo : nullptr; rb.thi[k] = cl ? cl->thi : nullptr;
       rb.cbox[k] = cl ? cl->cbox : nullptr; rb.sbox[k] = cl ? cl->sbox : nullptr;
@@ -448,6 +460,25 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count)
     for (int k = 0; k < m; ++k) clouds[base + k]->coords_valid = true;
   }
   return MVR_OK;
+}
+
+int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T)
+{
+  std::vector<Cloud *> todo; std::vector<const float4 *> from; std::vector<double> Ts;
+  for (int k = 0; k < count; ++k) {
+    Cloud *d = dst[k], *s = src[k];
+    if (!d || !s || d == s || d->n == 0 || d->n != s->n || d->set_id != s->set_id) continue;
+    if (std::find(todo.begin(), todo.end(), d) != todo.end()) continue;      // posed twice in one call: the lazy refresh sorts it out
+    // A point set without an ordering gets it from the POSED copy: cells are compact boxes in the frame the order
+    // was built in, and the search runs in the posed frame (an order built in the raw sensor frame, rotated by the
+    // pose, inflates every box: measured 15 % more distance evaluations on the turntable ring).
+    bool stale = false;
+    if (int rc = prepare_index(c, *d, &stale)) return rc;   // ordering (shared by all copies of the set) + buffers
+    if (int rc = ensure_index(c, *s)) return rc;            // the source's sorted copy: gathered once, then reused every pose
+    if (!stale || d->order != s->order) continue;
+    todo.push_back(d); from.push_back(s->sorted); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+  }
+  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data());
 }
 
 int ensure_index(Ctx *c, Cloud &cl)

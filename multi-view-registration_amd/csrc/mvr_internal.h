@@ -132,6 +132,7 @@ struct Ctx {
   double *bpartials = nullptr; size_t bpartials_cap = 0;
   int inplace_ratio = 3;                              // culled reverse search in place (flags) when nt < ratio * queries, else compacted list
   int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
+  int posed_refresh = 1;                              // mvr_cloud_transform_batch brings the posed copies' index up to date from the sources' sorted copies
   int pair_groups = 2;                                // fused pass: groups of pairs on concurrent streams (1: a single stream); measured on the 12-pair ring: 1.27 / 1.22 / 1.28 / 1.39 ms per step with 1 / 2 / 3 / 4
   // instrumentation
   bool prof = false;
@@ -187,10 +188,28 @@ int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
 constexpr int kBatchClouds = 16;
 struct Mat44d { double m[16]; };
 struct XformBatch { const float4 *src[kBatchClouds]; float4 *dst[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; };
+// p' = T p as mvr_cloud_transform (f64 pose, f32 result): the ONE definition, shared by the transform kernels
+// and by the index refresh that poses a scan's sorted copy directly (same operations, same bits)
+__device__ __forceinline__ float4 pose_point_f64(const Mat44d &T, const float4 p)
+{
+  const double x = p.x, y = p.y, z = p.z;
+  const double d = 1.0 / (((T.m[3] * x + T.m[7] * y) + T.m[11] * z) + T.m[15]);
+  float4 o;
+  o.x = (float)((((T.m[0] * x + T.m[4] * y) + T.m[8] * z) + T.m[12]) * d);
+  o.y = (float)((((T.m[1] * x + T.m[5] * y) + T.m[9] * z) + T.m[13]) * d);
+  o.z = (float)((((T.m[2] * x + T.m[6] * y) + T.m[10] * z) + T.m[14]) * d);
+  o.w = 1.0f;
+  return o;
+}
 struct RefreshBatch {
   const float4 *pts[kBatchClouds]; const uint32_t *perm[kBatchClouds]; unsigned long long n[kBatchClouds];
   float4 *sorted[kBatchClouds], *tlo[kBatchClouds], *thi[kBatchClouds], *cbox[kBatchClouds], *sbox[kBatchClouds];
+  // optional: the sorted copy of the cloud this one is a posed copy of (same ordering) and the pose -- the refresh
+  // then reads that copy in order and poses it, instead of gathering pts[] through the permutation
+  const float4 *from[kBatchClouds]; Mat44d T[kBatchClouds];
 };
+// index of posed copies, straight from the sources' sorted copies (culled mode; called by mvr_cloud_transform_batch)
+int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T);
 int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T);
 int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count);     // ensure_index for many clouds, coordinates refreshed in one launch
 

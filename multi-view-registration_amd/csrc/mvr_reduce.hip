@@ -170,15 +170,7 @@ __global__ void transform_f64_batch_kernel(XformBatch b)
   const int k = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n[k]) return;
-  const Mat44d &T = b.T[k];
-  const float4 p = b.src[k][i];
-  const double x = p.x, y = p.y, z = p.z;
-  const double d = 1.0 / (((T.m[3] * x + T.m[7] * y) + T.m[11] * z) + T.m[15]);
-  float4 o;
-  o.x = (float)((((T.m[0] * x + T.m[4] * y) + T.m[8] * z) + T.m[12]) * d);
-  o.y = (float)((((T.m[1] * x + T.m[5] * y) + T.m[9] * z) + T.m[13]) * d);
-  o.z = (float)((((T.m[2] * x + T.m[6] * y) + T.m[10] * z) + T.m[14]) * d);
-  o.w = 1.0f;
+  const float4 o = pose_point_f64(b.T[k], b.src[k][i]);
   b.dst[k][i] = o;
 }
 

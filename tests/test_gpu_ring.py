@@ -109,3 +109,38 @@ def test_transform_batch_equals_single_transforms(gpu, mvr):
     a = gpu.pair_moments2(20, 21, 8.0, np.zeros(3))
     b = gpu.pair_moments2(0, 1, 8.0, np.zeros(3))
     assert bytes(a) == bytes(b) and a.n > 100
+
+
+def test_posed_index_refresh_equals_lazy_refresh(gpu, mvr):
+    """In culled mode mvr_cloud_transform_batch also brings the posed copies' index up to date, straight from the
+    sources' sorted copies (tune key posed_refresh).  Same searches, bit for bit, as the lazy gather refresh --
+    over repeated re-posing, in place, and for a posed copy of a posed copy."""
+    g = load_golden("ring_12x2048.npz")
+    scans, poses0 = list(g["scans"]), list(g["poses0"])
+    V = 6
+    origin = np.array(mvr.synth_params(12, 3).pivot)
+    pairs = [(v, (v + 1) % V) for v in range(V)]
+    nudge = np.eye(4); nudge[:3, 3] = (0.3, -0.2, 0.1); nudge[0, 1], nudge[1, 0] = -0.01, 0.01
+    outs = []
+    try:
+        for flag in (0, 1):
+            gpu.tune(posed_refresh=flag)
+            rec = []
+            for v in range(V):
+                gpu.upload(20 + v, scans[v][: 2048 - 11 * v])            # fresh point sets: the ordering is rebuilt
+            gpu.transform_batch(list(range(V)), [20 + v for v in range(V)], poses0[:V])
+            rec += [bytes(m) for m in gpu.pair_moments2_batch(pairs, 8.0, origin)]
+            gpu.transform_batch(list(range(V)), [20 + v for v in range(V)], [nudge @ p for p in poses0[:V]])     # re-posed: orders and source copies reused
+            rec += [bytes(m) for m in gpu.pair_moments2_batch(pairs, 8.0, origin)]
+            gpu.transform_batch([9, 8], [20, 21], [poses0[0], poses0[1]])
+            gpu.transform_batch([9], [9], [nudge])                       # in place: the lazy refresh
+            rec.append(bytes(gpu.pair_moments2(9, 8, 8.0, origin)))
+            rec.append(gpu.download(9).tobytes())
+            gpu.transform_batch([7], [0], [nudge])                       # a posed copy of a posed copy
+            rec.append(bytes(gpu.pair_moments2(7, 1, 8.0, origin)))
+            idx, d2 = gpu.nn(7, 1)
+            rec += [idx.tobytes(), d2.tobytes()]
+            outs.append(rec)
+    finally:
+        gpu.tune(posed_refresh=1)
+    assert outs[0] == outs[1]
