@@ -249,8 +249,13 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
   const float d2 = __uint_as_float((uint32_t)(key >> 32));
   if ((double)d2 > b.max2) return;
   // the reverse search of that target may start from this distance: the point that matched it is that close
-  if (a.bound) atomicMin(&a.bound[a.tinv[j]], (uint32_t)(key >> 32));
-  else a.flags[a.tinv[j]] = 1;
+  if (a.bound) {
+    // (most targets are matched once, or by a closer point first: look before paying for the atomic; a stale
+    // read only means an atomic that was not needed)
+    uint32_t *slot = &a.bound[a.tinv[j]];
+    const uint32_t bits = (uint32_t)(key >> 32);
+    if (bits < __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMin(slot, bits);
+  } else a.flags[a.tinv[j]] = 1;
 }
 
 // ---- ordered compaction of the flags of ALL pairs of a batch (blockIdx.y = pair): count per 256-position chunk,
