@@ -264,6 +264,18 @@ int  mvr_lum_compute(int n, int ne, const int *edge_src, const int *edge_tgt,
 int  mvr_ring_host_step(int n_views, int ne, const int *edge_src, const int *edge_tgt, const double *rows,
                         const double origin[3], int lum_iterations, double *poses, double *lum_pose,
                         float *pair_T, double *pair_n, double *pair_mse, int *lum_iters);
+/* One outer pass of Registrator::registrationLUM (registrator.cpp:625-664) in ONE call, for a single process:
+ *   posed_slots[v] <- poses[v] applied to raw_slots[v]            (mvr_cloud_transform_batch)
+ *   per edge e: reciprocal correspondences of posed[edge_src[e]] in posed[edge_tgt[e]] + raw moments
+ *                                                                 (mvr_pair_moments2_batch)
+ *   host: per-pair Umeyama + residual, LUM::compute, pose_v <- LUM_v * pose_v   (mvr_ring_host_step)
+ * edge_src / edge_tgt are VIEW indices (0..n_views-1).  poses: n_views x 16 column-major, in/out.  Optional
+ * outputs (may be NULL): rows (ne x 32, the edge table as mvr_pair_moments2_dev lays it out), pair_T (ne x 16),
+ * timing_ms[3] = {enqueue, wait for the GPU + copy of the table, host solve}.  Synchronises the context's stream. */
+int  mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
+                   const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
+                   double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters,
+                   double *rows, double *timing_ms);
 /* pcl::getTransformation(x,y,z,roll,pitch,yaw) -> column-major 4x4. */
 void mvr_pose_to_mat4(const double pose[6], double T[16]);
 

@@ -148,6 +148,9 @@ SIGNATURES = {
                                   C.POINTER(C.c_int)]),
     "mvr_ring_host_step": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.c_int,
                                      _dp, _dp, _fp, _dp, _dp, C.POINTER(C.c_int)]),
+    "mvr_ring_step": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                                C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
+                                C.POINTER(C.c_int), _dp, _dp]),
     "mvr_pose_to_mat4": (None, [_dp, _dp]),
     "mvr_turntable_angle": (C.c_double, [C.c_int, C.c_int]),
     "mvr_axis_rotation": (None, [_dp, _dp, C.c_double, _dp]),
@@ -468,6 +471,31 @@ class Context:
         T = np.ascontiguousarray(np.stack([to_cm(p, np.float64).reshape(16) for p in poses]) if n else np.zeros((0, 16)),
                                  np.float64)
         _chk(_lib.mvr_cloud_transform_batch(self._h, n, d, s, _p(T, C.c_double)), self._h)
+
+    def ring_step(self, posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=16, reciprocal=True, fma=False):
+        """mvr_ring_step: one outer pass of registrationLUM in one native call (single process).  edges: [(src view,
+        tgt view)]; poses: list of (4,4) float64.  Returns (new poses, info) like ring_host_step, plus info["rows"]
+        (ne x 32 edge table) and info["timing_ms"] = (enqueue, GPU wait + copy, host solve)."""
+        V, ne = len(posed_slots), len(edges)
+        key = (tuple(posed_slots), tuple(raw_slots), tuple(edges))
+        st = getattr(self, "_ring_static", None)
+        if st is None or st[0] != key:                      # the slot / edge arrays of a registration never change
+            st = (key, (C.c_int * V)(*[int(v) for v in posed_slots]), (C.c_int * V)(*[int(v) for v in raw_slots]),
+                  (C.c_int * ne)(*[int(e[0]) for e in edges]), (C.c_int * ne)(*[int(e[1]) for e in edges]))
+            self._ring_static = st
+        _, ps, rs, es, et = st
+        # (4,4) column-vector matrices <-> the library's column-major 16-vectors: one transpose for all views
+        P = np.ascontiguousarray(np.asarray(poses, np.float64).transpose(0, 2, 1)).reshape(V, 16)
+        o = np.ascontiguousarray(origin, np.float64)
+        lum, rows, tm = np.zeros((V, 6)), np.empty((ne, 32)), np.zeros(3)
+        pT, pn, pm, its = np.empty((ne, 16), np.float32), np.empty(ne), np.empty(ne), C.c_int()
+        _chk(_lib.mvr_ring_step(self._h, V, ps, rs, ne, es, et, float(max_dist), int(reciprocal), int(fma), _p(o, C.c_double),
+                                int(lum_iterations), _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float), _p(pn, C.c_double),
+                                _p(pm, C.c_double), C.byref(its), _p(rows, C.c_double), _p(tm, C.c_double)), self._h)
+        new = list(np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1)))
+        info = dict(pair_T=list(np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1))), pair_n=pn.tolist(),
+                    pair_mse=pm.tolist(), lum_pose=lum, lum_iterations=its.value, rows=rows, timing_ms=tuple(tm.tolist()))
+        return new, info
 
     def pair_moments2_batch(self, pairs, max_dist, origin, dev_ptr=None, reciprocal=True, fma=False, ranges=None):
         """All scan pairs of one global iteration in one call: one launch per stage for all pairs (culled

@@ -970,6 +970,43 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
   return MVR_OK;
 }
 
+// One outer pass of registrationLUM without a host language in between (the Python / C++ drivers spend a tenth
+// of a 1.2 ms step on their own bookkeeping between the three calls this chains).
+API int mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
+                      const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
+                      double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters,
+                      double *rows, double *timing_ms)
+{
+  if (!ctx || n_views < 2 || ne < 0 || !posed_slots || !raw_slots || (ne && (!edge_src || !edge_tgt)) || !origin || !poses || !lum_pose)
+    return MVR_E_ARG;
+  for (int e = 0; e < ne; ++e) if (edge_src[e] < 0 || edge_src[e] >= n_views || edge_tgt[e] < 0 || edge_tgt[e] >= n_views) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  if (int rc = mvr_cloud_transform_batch(ctx, n_views, posed_slots, raw_slots, poses)) return rc;
+  std::vector<int> ss((size_t)ne), ts((size_t)ne);
+  for (int e = 0; e < ne; ++e) { ss[e] = posed_slots[edge_src[e]]; ts[e] = posed_slots[edge_tgt[e]]; }
+  if (int rc = ensure(c, c->batch_table, c->batch_cap, (size_t)std::max(ne, 1) * 32)) return rc;
+  if (ne) { if (int rc = mvr_pair_moments2_batch(ctx, ne, ss.data(), ts.data(), max_dist, reciprocal, fma, nullptr, nullptr, origin, nullptr, c->batch_table)) return rc; }
+  const auto t1 = clk::now();
+  std::vector<double> h((size_t)ne * 32);
+  if (ne) MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), c->batch_table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const auto t2 = clk::now();
+  if (rows && ne) std::memcpy(rows, h.data(), h.size() * sizeof(double));
+  std::vector<double> pn((size_t)ne), pm((size_t)ne);
+  const int rc = mvr_ring_host_step(n_views, ne, edge_src, edge_tgt, h.data(), origin, lum_iterations, poses, lum_pose, pair_T,
+                                    pair_n ? pair_n : pn.data(), pair_mse ? pair_mse : pm.data(), lum_iters);
+  const auto t3 = clk::now();
+  if (timing_ms) {
+    timing_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    timing_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    timing_ms[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  }
+  if (rc != MVR_OK) return set_error(c, rc, "LUM solve");
+  return MVR_OK;
+}
+
 // ---- target sharding over ranks (sequential mode): forward keys out, reduced keys in ----
 API int mvr_nn_forward_keys(mvr_ctx *ctx, int ss, int ts, double max_dist, int fma, long long *dev_keys)
 {

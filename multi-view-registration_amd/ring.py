@@ -21,6 +21,8 @@ plug the CPU oracle in from tests/, the product never does.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import Context, ring_host_step
@@ -96,13 +98,18 @@ class HipBackend:
         with self._on_stream():
             return table.cpu().numpy()
 
+    def fused_step(self, edges, poses, max_dist, origin, lum_iterations):
+        """the whole step in one native call (mvr_ring_step): single process only, every edge whole"""
+        return self.ctx.ring_step(list(range(self.V)), [self.V + v for v in range(self.V)], edges, poses, max_dist, origin,
+                                  lum_iterations=lum_iterations, reciprocal=True, fma=self.fma)
+
     def close(self):
         self.ctx.close()
 
 
 class RingLUM:
     def __init__(self, backend, n_views, sizes, max_dist, origin, rank=0, world=1, all_reduce=None,
-                 lum_iterations=16):
+                 lum_iterations=16, fused=True):
         self.b, self.V = backend, n_views
         self.edges = ring_edges(n_views)
         self.max_dist, self.origin = float(max_dist), np.asarray(origin, np.float64)
@@ -110,6 +117,7 @@ class RingLUM:
         if world > 1 and all_reduce is None:
             raise ValueError("world > 1 needs an all_reduce callable")
         self.lum_iterations = lum_iterations
+        self.fused = fused            # world == 1: use the backend's one-call step when it has one
         # edge e's queries are the points of its SOURCE view
         self.segments = split_queries([sizes[s] for s, _ in self.edges], world, rank)
         self.views_needed = sorted({v for e, _, _ in self.segments for v in self.edges[e]})
@@ -119,6 +127,15 @@ class RingLUM:
         """poses: list of V (4,4) float64 column-vector poses -> new list."""
         import time
         b = self.b
+        if self.world == 1 and self.fused and hasattr(b, "fused_step") and os.environ.get("MVR_RING_FUSED", "1") != "0":
+            # single process: posing, searches, reductions, copy of the table and the host solve in ONE native call
+            new, info = b.fused_step(self.edges, poses, self.max_dist, self.origin, self.lum_iterations)
+            n = float(sum(info["pair_n"]))
+            tm = info["timing_ms"]
+            self.last = dict(info, n_corr=n,
+                             mse=(sum(a * c for a, c in zip(info["pair_n"], info["pair_mse"])) / n) if n else 0.0,
+                             ms_enqueue=tm[0], ms_drain=tm[1], ms_host_solve=tm[2])
+            return new
         t0 = time.perf_counter()
         b.pose_clouds(poses, self.views_needed)     # only the scans this rank's segments touch
         table = b.edge_rows(self.segments, self.edges, self.max_dist, self.origin)

@@ -38,6 +38,32 @@ def test_ring_step_matches_oracle_lum_pass(mvr, ring):
         be.close()
 
 
+def test_one_call_step_equals_three_call_step(mvr, ring):
+    """mvr_ring_step (posing, searches, reductions, table copy and host solve in one native call) walks exactly the
+    poses of the step driven from Python through mvr_cloud_transform_batch / mvr_pair_moments2_batch /
+    mvr_ring_host_step, over several outer passes."""
+    g = load_golden("ring_12x2048.npz")
+    scans, poses0 = list(g["scans"]), list(g["poses0"])
+    origin = np.array(mvr.synth_params(12, 3).pivot)
+    runs = []
+    for fused in (True, False):
+        be = ring.HipBackend(scans, device=0)
+        try:
+            r = ring.RingLUM(be, 12, [len(s) for s in scans], 8.0, origin, fused=fused)
+            poses, log = [p.copy() for p in poses0], []
+            for _ in range(3):
+                poses = r.step(poses)
+                log.append((np.stack(poses).tobytes(), [int(n) for n in r.last["pair_n"]], r.last["lum_iterations"],
+                            np.asarray(r.last["lum_pose"]).tobytes(), float(r.last["mse"])))
+            if fused:
+                assert r.last["rows"].shape == (12, 32) and [int(x) for x in r.last["rows"][:, 0]] == log[-1][1]
+                assert all(t >= 0 for t in r.last["timing_ms"])
+            runs.append(log)
+        finally:
+            be.close()
+    assert runs[0] == runs[1]
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_fake_world_partition_sums_to_unsharded(mvr, ring, world):
     g = load_golden("ring_12x2048.npz")
