@@ -147,6 +147,33 @@ int invert6(const double A[36], double Ainv[36])
   return MVR_OK;
 }
 
+// x = A^-1 b for one right-hand side: elimination with partial pivoting on the 6 x 7 augmented matrix (a
+// quarter of the arithmetic of forming the inverse; the LUM loop solves one such system per edge and per vertex
+// in every iteration)
+int solve6(const double A[36], const double b[6], double x[6])
+{
+  double W[6][7];
+  for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) W[r][c] = A[6 * r + c]; W[r][6] = b[r]; }
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < 6; ++r) if (std::fabs(W[r][k]) > std::fabs(W[piv][k])) piv = r;
+    if (W[piv][k] == 0.0) return MVR_E_SINGULAR;
+    if (piv != k) for (int c = k; c < 7; ++c) std::swap(W[k][c], W[piv][c]);
+    const double inv = 1.0 / W[k][k];
+    for (int r = k + 1; r < 6; ++r) {
+      const double f = W[r][k] * inv;
+      if (f == 0.0) continue;
+      for (int c = k + 1; c < 7; ++c) W[r][c] -= f * W[k][c];
+    }
+  }
+  for (int k = 5; k >= 0; --k) {
+    double s = W[k][6];
+    for (int c = k + 1; c < 6; ++c) s -= W[k][c] * x[c];
+    x[k] = s / W[k][k];
+  }
+  return MVR_OK;
+}
+
 // Extension (K10): pcl::registration::TransformationEstimationPointToPlaneLLS --
 // x = (A^T A)^-1 A^T b with x = (alpha, beta, gamma, tx, ty, tz), then
 // constructTransformationMatrix: R = Rz(gamma) Ry(beta) Rx(alpha), t.
@@ -350,9 +377,8 @@ API int mvr_lum_edge_from_moments(const mvr_pair_moments2_t *m2, const double po
   MZ[3] = Sxd(1, 2) - Sxd(2, 1);   // sum (y dz - z dy)
   MZ[4] = Sxd(0, 1) - Sxd(1, 0);   // sum (x dy - y dx)
   MZ[5] = Sxd(2, 0) - Sxd(0, 2);   // sum (z dx - x dz)
-  double Minv[36], D[6] = {0, 0, 0, 0, 0, 0};
-  if (invert6(MM, Minv) != MVR_OK) { *ss = NAN; return MVR_OK; }
-  for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) D[r] += Minv[6 * r + c] * MZ[c];
+  double D[6] = {0, 0, 0, 0, 0, 0};
+  if (solve6(MM, MZ, D) != MVR_OK) { *ss = NAN; return MVR_OK; }      // D = MM^-1 MZ
   // residual e = diff - Dt - C av, C = [[0,-D4,D5],[D4,0,-D3],[-D5,D3,0]]; in
   // the shifted frame e = diff - (Dt + C o) - C av'
   M3 Cm = zero3();
@@ -447,14 +473,10 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     if (solve_spd(dim, G.data(), B.data(), row_end.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
     double sum = 0.0;
     for (int vi = 1; vi < n; ++vi) {
-      double inc[36], incinv[36], dp[6], nrm = 0.0;
+      double inc[36], sol[6], dp[6], nrm = 0.0;
       lum_incidence(poses + 6 * vi, inc);
-      if (invert6(inc, incinv) != MVR_OK) continue;
-      for (int r = 0; r < 6; ++r) {
-        double s = 0.0;
-        for (int c = 0; c < 6; ++c) s += incinv[6 * r + c] * B[6 * (vi - 1) + c];
-        dp[r] = -s; nrm += s * s;
-      }
+      if (solve6(inc, &B[6 * (vi - 1)], sol) != MVR_OK) continue;       // incidence^-1 * X_vi
+      for (int r = 0; r < 6; ++r) { dp[r] = -sol[r]; nrm += sol[r] * sol[r]; }
       sum += std::sqrt(nrm);
       for (int r = 0; r < 6; ++r) poses[6 * vi + r] += dp[r];
     }
