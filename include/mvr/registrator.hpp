@@ -318,12 +318,9 @@ class Registrator {
       const PCLPoint &p = model_->getPointCloud(object, 0).points.points[0];
       origin[0] = p.x; origin[1] = p.y; origin[2] = p.z;
     }
-    std::vector<int> slot_src((size_t)V), slot_tgt((size_t)V);
-    for (int e = 0; e < V; ++e) { slot_src[e] = posed_s[es[e]]; slot_tgt[e] = posed_s[et[e]]; }
     const int lum_max_iterations = 16;
     const int outer_loop_num = std::max(1, max_iterations / lum_max_iterations);
     std::vector<double> poses((size_t)V * 16), rows((size_t)V * 32), pair_n((size_t)V), pair_mse((size_t)V), lum_pose((size_t)V * 6);
-    std::vector<mvr_pair_moments2_t> m2((size_t)V);
     for (int loop = 0; loop < outer_loop_num; ++loop) {
       for (int v = 0; v < V; ++v) {
         ScanCloud &pc = model_->getPointCloud(object, v);
@@ -331,16 +328,11 @@ class Registrator {
         pc.setRegisterState(true);
         std::memcpy(&poses[(size_t)v * 16], pc.getMatrix().asColumnMajorColumnVector(), 16 * sizeof(double));
       }
-      d.check(mvr_cloud_transform_batch(d.ctx(), V, posed_s.data(), raw_s.data(), poses.data()), "mvr_cloud_transform_batch");
-      d.check(mvr_pair_moments2_batch(d.ctx(), V, slot_src.data(), slot_tgt.data(), max_distance, 1, 0, nullptr, nullptr, origin,
-                                      m2.data(), nullptr), "mvr_pair_moments2_batch");
-      for (int e = 0; e < V; ++e) {
-        std::memset(&rows[(size_t)e * 32], 0, 32 * sizeof(double));
-        std::memcpy(&rows[(size_t)e * 32], &m2[e], sizeof(mvr_pair_moments2_t));
-      }
+      // posing, reciprocal correspondences + moments of every ring edge, table copy and the LUM solve: one native call
       int iters = 0;
-      d.check(mvr_ring_host_step(V, V, es.data(), et.data(), rows.data(), origin, lum_max_iterations, poses.data(), lum_pose.data(),
-                                 nullptr, pair_n.data(), pair_mse.data(), &iters), "mvr_ring_host_step");
+      d.check(mvr_ring_step(d.ctx(), V, posed_s.data(), raw_s.data(), V, es.data(), et.data(), max_distance, 1, 0, origin,
+                            lum_max_iterations, poses.data(), lum_pose.data(), nullptr, pair_n.data(), pair_mse.data(), &iters,
+                            rows.data(), nullptr), "mvr_ring_step");
       lum_ncorr.clear();
       for (int e = 0; e < V; ++e) lum_ncorr.push_back((int)pair_n[e]);
       for (int v = 0; v < V; ++v) {
