@@ -475,7 +475,8 @@ class Context:
     def ring_step(self, posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=16, reciprocal=True, fma=False):
         """mvr_ring_step: one outer pass of registrationLUM in one native call (single process).  edges: [(src view,
         tgt view)]; poses: list of (4,4) float64.  Returns (new poses, info) like ring_host_step, plus info["rows"]
-        (ne x 32 edge table) and info["timing_ms"] = (enqueue, GPU wait + copy, host solve)."""
+        (ne x 32 edge table) and info["timing_ms"] = (enqueue, GPU wait + copy, host solve).  poses may be a list of
+        (4,4) arrays or one (V,4,4) array; the new poses come back as a (V,4,4) array."""
         V, ne = len(posed_slots), len(edges)
         key = (tuple(posed_slots), tuple(raw_slots), tuple(edges))
         st = getattr(self, "_ring_static", None)
@@ -492,8 +493,8 @@ class Context:
         _chk(_lib.mvr_ring_step(self._h, V, ps, rs, ne, es, et, float(max_dist), int(reciprocal), int(fma), _p(o, C.c_double),
                                 int(lum_iterations), _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float), _p(pn, C.c_double),
                                 _p(pm, C.c_double), C.byref(its), _p(rows, C.c_double), _p(tm, C.c_double)), self._h)
-        new = list(np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1)))
-        info = dict(pair_T=list(np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1))), pair_n=pn.tolist(),
+        new = np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1))        # (V,4,4): indexable like the list that came in
+        info = dict(pair_T=np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1)), pair_n=pn.tolist(),
                     pair_mse=pm.tolist(), lum_pose=lum, lum_iterations=its.value, rows=rows, timing_ms=tuple(tm.tolist()))
         return new, info
 
