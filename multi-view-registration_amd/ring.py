@@ -127,7 +127,8 @@ class RingLUM:
         """poses: list of V (4,4) float64 column-vector poses -> new list."""
         import time
         b = self.b
-        if self.world == 1 and self.fused and hasattr(b, "fused_step") and os.environ.get("MVR_RING_FUSED", "1") != "0":
+        if (self.world == 1 and self.all_reduce is None and self.fused and hasattr(b, "fused_step")
+                and os.environ.get("MVR_RING_FUSED", "1") != "0"):
             # single process: posing, searches, reductions, copy of the table and the host solve in ONE native call
             new, info = b.fused_step(self.edges, poses, self.max_dist, self.origin, self.lum_iterations)
             n = float(sum(info["pair_n"]))
