@@ -6,33 +6,37 @@
 // from PCL/FLANN (tree_->nearestKSearch inside icp.align, registrator.cpp:569,
 // and inside determineReciprocalCorrespondences, :502/:649).
 //
-// One BLOCK = one set of 64*Q Hilbert-consecutive queries, held by all 4 waves;
-// wave w owns the target tiles with (tile & 3) == w, so the serial chain of
-// tiles a query set has to visit is cut four ways.  The waves share nothing
-// but a per-query "best so far" in LDS (ds_min_u32 on the float bits, read
-// without a barrier: it only ever decreases, a stale value merely prunes less)
-// and meet once, at the end, to combine their partial results.
+// One BLOCK = one set of 64*Q Hilbert-consecutive queries, held by W waves (template parameter: 1, 2 or 4);
+// wave w owns the target tiles with tile mod W == w, so the serial chain of tiles a query set has to visit
+// is cut W ways.  The waves share nothing but a per-query "best so far" in LDS (ds_min_u32 on the float
+// bits, read without a barrier: it only ever decreases, a stale value merely prunes less) and meet once, at
+// the end, to combine their partial results.  A lone launch is bound by its longest chain and likes W = 2;
+// a launch that keeps the chip full (the fused pass: all scan pairs of a step, blockIdx.y = pair) does the
+// same work with fewer, better filled passes at W = 1.
 //
-// Inside a wave the 64 lanes are 4 GROUPS of 16: every group holds the SAME
-// 64*Q queries (4*Q per lane) and evaluates them against its own quarter of
-// the staged 256-target tile.  One ds_read_b128 therefore feeds 4*Q distance
-// evaluations per lane instead of Q: with one query per lane (the first
-// version of this kernel) the LDS pipe was the busiest unit of the CU (in-kernel
-// cycle stamps, tools/build_stamp.sh: 25k cycles per tile against 4.4k of VALU
-// work).  The four groups read four different addresses; the group regions
+// Inside a wave the 64 lanes are 4 GROUPS of 16: every group holds the SAME 64*Q queries (4*Q per lane)
+// and evaluates them against its own 64-point CELL staged in LDS.  One ds_read_b128 therefore feeds 4*Q
+// distance evaluations per lane instead of Q: with one query per lane (the first version of this kernel)
+// the LDS pipe was the busiest unit of the CU (in-kernel cycle stamps, tools/build_stamp.sh: 25k cycles
+// per tile against 4.4k of VALU work).  The four groups read four different addresses; the group regions
 // are 65 float4 apart so that they fall into disjoint LDS banks.
 //
-// Culling is two-level.  A 256-point tile is looked at only if SOME query of
-// the set can still find an equal-or-closer point inside the tile's box (exact
-// per-query point/box test with a 1e-5 relative safety margin for the rounding
-// of the box distance); the same test then runs on the boxes of the tile's four
-// 64-point CELLS, and only the cells that pass are queued.  The wave evaluates
-// four queued cells at a time, one per lane group, wherever they come from
-// (tools/cull_model.py: 64-point boxes need 2.3x fewer evaluations than 256-point
-// ones on the turntable pair).  Every point that could win or tie is still
-// evaluated: results stay exact.  The inner loop is the brute-force one (min3
-// tracking per 32-target sub-tile); the index is recovered once, at the very end,
-// by a re-scan of the winning sub-tile that the 4 lane groups share (8 points each).
+// Culling is three-level: super boxes (64 tiles) decide which blocks of tile boxes are loaded at all; a
+// 256-point tile is looked at only if SOME query of the set can still find an equal-or-closer point inside
+// the tile's box (exact per-query point/box test with a 1e-5 relative safety margin for the rounding of the
+// box distance); the same test then runs on the boxes of the tile's four 64-point cells, one cell per lane
+// group, and only the cells that pass are queued.  The wave evaluates four queued cells at a time, one per
+// lane group, wherever they come from (tools/cull_model.py: 64-point boxes need 2.3x fewer evaluations than
+// 256-point ones on the turntable pair); the next four are prefetched into registers meanwhile and
+// re-validated against the new bounds before they are staged.  Every point that could win or tie is still
+// evaluated: results stay exact.  The inner loop is the brute-force one (min tracking per 32-target
+// sub-tile); the index is recovered once, at the very end, by a re-scan of the winning sub-tile that the 4
+// lane groups share (8 points each).
+//
+// A query may come with a KNOWN bound (qbound): the reverse search of a matched target starts from the
+// distance of the source point that matched it, so its first cells are not chosen blind.  Keys go to the
+// query's original index, to its list / sorted position (compacted or flagged queries), or -- key_by_pos,
+// the fused pass -- to its absolute sorted position, so that every consumer reads them coalesced.
 // Compiled with -ffp-contract=off.
 #include "mvr_internal.h"
 

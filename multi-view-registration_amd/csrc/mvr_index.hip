@@ -5,14 +5,20 @@
 // inside icp.align, registrator.cpp:569, and inside determineReciprocalCorrespondences, :502/:649):
 //  * every cloud keeps a Hilbert-ordered copy of its points (w = bits of the original index).  The
 //    ORDER belongs to the point set and is shared by all posed copies of a scan, so it is built once
-//    (bbox -> 30-bit Hilbert codes -> hipCUB radix sort -> perm / inv);
+//    (bbox -> 30-bit Hilbert codes -> hipCUB radix sort -> perm / inv) -- from the first POSED copy that is
+//    searched, not from the raw scan: cells are compact in the frame the codes were computed in, and a
+//    rotation between that frame and the frame of the search inflates every box (+15 % evaluations measured);
 //  * three levels of AABBs over that order, always computed from the CURRENT coordinates (the order
 //    only affects speed): one box per 64-point cell (cbox, a 128-byte record per tile), one per
 //    256-point tile (tlo / thi), one per 64 consecutive tiles (sbox);
 //  * after a rigid motion only the sorted copy and the boxes are refreshed: two launches for all the
-//    views of a global iteration (refresh_sorted_kernel / super_box_kernel, blockIdx.y = cloud);
-//  * the reciprocal glue of the culled mode: flag matched targets in sorted space, ordered compaction
-//    (hipCUB DeviceSelect) into the query list of the reverse search.
+//    views of a global iteration (refresh_sorted_kernel / super_box_kernel, blockIdx.y = cloud).  A posed
+//    copy made by mvr_cloud_transform_batch is refreshed right there, by posing the SOURCE's sorted copy in
+//    order (refresh_posed_batch) instead of gathering the posed points through the permutation;
+//  * the reciprocal glue of the culled mode: flag matched targets in sorted space -- or record the smallest
+//    matching d2 per target, the bound its reverse search starts from (seed_bounds / flag_matched_batch) --
+//    and their ordered compaction (hipCUB DeviceSelect, or count / scan / scatter per 256-position chunk for
+//    all pairs of a fused pass) into the query list of the reverse search.
 // Compiled with -ffp-contract=off.
 #include <hipcub/hipcub.hpp>
 

@@ -55,6 +55,24 @@ def test_ctx_create_fails_loudly_without_gpu(mvr):
     assert mvr._lib.mvr_strerror(mvr.E_NOCORR).decode().startswith("not enough")
 
 
+def test_entry_points_reject_null_arguments_before_touching_the_gpu(mvr):
+    """argument errors are reported as MVR_E_ARG, not as a crash -- checked without a device for the calls a binder
+    is most likely to get wrong (the one-call ring step, the batch calls)"""
+    import ctypes as C
+    L, NULL = mvr._lib, None
+    i2 = (C.c_int * 2)(0, 1)
+    d3, d32 = (C.c_double * 3)(), (C.c_double * 32)()
+    assert L.mvr_ring_step(NULL, 2, i2, i2, 1, i2, i2, 4.0, 1, 0, d3, 16, d32, d32, NULL, NULL, NULL, NULL, NULL, NULL) == mvr.E_ARG
+    assert L.mvr_pair_moments2_batch(NULL, 1, i2, i2, 4.0, 1, 0, NULL, NULL, d3, NULL, d32) == mvr.E_ARG
+    assert L.mvr_cloud_transform_batch(NULL, 1, i2, i2, d32) == mvr.E_ARG
+    assert L.mvr_ctx_tune(NULL, b"pair_groups", 2) == mvr.E_ARG
+    # the host-only step validates its graph: an edge that names a view outside [0, n)
+    es, et = (C.c_int * 1)(0), (C.c_int * 1)(5)
+    poses = (C.c_double * 32)(); lum = (C.c_double * 12)(); pn = (C.c_double * 1)(); pm = (C.c_double * 1)(); its = C.c_int()
+    rc = L.mvr_ring_host_step(2, 1, es, et, d32, d3, 16, poses, lum, NULL, pn, pm, C.byref(its))
+    assert rc != 0
+
+
 def _moments_numpy(src, tgt, q, m, origin):
     p = src[q, :3].astype(np.float64) - origin
     t = tgt[m, :3].astype(np.float64) - origin
