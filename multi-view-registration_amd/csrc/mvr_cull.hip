@@ -337,8 +337,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   // (Testing one box with one query per lane was a ~60-instruction dependent chain per box; thirty of
   // those per wave were a third of a wave's life -- tools/block_trace.py.)
   auto needed4 = [&](const float lo_x, const float lo_y, const float lo_z, const float hi_x, const float hi_y,
-                     const float hi_z) -> unsigned {
-    bool need = false;
+                     const float hi_z, unsigned *hot = nullptr) -> unsigned {
+    bool need = false, inside = false;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const float dx = fmaxf(0.f, fmaxf(lo_x - qx[q], qx[q] - hi_x));
@@ -347,8 +347,14 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       const float pb = dx * dx + dy * dy + dz * dz;
       const float bound = fminf(__uint_as_float(__atomic_load_n(&sbest[q * 16 + l16], __ATOMIC_RELAXED)), cap2);
       need |= (pb * 0.99999f <= bound);
+      inside |= (pb == 0.f);
     }
     ++tiles_tested;
+    if (hot) {           // boxes that CONTAIN a query of the set: the cells most likely to settle its bound
+      const unsigned long long h = __ballot(inside);
+      *hot = ((h & 0xFFFFull) ? 1u : 0u) | ((h & 0xFFFF0000ull) ? 2u : 0u) | ((h & 0xFFFF00000000ull) ? 4u : 0u) |
+             ((h & 0xFFFF000000000000ull) ? 8u : 0u);
+    }
     const unsigned long long b = __ballot(need);
     return ((b & 0xFFFFull) ? 1u : 0u) | ((b & 0xFFFF0000ull) ? 2u : 0u) | ((b & 0xFFFF00000000ull) ? 4u : 0u) |
            ((b & 0xFFFF000000000000ull) ? 8u : 0u);
@@ -421,8 +427,11 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     }
   };
 
-  // queue of needed cells: entry k lives in lane k & 63 of these registers (written under a lane
-  // compare, read back with v_readlane); it never holds more than 3 + 4 cells
+  // queue of needed cells, a deque: entry k lives in lane k & 63 of these registers (written under a lane
+  // compare, read back with v_readlane); cells whose box CONTAINS a query of the set enter at the front, the
+  // others at the back (measured on the ring step: 5.5 % fewer evaluations, launches 2.5 % shorter; looking a
+  // few tiles ahead for such a cell before the first pop was tried too: 0.6 % fewer evaluations, 1 % slower).
+  // It never holds more than 3 + 4 cells.
   uint32_t pq_cell = 0;
   float pq_box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint32_t pq_head = 0, pq_tail = 0;
@@ -438,17 +447,27 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     } else {                             // beyond the prefetched eight: read it now
       clo = cbox[(size_t)tile * 8 + 2 * g]; chi = cbox[(size_t)tile * 8 + 2 * g + 1];
     }
+#ifndef MVR_NO_HOT_FIRST
+    unsigned hot = 0;
+    const unsigned nd = needed4(clo.x, clo.y, clo.z, chi.x, chi.y, chi.z, &hot);
+#else
+    const unsigned hot = 0;
     const unsigned nd = needed4(clo.x, clo.y, clo.z, chi.x, chi.y, chi.z);
+#endif
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
       if ((nd >> cidx) & 1u) {
-        const int at = (int)(pq_tail & 63u), from = 16 * cidx;          // any lane of group cidx holds that cell's box
+        // a cell that contains a query goes to the FRONT of the queue: evaluated before the merely near ones queued
+        // earlier, it tightens the bounds they will be re-validated against
+        const bool front = ((hot >> cidx) & 1u) != 0;
+        if (front) --pq_head;
+        const int at = (int)((front ? pq_head : pq_tail) & 63u), from = 16 * cidx;          // any lane of group cidx holds that cell's box
         pq_cell = (lane == at) ? tile * 4u + (uint32_t)cidx : pq_cell;
         const float bx[6] = {lane_value(clo.x, from), lane_value(clo.y, from), lane_value(clo.z, from),
                              lane_value(chi.x, from), lane_value(chi.y, from), lane_value(chi.z, from)};
 #pragma unroll
         for (int k = 0; k < 6; ++k) pq_box[k] = (lane == at) ? bx[k] : pq_box[k];
-        ++pq_tail;
+        if (!front) ++pq_tail;
       }
     }
     MVR_TOC(tr_t_exp, tr_exp);
