@@ -113,6 +113,11 @@ def main():
         # one registrationLUM outer pass over all scan pairs (ring.RingLUM.step)
         state["poses"] = reg.step(state["poses"])
 
+    def run(n):
+        # n outer passes, exactly n steps of the kind above.  Single process: the loop itself is native (mvr_ring_run,
+        # as in Registrator::registrationLUMDevice of the C++ shim); several ranks: step by step, with the all-reduce
+        state["poses"] = reg.run(state["poses"], n)
+
     def barrier():
         if use_dist:
             dist.barrier()
@@ -122,14 +127,12 @@ def main():
     prof_level = int(os.environ.get("MVR_BENCH_PROF", "2"))      # 2: time the NN kernels only
     reset()
     ctx.prof_enable(prof_level)             # warm up WITH the timing events (they are pooled after first use)
-    for _ in range(max(args.warmup, 1)):
-        step()
+    run(max(args.warmup, 1))
     reset()
     ctx.prof_reset(); ctx.prof_enable(prof_level)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
@@ -201,8 +204,7 @@ def main():
         reset(); step(); reset()
         ctx.prof_reset(); ctx.prof_enable(1)
         barrier(); ti = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run(args.steps)
         barrier(); iso_elapsed = time.perf_counter() - ti
         ctx.prof_enable(False)
         iso = dict(nn=ctx.prof_get(mvr.K_NN), rd=ctx.prof_get(mvr.K_REDUCE), gl=ctx.prof_get(mvr.K_GLUE),

@@ -276,6 +276,12 @@ int  mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int 
                    const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
                    double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters,
                    double *rows, double *timing_ms);
+/* n_steps outer passes (the loop of registrator.cpp:625-664), each exactly one mvr_ring_step; the outputs are those
+ * of the LAST pass, timing_ms the SUM over the passes.  Stops at the first pass that fails and returns its status. */
+int  mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                  const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                  int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
+                  int *lum_iters, double *rows, double *timing_ms);
 /* pcl::getTransformation(x,y,z,roll,pitch,yaw) -> column-major 4x4. */
 void mvr_pose_to_mat4(const double pose[6], double T[16]);
 

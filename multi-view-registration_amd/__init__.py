@@ -151,6 +151,9 @@ SIGNATURES = {
     "mvr_ring_step": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
                                 C.POINTER(C.c_int), _dp, _dp]),
+    "mvr_ring_run": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                               C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
+                               C.POINTER(C.c_int), _dp, _dp]),
     "mvr_pose_to_mat4": (None, [_dp, _dp]),
     "mvr_turntable_angle": (C.c_double, [C.c_int, C.c_int]),
     "mvr_axis_rotation": (None, [_dp, _dp, C.c_double, _dp]),
@@ -472,11 +475,13 @@ class Context:
                                  np.float64)
         _chk(_lib.mvr_cloud_transform_batch(self._h, n, d, s, _p(T, C.c_double)), self._h)
 
-    def ring_step(self, posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=16, reciprocal=True, fma=False):
+    def ring_step(self, posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=16, reciprocal=True, fma=False,
+                  steps=None):
         """mvr_ring_step: one outer pass of registrationLUM in one native call (single process).  edges: [(src view,
         tgt view)]; poses: list of (4,4) float64.  Returns (new poses, info) like ring_host_step, plus info["rows"]
         (ne x 32 edge table) and info["timing_ms"] = (enqueue, GPU wait + copy, host solve).  poses may be a list of
-        (4,4) arrays or one (V,4,4) array; the new poses come back as a (V,4,4) array."""
+        (4,4) arrays or one (V,4,4) array; the new poses come back as a (V,4,4) array.  steps=K: K passes in one
+        native call (mvr_ring_run)."""
         V, ne = len(posed_slots), len(edges)
         key = (tuple(posed_slots), tuple(raw_slots), tuple(edges))
         st = getattr(self, "_ring_static", None)
@@ -490,9 +495,13 @@ class Context:
         o = np.ascontiguousarray(origin, np.float64)
         lum, rows, tm = np.zeros((V, 6)), np.empty((ne, 32)), np.zeros(3)
         pT, pn, pm, its = np.empty((ne, 16), np.float32), np.empty(ne), np.empty(ne), C.c_int()
-        _chk(_lib.mvr_ring_step(self._h, V, ps, rs, ne, es, et, float(max_dist), int(reciprocal), int(fma), _p(o, C.c_double),
-                                int(lum_iterations), _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float), _p(pn, C.c_double),
-                                _p(pm, C.c_double), C.byref(its), _p(rows, C.c_double), _p(tm, C.c_double)), self._h)
+        args = (V, ps, rs, ne, es, et, float(max_dist), int(reciprocal), int(fma), _p(o, C.c_double), int(lum_iterations),
+                _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float), _p(pn, C.c_double), _p(pm, C.c_double), C.byref(its),
+                _p(rows, C.c_double), _p(tm, C.c_double))
+        if steps is None:
+            _chk(_lib.mvr_ring_step(self._h, *args), self._h)
+        else:                     # mvr_ring_run: `steps` passes in one call; outputs of the last one, timing summed
+            _chk(_lib.mvr_ring_run(self._h, int(steps), *args), self._h)
         new = np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1))        # (V,4,4): indexable like the list that came in
         info = dict(pair_T=np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1)), pair_n=pn.tolist(),
                     pair_mse=pm.tolist(), lum_pose=lum, lum_iterations=its.value, rows=rows, timing_ms=tuple(tm.tolist()))

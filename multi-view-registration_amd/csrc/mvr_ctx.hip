@@ -1007,6 +1007,23 @@ API int mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const i
   return MVR_OK;
 }
 
+API int mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                     const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                     int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
+                     int *lum_iters, double *rows, double *timing_ms)
+{
+  if (n_steps < 0) return MVR_E_ARG;
+  double sum[3] = {0.0, 0.0, 0.0}, t[3];
+  for (int k = 0; k < n_steps; ++k) {
+    const int rc = mvr_ring_step(ctx, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin,
+                                 lum_iterations, poses, lum_pose, pair_T, pair_n, pair_mse, lum_iters, rows, t);
+    if (rc != MVR_OK) return rc;
+    for (int j = 0; j < 3; ++j) sum[j] += t[j];
+  }
+  if (timing_ms) for (int j = 0; j < 3; ++j) timing_ms[j] = sum[j];
+  return MVR_OK;
+}
+
 // ---- target sharding over ranks (sequential mode): forward keys out, reduced keys in ----
 API int mvr_nn_forward_keys(mvr_ctx *ctx, int ss, int ts, double max_dist, int fma, long long *dev_keys)
 {

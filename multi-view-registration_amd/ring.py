@@ -98,10 +98,11 @@ class HipBackend:
         with self._on_stream():
             return table.cpu().numpy()
 
-    def fused_step(self, edges, poses, max_dist, origin, lum_iterations):
-        """the whole step in one native call (mvr_ring_step): single process only, every edge whole"""
+    def fused_step(self, edges, poses, max_dist, origin, lum_iterations, steps=None):
+        """the whole step in one native call (mvr_ring_step; steps=K: K of them, mvr_ring_run): single process only,
+        every edge whole"""
         return self.ctx.ring_step(list(range(self.V)), [self.V + v for v in range(self.V)], edges, poses, max_dist, origin,
-                                  lum_iterations=lum_iterations, reciprocal=True, fma=self.fma)
+                                  lum_iterations=lum_iterations, reciprocal=True, fma=self.fma, steps=steps)
 
     def close(self):
         self.ctx.close()
@@ -123,19 +124,43 @@ class RingLUM:
         self.views_needed = sorted({v for e, _, _ in self.segments for v in self.edges[e]})
         self.last = {}
 
+    def _native(self):
+        b = self.b
+        return (self.world == 1 and self.all_reduce is None and self.fused and hasattr(b, "fused_step")
+                and os.environ.get("MVR_RING_FUSED", "1") != "0")
+
+    def run(self, poses, steps):
+        """`steps` outer passes (the loop of registrator.cpp:625-664).  Single process: one native call for all of them
+        (mvr_ring_run); otherwise step by step.  self.last describes the last pass, its ms_* fields are per-pass means."""
+        if steps <= 0:
+            return poses
+        if not self._native():
+            acc = [0.0, 0.0, 0.0]
+            for _ in range(steps):
+                poses = self.step(poses)
+                for j, k in enumerate(("ms_enqueue", "ms_drain", "ms_host_solve")):
+                    acc[j] += self.last[k]
+            self.last.update(ms_enqueue=acc[0] / steps, ms_drain=acc[1] / steps, ms_host_solve=acc[2] / steps)
+            return poses
+        new, info = self.b.fused_step(self.edges, poses, self.max_dist, self.origin, self.lum_iterations, steps=steps)
+        self._set_last(info, steps)
+        return new
+
+    def _set_last(self, info, steps=1):
+        n = float(sum(info["pair_n"]))
+        tm = info["timing_ms"]
+        self.last = dict(info, n_corr=n,
+                         mse=(sum(a * c for a, c in zip(info["pair_n"], info["pair_mse"])) / n) if n else 0.0,
+                         ms_enqueue=tm[0] / steps, ms_drain=tm[1] / steps, ms_host_solve=tm[2] / steps)
+
     def step(self, poses):
         """poses: list of V (4,4) float64 column-vector poses -> new list."""
         import time
         b = self.b
-        if (self.world == 1 and self.all_reduce is None and self.fused and hasattr(b, "fused_step")
-                and os.environ.get("MVR_RING_FUSED", "1") != "0"):
+        if self._native():
             # single process: posing, searches, reductions, copy of the table and the host solve in ONE native call
             new, info = b.fused_step(self.edges, poses, self.max_dist, self.origin, self.lum_iterations)
-            n = float(sum(info["pair_n"]))
-            tm = info["timing_ms"]
-            self.last = dict(info, n_corr=n,
-                             mse=(sum(a * c for a, c in zip(info["pair_n"], info["pair_mse"])) / n) if n else 0.0,
-                             ms_enqueue=tm[0], ms_drain=tm[1], ms_host_solve=tm[2])
+            self._set_last(info)
             return new
         t0 = time.perf_counter()
         b.pose_clouds(poses, self.views_needed)     # only the scans this rank's segments touch

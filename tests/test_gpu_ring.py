@@ -59,6 +59,11 @@ def test_one_call_step_equals_three_call_step(mvr, ring):
                 assert r.last["rows"].shape == (12, 32) and [int(x) for x in r.last["rows"][:, 0]] == log[-1][1]
                 assert all(t >= 0 for t in r.last["timing_ms"])
             runs.append(log)
+            if fused:                     # the native loop (mvr_ring_run) walks the same poses as step-by-step calls
+                r2 = ring.RingLUM(be, 12, [len(s) for s in scans], 8.0, origin)
+                p3 = r2.run([p.copy() for p in poses0], 3)
+                assert np.asarray(p3).tobytes() == log[-1][0] and [int(n) for n in r2.last["pair_n"]] == log[-1][1]
+                assert r2.last["ms_drain"] > 0
         finally:
             be.close()
     assert runs[0] == runs[1]
