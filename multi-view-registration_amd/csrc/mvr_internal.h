@@ -125,7 +125,7 @@ struct Ctx {
   // workspace of the fused batch (culled mode): forward keys of all pairs, reverse keys + flags, per-pair partial rows
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
-  uint32_t *bbound = nullptr; size_t bbound_cap = 0;     // [targets of all pairs] bits of the smallest forward d2 that matched a target (~0: not matched)
+  uint32_t *bbound = nullptr; size_t bbound_cap = 0;     // [targets of all pairs] bits of the forward d2 of a source that matched the target (~0: not matched)
   uint32_t *blist = nullptr; size_t blist_cap = 0;
   uint32_t *bslot = nullptr; size_t bslot_cap = 0;
   uint32_t *bchunks = nullptr; size_t bchunks_cap = 0;      // per-chunk counts / offsets, then one count per pair
@@ -252,7 +252,7 @@ struct GluePair {
   const nnkey_t *keys = nullptr, *rkeys = nullptr;        // forward keys [ns] (by original index, or by sorted position: by_pos), reverse keys [nt] (by sorted position)
   const uint32_t *qperm = nullptr, *tinv = nullptr;
   uint8_t *flags = nullptr;                               // [nt], sorted target space
-  uint32_t *bound = nullptr;                              // instead of flags: [nt] bits of the smallest matching d2 per target (~0 = not matched)
+  uint32_t *bound = nullptr;                              // instead of flags: [nt] bits of a matching d2 per target (~0 = not matched)
   uint32_t *list = nullptr, *slot = nullptr;              // [<= nt] flagged sorted positions in order; [nt] position -> list index
   uint32_t *chunks = nullptr, *qcount = nullptr;          // [ceil(nt / 256)] flagged per chunk -> exclusive offsets; number flagged
   unsigned long long nt = 0;
@@ -269,7 +269,7 @@ int reduce_blocks_for(const Ctx *c, size_t n);
 // the same flags compacted (ordered) into list[] with count and the inverse slot[] (sorted position -> list position)
 int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                        const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *slot);
-// bound[sorted target position] = bits of the smallest forward d2 that matched it (~0: none): where the reverse search of a matched target starts
+// bound[sorted target position] = bits of the forward d2 of a source that matched it (~0: none): where the reverse search of a matched target starts
 int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                        const uint32_t *tinv, size_t nt, uint32_t *bound);
 // culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)
