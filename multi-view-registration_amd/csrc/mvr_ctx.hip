@@ -333,6 +333,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
                   c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->bpartials, c->blist, c->bslot, c->bchunks};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
+  if (c->h_table) (void)hipHostFree(c->h_table);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -986,12 +987,22 @@ API int mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const i
   if (int rc = mvr_cloud_transform_batch(ctx, n_views, posed_slots, raw_slots, poses)) return rc;
   std::vector<int> ss((size_t)ne), ts((size_t)ne);
   for (int e = 0; e < ne; ++e) { ss[e] = posed_slots[edge_src[e]]; ts[e] = posed_slots[edge_tgt[e]]; }
-  if (int rc = ensure(c, c->batch_table, c->batch_cap, (size_t)std::max(ne, 1) * 32)) return rc;
-  if (ne) { if (int rc = mvr_pair_moments2_batch(ctx, ne, ss.data(), ts.data(), max_dist, reciprocal, fma, nullptr, nullptr, origin, nullptr, c->batch_table)) return rc; }
+  // the 32 doubles per edge go straight into pinned host memory (the final kernels write them over the bus: no copy
+  // to enqueue, nothing to wait for but the stream itself)
+  if (c->h_table_cap < (size_t)std::max(ne, 1) * 32) {
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_table) (void)hipHostFree(c->h_table);
+    c->h_table = nullptr; c->h_table_cap = 0;
+    const size_t cap = (size_t)std::max(ne, 16) * 32;
+    MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), cap * sizeof(double), hipHostMallocMapped));
+    c->h_table_cap = cap;
+  }
+  double *d_table = nullptr;
+  MVR_HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&d_table), c->h_table, 0));
+  if (ne) { if (int rc = mvr_pair_moments2_batch(ctx, ne, ss.data(), ts.data(), max_dist, reciprocal, fma, nullptr, nullptr, origin, nullptr, d_table)) return rc; }
   const auto t1 = clk::now();
-  std::vector<double> h((size_t)ne * 32);
-  if (ne) MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), c->batch_table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<double> h(c->h_table, c->h_table + (size_t)ne * 32);
   const auto t2 = clk::now();
   if (rows && ne) std::memcpy(rows, h.data(), h.size() * sizeof(double));
   std::vector<double> pn((size_t)ne), pm((size_t)ne);
