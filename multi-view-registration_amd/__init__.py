@@ -285,23 +285,28 @@ def lum_edge_from_moments(m2: PairMoments2, pose_s, pose_t):
     return rc, MM.reshape(6, 6), MZ, ss.value
 
 
+_edge_cache = {}
+
+
 def ring_host_step(n_views, edges, rows, origin, poses, lum_iterations=16):
     """One call for the host side of a global step.  rows: (ne, 32) float64 edge
     table; poses: list of (4,4) float64.  Returns (rc, new_poses, info dict)."""
     ne = len(edges)
-    es = (C.c_int * ne)(*[e[0] for e in edges])
-    et = (C.c_int * ne)(*[e[1] for e in edges])
+    key = tuple(map(tuple, edges))
+    if _edge_cache.get("key") != key:                       # the graph of a registration does not change between steps
+        _edge_cache.update(key=key, es=(C.c_int * ne)(*[e[0] for e in edges]), et=(C.c_int * ne)(*[e[1] for e in edges]))
+    es, et = _edge_cache["es"], _edge_cache["et"]
     R = np.ascontiguousarray(rows, np.float64).reshape(ne, 32)
     o = np.ascontiguousarray(origin, np.float64)
-    P = np.ascontiguousarray(np.stack([np.asarray(p, np.float64).T for p in poses])).reshape(n_views, 16)
+    P = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(n_views, 4, 4).transpose(0, 2, 1)).reshape(n_views, 16)
     lum = np.zeros((n_views, 6))
     pT, pn, pm, its = np.empty((ne, 16), np.float32), np.empty(ne), np.empty(ne), C.c_int()
     rc = _lib.mvr_ring_host_step(n_views, ne, es, et, _p(R, C.c_double), _p(o, C.c_double), int(lum_iterations),
                                  _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float), _p(pn, C.c_double),
                                  _p(pm, C.c_double), C.byref(its))
-    new = [P[v].reshape(4, 4).T.copy() for v in range(n_views)]
-    info = dict(pair_T=[pT[e].reshape(4, 4).T.copy() for e in range(ne)], pair_n=list(pn), pair_mse=list(pm),
-                lum_pose=lum, lum_iterations=its.value)
+    new = list(np.ascontiguousarray(P.reshape(n_views, 4, 4).transpose(0, 2, 1)))
+    info = dict(pair_T=list(np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1))), pair_n=pn.tolist(),
+                pair_mse=pm.tolist(), lum_pose=lum, lum_iterations=its.value)
     return rc, new, info
 
 
@@ -471,8 +476,9 @@ class Context:
         n = len(dst_slots)
         d = (C.c_int * n)(*[int(v) for v in dst_slots])
         s = (C.c_int * n)(*[int(v) for v in src_slots])
-        T = np.ascontiguousarray(np.stack([to_cm(p, np.float64).reshape(16) for p in poses]) if n else np.zeros((0, 16)),
-                                 np.float64)
+        # (4,4) column-vector matrices -> column-major 16-vectors: one transpose for all clouds
+        T = (np.ascontiguousarray(np.asarray(poses, np.float64).reshape(n, 4, 4).transpose(0, 2, 1)).reshape(n, 16) if n
+             else np.zeros((0, 16)))
         _chk(_lib.mvr_cloud_transform_batch(self._h, n, d, s, _p(T, C.c_double)), self._h)
 
     def ring_step(self, posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=16, reciprocal=True, fma=False,
