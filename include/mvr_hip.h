@@ -305,7 +305,8 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_CO
  * query set: 1,2,4; 0 = by launch size; also MVR_CULL_W); "pair_fused" (1, default: in culled mode
  * mvr_pair_moments2_batch runs every stage of all pairs as ONE launch; 0: one pair per worker stream;
  * also MVR_PAIR_FUSED), "pair_groups" (1..8, default 2: the fused pass runs its pairs in that many groups on
- * concurrent streams, so one group's small kernels overlap another's searches; also MVR_PAIR_GROUPS),
+ * concurrent streams -- when there are at least four pairs per group -- so one group's small kernels overlap
+ * another's searches; also MVR_PAIR_GROUPS),
  * "pair_streams" (worker streams, 1..16; also MVR_PAIR_STREAMS); "posed_refresh" (1, default: in culled mode
  * mvr_cloud_transform_batch also refreshes the index of the posed copies, from the sources' sorted copies;
  * 0: at the first search, by a gather; also MVR_POSED_REFRESH).

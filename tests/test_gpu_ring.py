@@ -102,8 +102,10 @@ def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
     for v in range(V):
         gpu.upload(V + v, scans[v])
         gpu.transform(v, V + v, poses0[v])
-    pairs = [(v, (v + 1) % V) for v in range(V)] + [(2, 5), (5, 2)]
-    ranges = [(0, None), (100, 700), (0, 0), (2000, None), (5, 1), (0, None), (1024, 1024), (3, 2040), (0, None)]
+    # 16 pairs: enough for the fused pass to split them into 2 and into 4 groups (it wants four pairs per group)
+    pairs = [(v, (v + 1) % V) for v in range(V)] + [(2, 5), (5, 2)] + [(v, (v + 2) % V) for v in range(V)]
+    ranges = [(0, None), (100, 700), (0, 0), (2000, None), (5, 1), (0, None), (1024, 1024), (3, 2040), (0, None)] + \
+             [(0, None), (7, 1000), (0, None), (1500, 548), (0, None), (0, 1), (64, 64)]
     # streams == 3: the worker-stream path also in culled mode; the fused pass in 1, 2 (default) or 4 groups of pairs
     gpu.tune(pair_streams=streams, pair_fused=int(streams != 3), pair_groups={1: 1, 3: 1, 6: 2}.get(streams, 4))
     try:
