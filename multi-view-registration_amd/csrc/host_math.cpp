@@ -19,6 +19,8 @@
 #include <cstring>
 #include <vector>
 
+#include <immintrin.h>
+
 #include "mvr_internal.h"
 
 namespace mvr {
@@ -226,50 +228,72 @@ int solve_dense(int n, double *A, double *b)
 // caller knows the structure (saves the scan of the matrix).
 int solve_spd(int n, double *A, double *b, const int *row_end = nullptr)
 {
-  static thread_local std::vector<double> U;          // scratch, reused: only [j, end[j]) of a row is ever valid
-  static thread_local std::vector<double> dinv;       // 1 / U[j][j]
+  // Scratch: rows of `stride` doubles; row j is valid on [j, end[j]) and ZERO up to j + pad, so the row updates
+  // below run over whole 4-wide vectors without a scalar tail (the rows of a ring's normal equations are at most
+  // 12 long: a counted loop with a remainder cost more than the arithmetic).  Element by element the operations
+  // are the ones of the scalar loop (multiply, then subtract: no contraction), so the bits are the same.
+  static thread_local std::vector<double> U, dinv, rhs;
   static thread_local std::vector<int> end;           // one past the last non-zero of row j (upper part)
-  if (U.size() < (size_t)n * n) U.resize((size_t)n * n);
   if (end.size() < (size_t)n) { end.resize((size_t)n); dinv.resize((size_t)n); }
   double amax = 0.0;
+  int width = 1;
   for (int j = 0; j < n; ++j) {
     amax = std::max(amax, std::fabs(A[(size_t)j * n + j]));
     int e = j + 1;
     if (row_end) e = std::max(e, std::min(n, row_end[j]));
     else for (int k = n - 1; k > j; --k) if (A[(size_t)j * n + k] != 0.0) { e = k + 1; break; }
-    std::memcpy(&U[(size_t)j * n + j], &A[(size_t)j * n + j], (size_t)(e - j) * sizeof(double));
     end[j] = e;
+    width = std::max(width, e - j);
+  }
+  // fill-in never reaches beyond the widest row's span from the pivot, so every row stays within `width` of its diagonal
+  const int pad = ((width + 3) & ~3) + 4;
+  const size_t stride = (size_t)n + (size_t)pad;
+  if (U.size() < (size_t)n * stride) U.resize((size_t)n * stride);
+  if (rhs.size() < stride) rhs.resize(stride);
+  for (int j = 0; j < n; ++j) {
+    double *Uj = &U[(size_t)j * stride];
+    std::memset(Uj + j, 0, (size_t)pad * sizeof(double));
+    std::memcpy(Uj + j, &A[(size_t)j * n + j], (size_t)(end[j] - j) * sizeof(double));
   }
   bool ok = amax > 0.0;
   for (int j = 0; j < n && ok; ++j) {
-    double *Uj = &U[(size_t)j * n];
+    double *Uj = &U[(size_t)j * stride];
     const double d = Uj[j];
     if (!(d > 1e-13 * amax)) { ok = false; break; }
     const double ujj = std::sqrt(d), inv = 1.0 / ujj;
     const int ej = end[j];
     Uj[j] = ujj; dinv[j] = inv;
-    for (int k = j + 1; k < ej; ++k) Uj[k] *= inv;
+    const __m256d vinv = _mm256_set1_pd(inv);
+    for (int k = j + 1; k < ej; k += 4) _mm256_storeu_pd(Uj + k, _mm256_mul_pd(_mm256_loadu_pd(Uj + k), vinv));
     for (int i = j + 1; i < ej; ++i) {
       const double f = Uj[i];
       if (f == 0.0) continue;
-      double *Ui = &U[(size_t)i * n];
-      if (end[i] < ej) { std::memset(Ui + end[i], 0, (size_t)(ej - end[i]) * sizeof(double)); end[i] = ej; }   // fill-in
-      for (int k = i; k < ej; ++k) Ui[k] -= f * Uj[k];
+      double *Ui = &U[(size_t)i * stride];
+      if (end[i] < ej) end[i] = ej;                     // fill-in (the row is zero there already)
+      const __m256d vf = _mm256_set1_pd(f);
+      for (int k = i; k < ej; k += 4)
+        _mm256_storeu_pd(Ui + k, _mm256_sub_pd(_mm256_loadu_pd(Ui + k), _mm256_mul_pd(vf, _mm256_loadu_pd(Uj + k))));
     }
   }
   if (!ok) return solve_dense(n, A, b);
+  double *y = rhs.data();
+  std::memcpy(y, b, (size_t)n * sizeof(double));
+  std::memset(y + n, 0, (size_t)pad * sizeof(double));
   for (int i = 0; i < n; ++i) {                       // U^T y = b, column-oriented: axpy over row i of U
-    const double y = b[i] * dinv[i];                  // (a multiply keeps the divider off the dependent chain)
-    b[i] = y;
-    const double *Ui = &U[(size_t)i * n];
-    for (int k = i + 1; k < end[i]; ++k) b[k] -= Ui[k] * y;
+    const double yi = y[i] * dinv[i];                 // (a multiply keeps the divider off the dependent chain)
+    y[i] = yi;
+    const double *Ui = &U[(size_t)i * stride];
+    const __m256d vy = _mm256_set1_pd(yi);
+    for (int k = i + 1; k < end[i]; k += 4)
+      _mm256_storeu_pd(y + k, _mm256_sub_pd(_mm256_loadu_pd(y + k), _mm256_mul_pd(_mm256_loadu_pd(Ui + k), vy)));
   }
-  for (int i = n - 1; i >= 0; --i) {                  // U x = y
-    const double *Ui = &U[(size_t)i * n];
-    double s = b[i];
-    for (int k = i + 1; k < end[i]; ++k) s -= Ui[k] * b[k];
-    b[i] = s * dinv[i];
+  for (int i = n - 1; i >= 0; --i) {                  // U x = y (a sum: kept in order)
+    const double *Ui = &U[(size_t)i * stride];
+    double sacc = y[i];
+    for (int k = i + 1; k < end[i]; ++k) sacc -= Ui[k] * y[k];
+    y[i] = sacc * dinv[i];
   }
+  std::memcpy(b, y, (size_t)n * sizeof(double));
   return MVR_OK;
 }
 
@@ -323,15 +347,26 @@ API void mvr_pose_to_mat4(const double pose[6], double T[16])
 // (cs = Rs o + ts - o), so every sum over aver = (a+b)/2 and diff = a-b is an
 // algebraic function of {n, sum p', sum q', sum p'p'^T, sum q'q'^T, sum p'q'^T}.
 // Work in the shifted frame (small magnitudes), shift MM/MZ back at the end.
+static int lum_edge_from_moments_T(const mvr_pair_moments2_t *m2, const double Ts[16], const double Tt[16], double MM[36],
+                                   double MZ[6], double *ss);
+
 API int mvr_lum_edge_from_moments(const mvr_pair_moments2_t *m2, const double pose_s[6], const double pose_t[6],
                                   double MM[36], double MZ[6], double *ss)
 {
   if (!m2 || !pose_s || !pose_t || !MM || !MZ || !ss) return MVR_E_ARG;
+  double Ts[16], Tt[16];
+  mvr_pose_to_mat4(pose_s, Ts); mvr_pose_to_mat4(pose_t, Tt);
+  return lum_edge_from_moments_T(m2, Ts, Tt, MM, MZ, ss);
+}
+
+// the same with the two vertex poses already as 4x4 (LUM::compute converts every vertex once per iteration, not
+// once per edge end: the twelve sin / cos per edge were a third of its cost)
+static int lum_edge_from_moments_T(const mvr_pair_moments2_t *m2, const double Ts[16], const double Tt[16], double MM[36],
+                                   double MZ[6], double *ss)
+{
   std::memset(MM, 0, 36 * sizeof(double)); std::memset(MZ, 0, 6 * sizeof(double)); *ss = 0.0;
   const double n = m2->n;
   if (n < 3.0) return MVR_E_NOCORR;
-  double Ts[16], Tt[16];
-  mvr_pose_to_mat4(pose_s, Ts); mvr_pose_to_mat4(pose_t, Tt);
   M3 Rs, Rt;
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Rs(r, c) = Ts[r + 4 * c]; Rt(r, c) = Tt[r + 4 * c]; }
   const double *o = m2->origin;
@@ -444,11 +479,13 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     for (int vj = 1; vj < n; ++vj) if (eidx[(size_t)vi * n + vj] >= 0) hi = std::max(hi, vj);
     for (int r = 0; r < 6; ++r) row_end[6 * (vi - 1) + r] = 6 * hi;
   }
+  std::vector<double> Tv((size_t)n * 16);
   int it = 0;
   for (; it < max_iterations; ++it) {
+    for (int v = 0; v < n; ++v) mvr_pose_to_mat4(poses + 6 * v, &Tv[(size_t)v * 16]);
     for (int e = 0; e < ne; ++e) {
       double MM[36], MZ[6], ss;
-      const int rc = mvr_lum_edge_from_moments(&m2[e], poses + 6 * es[e], poses + 6 * et[e], MM, MZ, &ss);
+      const int rc = lum_edge_from_moments_T(&m2[e], &Tv[(size_t)es[e] * 16], &Tv[(size_t)et[e] * 16], MM, MZ, &ss);
       if (rc != MVR_OK || ss < 0.0000000000001 || !std::isfinite(ss)) {
         std::fill(cinv.begin() + 36 * e, cinv.begin() + 36 * (e + 1), 0.0);
         std::fill(cinvd.begin() + 6 * e, cinvd.begin() + 6 * (e + 1), 0.0);
