@@ -605,27 +605,44 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     if (dst[k] != src[k]) { c->slots[dst[k]].n = 0; if (int rc = cloud_reserve(c, c->slots[dst[k]], n[k], false)) return rc; }
     in[k] = c->slots[src[k]].pts; out[k] = c->slots[dst[k]].pts;
   }
-  if (int rc = launch_transform_f64_batch(c, count, in.data(), out.data(), n.data(), T)) return rc;
+  // bookkeeping first (host side only): the destinations are posed copies of their sources' point sets
   for (int k = 0; k < count; ++k) {
-    if (!in[k] && !n[k] && c->slots[src[k]].has_normals) continue;
+    if (!in[k]) continue;
     c->slots[dst[k]].n = n[k];
     if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
     c->slots[dst[k]].coords_valid = false;
     c->slots[dst[k]].has_normals = false;
   }
-  if (c->nn_mode != 0 && c->posed_refresh) {
-    // culled search: the posed copies are about to be searched -- bring their index up to date here, from the
-    // sources' sorted copies (read in order) instead of a gather through the permutation at the first search
-    std::vector<Cloud *> d, s; std::vector<double> Ts;
+  // Culled search: the posed copies are about to be searched -- bring their index up to date here, from the
+  // sources' sorted copies (read in order) instead of a gather through the permutation at the first search.
+  // Where the ordering of the point set exists already (every pose but a scan's first) the SAME launch writes
+  // the posed points in original order too, and the plain transform launch below has nothing left to do.
+  std::vector<int> cand;
+  if (c->nn_mode != 0 && c->posed_refresh)
     for (int k = 0; k < count; ++k) {
-      if (!in[k] || dst[k] == src[k]) continue;
+      if (!in[k] || dst[k] == src[k] || n[k] == 0) continue;
       bool again = false;                                   // a slot written twice keeps its LAST pose: leave it to the lazy path
       for (int j = 0; j < count; ++j) again |= (j != k && dst[j] == dst[k]);
       for (int j = 0; j < count; ++j) again |= (dst[j] == src[k]);          // ... and so does a source that is also written
-      if (again) continue;
-      d.push_back(&c->slots[dst[k]]); s.push_back(&c->slots[src[k]]); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+      if (!again) cand.push_back(k);
     }
-    if (!d.empty()) { if (int rc = refresh_posed_batch(c, (int)d.size(), d.data(), s.data(), Ts.data())) return rc; }
+  std::vector<char> done((size_t)count, 0);
+  for (int pass = 0; pass < 2; ++pass) {                    // pass 0: with the points, before the transform launch; pass 1: the rest, after it
+    std::vector<Cloud *> d, s; std::vector<double> Ts; std::vector<int> which;
+    for (int k : cand) {
+      Cloud &dc = c->slots[dst[k]];
+      if (done[k]) continue;
+      if (pass == 0 && !(dc.order && dc.order->n == n[k])) continue;      // no ordering yet: it is built from the posed points (pass 1)
+      d.push_back(&dc); s.push_back(&c->slots[src[k]]); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+      which.push_back(k);
+    }
+    std::vector<char> handled(d.size(), 0);
+    if (!d.empty()) { if (int rc = refresh_posed_batch(c, (int)d.size(), d.data(), s.data(), Ts.data(), pass == 0, handled.data())) return rc; }
+    if (pass == 0) {
+      for (size_t i = 0; i < which.size(); ++i) if (handled[i]) { done[which[i]] = 1; n[which[i]] = 0; }    // posed by the refresh launch
+      if (int rc = launch_transform_f64_batch(c, count, in.data(), out.data(), n.data(), T)) return rc;
+      for (size_t i = 0; i < which.size(); ++i) if (handled[i]) n[which[i]] = c->slots[dst[which[i]]].n;
+    }
   }
   return MVR_OK;
 }

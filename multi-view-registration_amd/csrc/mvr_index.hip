@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
         const float4 p = from[k];
         v = pose_point_f64(rb.T[cloud], p);
         v.w = p.w;
+        if (rb.xsrc[cloud]) rb.xdst[cloud][k] = pose_point_f64(rb.T[cloud], rb.xsrc[cloud][k]);     // and the points in original order
       } else {
         const uint32_t o = perm[k];
         v = pts[o];
@@ -447,7 +448,8 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
 }
 
 // from / T: optional, per cloud (see RefreshBatch)
-static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *const *from = nullptr, const double *T = nullptr)
+static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *const *from = nullptr, const double *T = nullptr,
+                         const float4 *const *xsrc = nullptr)
 {
   for (int base = 0; base < count; base += kBatchClouds) {
     RefreshBatch rb;
@@ -457,6 +459,8 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
       Cloud *cl = k < m ? clouds[base + k] : nullptr;
       rb.from[k] = (cl && from) ? from[base + k] : nullptr;
       if (rb.from[k]) std::memcpy(rb.T[k].m, T + (size_t)(base + k) * 16, sizeof rb.T[k].m);
+      rb.xsrc[k] = (rb.from[k] && xsrc) ? xsrc[base + k] : nullptr;
+      rb.xdst[k] = rb.xsrc[k] ? cl->pts : nullptr;
       rb.pts[k] = cl ? cl->pts : nullptr; rb.perm[k] = cl ? cl->order->perm : nullptr; rb.n[k] = cl ? cl->n : 0;
       rb.sorted[k] = cl ? cl->sorted : nullptr; rb.tlo[k] = cl ? cl->tlo : nullptr; rb.thi[k] = cl ? cl->thi : nullptr;
       rb.cbox[k] = cl ? cl->cbox : nullptr; rb.sbox[k] = cl ? cl->sbox : nullptr;
@@ -472,11 +476,12 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
   return MVR_OK;
 }
 
-int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T)
+int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts, char *handled)
 {
-  std::vector<Cloud *> todo; std::vector<const float4 *> from; std::vector<double> Ts;
+  std::vector<Cloud *> todo; std::vector<const float4 *> from, xsrc; std::vector<double> Ts;
   for (int k = 0; k < count; ++k) {
     Cloud *d = dst[k], *s = src[k];
+    if (handled) handled[k] = 0;
     if (!d || !s || d == s || d->n == 0 || d->n != s->n || d->set_id != s->set_id) continue;
     if (std::find(todo.begin(), todo.end(), d) != todo.end()) continue;      // posed twice in one call: the lazy refresh sorts it out
     // A point set without an ordering gets it from the POSED copy: cells are compact boxes in the frame the order
@@ -486,9 +491,10 @@ int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src,
     if (int rc = prepare_index(c, *d, &stale)) return rc;   // ordering (shared by all copies of the set) + buffers
     if (int rc = ensure_index(c, *s)) return rc;            // the source's sorted copy: gathered once, then reused every pose
     if (!stale || d->order != s->order) continue;
-    todo.push_back(d); from.push_back(s->sorted); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+    todo.push_back(d); from.push_back(s->sorted); xsrc.push_back(s->pts); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+    if (handled) handled[k] = 1;
   }
-  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data());
+  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data(), with_pts ? xsrc.data() : nullptr);
 }
 
 int ensure_index(Ctx *c, Cloud &cl)

@@ -208,9 +208,14 @@ struct RefreshBatch {
   // optional: the sorted copy of the cloud this one is a posed copy of (same ordering) and the pose -- the refresh
   // then reads that copy in order and poses it, instead of gathering pts[] through the permutation
   const float4 *from[kBatchClouds]; Mat44d T[kBatchClouds];
+  // optional, with `from`: the source's points in original order and where their posed copies go (the transform itself,
+  // done by the same launch)
+  const float4 *xsrc[kBatchClouds]; float4 *xdst[kBatchClouds];
 };
-// index of posed copies, straight from the sources' sorted copies (culled mode; called by mvr_cloud_transform_batch)
-int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T);
+// index of posed copies, straight from the sources' sorted copies (culled mode; called by mvr_cloud_transform_batch).
+// with_pts: also write dst->pts = T * src->pts.  handled[k] (optional) = cloud k was refreshed by this call.
+int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts = false,
+                        char *handled = nullptr);
 int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T);
 int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count);     // ensure_index for many clouds, coordinates refreshed in one launch
 

@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --view
 python3 - "$(find $O -name '*kernel_trace.csv' | head -1)" "${3:-8}" <<'P'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'transform_f64_batch' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'refresh_sorted' in r['Kernel_Name']]
 w=int(sys.argv[2]); i0,i1=idx[w],idx[w+1]; t0=int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1+1]:
     s=int(r['Start_Timestamp'])-t0; e=int(r['End_Timestamp'])-t0
