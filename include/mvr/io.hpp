@@ -160,11 +160,21 @@ inline bool loadPCDFile(const std::string &filename, RichCloud &cloud)
   bool hx = false, hy = false, hz = false;
   for (auto &pf : fields) {
     if (pf.size != 1 && pf.size != 2 && pf.size != 4 && pf.size != 8) return false;
-    if (pf.count < 1 || (pf.type != 'F' && pf.type != 'U' && pf.type != 'I')) return false;
+    if (pf.count < 1 || pf.count > 4096 || (pf.type != 'F' && pf.type != 'U' && pf.type != 'I')) return false;
     pf.offset = step; step += (size_t)pf.size * pf.count;
     hx |= pf.name == "x"; hy |= pf.name == "y"; hz |= pf.name == "z";
   }
   if (!hx || !hy || !hz) return false;
+  // A header is input, not truth: before any buffer is sized from it, the point count must fit the bytes that
+  // actually follow (every encoding spends at least one byte per point; binary exactly `step` per point; LZF
+  // expands at most 88-fold: a 3-byte reference yields up to 264 bytes).
+  const std::streampos body = f.tellg();
+  f.seekg(0, std::ios::end);
+  const size_t remain = (body >= 0 && f.tellg() >= body) ? (size_t)(f.tellg() - body) : 0;
+  f.seekg(body);
+  if (step == 0 || step > (1u << 20) || points > remain) return false;
+  if (data == "binary" && points > remain / step) return false;
+  if (data == "binary_compressed" && points > (remain * 100 + 64) / step) return false;
   RichCloud out(points);
   if (data == "ascii") {
     for (size_t i = 0; i < points; ++i) {
@@ -195,7 +205,7 @@ inline bool loadPCDFile(const std::string &filename, RichCloud &cloud)
   } else if (data == "binary_compressed") {
     uint32_t csize = 0, usize = 0;
     if (!f.read(reinterpret_cast<char *>(&csize), 4) || !f.read(reinterpret_cast<char *>(&usize), 4)) return false;
-    if ((size_t)usize != points * step) return false;
+    if ((size_t)usize != points * step || (size_t)csize + 8 > remain || (size_t)usize > (size_t)csize * 100 + 64) return false;
     std::vector<uint8_t> cbuf(csize), ubuf(usize);
     if (csize && !f.read(reinterpret_cast<char *>(cbuf.data()), csize)) return false;
     if (usize && lzf_decompress(cbuf.data(), csize, ubuf.data(), usize) != usize) return false;
