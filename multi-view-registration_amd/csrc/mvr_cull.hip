@@ -505,6 +505,15 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   const unsigned long long st_begin = MVR_CLK();
   uint32_t cur[4], nxt[4];
   float cbx[4][6], nbx[4][6];
+  // Wave priority: everything but the distance loop -- candidate search, queue bookkeeping, re-validation, the merge --
+  // is a chain of dependent ballots, read-lanes and box loads that is a third of the instructions and half of the
+  // time.  Those phases run at raised priority, so a wave in them issues ahead of the waves of its SIMD
+  // that are in the distance loop (which have instruction-level parallelism to spare).  Measured on the ring step:
+  // fused launches 0.396 -> 0.374 ms; priority 1 and 3 do the same.
+#ifndef MVR_SETPRIO
+#define MVR_SETPRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(MVR_SETPRIO);
   uint32_t n_cur = next_quad(cur, cbx);
   MVR_MARK(1);
   if (n_cur) fetch(cur);
@@ -520,7 +529,9 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     if (n_nxt) fetch(nxt);                    // in flight during the evaluation below
     const unsigned long long t2 = MVR_CLK();
     MVR_MARK(3);
+    __builtin_amdgcn_s_setprio(0);
     process(cur);
+    __builtin_amdgcn_s_setprio(MVR_SETPRIO);
     MVR_MARK(4);
     const unsigned long long t3 = MVR_CLK();
     // the bounds have shrunk: re-validate the prefetched cells (a cell that is no longer needed is dropped,
