@@ -30,10 +30,36 @@
 
 namespace mvr {
 
+uint32_t *OrderPool::take(size_t bytes, size_t *got)
+{
+  int best = -1;
+  for (int k = 0; k < (int)free.size(); ++k)        // smallest buffer that fits and is not absurdly larger
+    if (free[k].bytes >= bytes && free[k].bytes <= 4 * bytes + (1u << 20) && (best < 0 || free[k].bytes < free[best].bytes)) best = k;
+  if (best < 0) return nullptr;
+  uint32_t *p = free[best].p;
+  *got = free[best].bytes;
+  free.erase(free.begin() + best);
+  return p;
+}
+
+void OrderPool::give(uint32_t *p, size_t bytes)
+{
+  if (!p) return;
+  if (closed || free.size() >= 8) { (void)hipFree(p); return; }
+  free.push_back(Buf{p, bytes});
+}
+
+void OrderPool::close()
+{
+  closed = true;
+  for (Buf &b : free) (void)hipFree(b.p);
+  free.clear();
+}
+
 Order::~Order()
 {
-  if (perm) (void)hipFree(perm);
-  if (inv) (void)hipFree(inv);
+  if (pool) { pool->give(perm, perm_bytes); pool->give(inv, inv_bytes); }
+  else { if (perm) (void)hipFree(perm); if (inv) (void)hipFree(inv); }
 }
 
 namespace {
@@ -399,8 +425,16 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
     }
     if (int rc = ensure(c, c->partials, c->partials_cap, (size_t)1024 * 32)) return rc;
     auto ord = std::make_shared<Order>();
-    MVR_HIP_TRY(c, hipMalloc(&ord->perm, n * 4));
-    MVR_HIP_TRY(c, hipMalloc(&ord->inv, n * 4));
+    ord->pool = c->order_pool;
+    // sized for the cloud's CAPACITY: a target reserved for all its scans gets buffers it can keep re-using as it grows
+    const size_t want = std::max(n, cl.cap) * sizeof(uint32_t);
+    for (uint32_t **slot : {&ord->perm, &ord->inv}) {
+      size_t got = 0;
+      uint32_t *p = c->order_pool ? c->order_pool->take(want, &got) : nullptr;
+      if (!p) { MVR_HIP_TRY(c, hipMalloc(&p, want)); got = want; }
+      *slot = p;
+      (slot == &ord->perm ? ord->perm_bytes : ord->inv_bytes) = got;
+    }
     ord->n = n;
     ProfScope ps(c, MVR_K_GLUE, 40.0 * (double)n);
     const int bb = (int)std::min<size_t>(256, (n + 255) / 256);
@@ -427,7 +461,9 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
     cl.coords_valid = false;
   }
   if (!cl.coords_valid) {
-    if (int rc = ensure(c, cl.sorted, cl.sorted_cap, n)) return rc;
+    // buffers follow the cloud's CAPACITY (a target reserved for all its scans is never re-allocated as it grows)
+    const size_t room = std::max(n, cl.cap), room_tiles = (room + kCullTile - 1) / kCullTile;
+    if (int rc = ensure(c, cl.sorted, cl.sorted_cap, cl.sorted_cap >= n ? n : room)) return rc;
     if (cl.tiles_cap < tiles) {
       (void)hipStreamSynchronize(c->stream);
       if (cl.tlo) (void)hipFree(cl.tlo);
@@ -435,7 +471,7 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
       if (cl.cbox) (void)hipFree(cl.cbox);
       if (cl.sbox) (void)hipFree(cl.sbox);
       cl.tlo = cl.thi = cl.cbox = cl.sbox = nullptr; cl.tiles_cap = 0;
-      const size_t cap = tiles + tiles / 4 + 16;
+      const size_t cap = std::max(tiles + tiles / 4, room_tiles) + 16;
       MVR_HIP_TRY(c, hipMalloc(&cl.tlo, cap * sizeof(float4)));
       MVR_HIP_TRY(c, hipMalloc(&cl.thi, cap * sizeof(float4)));
       MVR_HIP_TRY(c, hipMalloc(&cl.cbox, cap * 8 * sizeof(float4)));

@@ -18,10 +18,25 @@ namespace mvr {
 // Morton ordering of one point SET, shared by every cloud that holds that set
 // (a posed copy of a scan keeps the scan's ordering: rigid motion does not
 // change which points are neighbours).
+// Buffers of dropped orderings, kept for the next one: a target that grows by one scan per align gets a new
+// ordering every time, and hipFree + hipMalloc of its two index arrays (a device-wide synchronisation each) cost
+// more host time than the whole align took on the GPU (0.45 of 1.0 ms, rocprofv3 timeline of the sequential mode).
+// One pool per context: a recycled buffer is next written by a kernel on the same stream, after its last reader.
+struct OrderPool {
+  struct Buf { uint32_t *p; size_t bytes; };
+  std::vector<Buf> free;
+  bool closed = false;
+  uint32_t *take(size_t bytes, size_t *got);
+  void give(uint32_t *p, size_t bytes);
+  void close();
+  ~OrderPool() { close(); }
+};
 struct Order {
   uint32_t *perm = nullptr;   // sorted position -> original index
   uint32_t *inv = nullptr;    // original index  -> sorted position
   size_t n = 0;
+  size_t perm_bytes = 0, inv_bytes = 0;
+  std::shared_ptr<OrderPool> pool;
   ~Order();
 };
 
@@ -93,6 +108,7 @@ struct Ctx {
   Cloud slots[MVR_MAX_SLOTS + 2];          // +2 internal scratch clouds
   uint64_t next_set_id = 1;
   std::map<uint64_t, std::weak_ptr<Order> > orders;   // set_id -> ordering (shared between posed copies)
+  std::shared_ptr<OrderPool> order_pool = std::make_shared<OrderPool>();
   // per-pair work buffers (grown on demand)
   nnkey_t *keys = nullptr;   size_t keys_cap = 0;     // [Ns] forward NN keys (by original source index)
   nnkey_t *rkeys = nullptr;  size_t rkeys_cap = 0;    // [Nt'] reverse NN keys (by list position)
