@@ -138,6 +138,7 @@ struct Ctx {
   Ctx *parent = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *batch_table = nullptr; size_t batch_cap = 0;   // [pairs][32] staging of mvr_pair_moments2_batch
+  char *dn_arena = nullptr; size_t dn_arena_cap = 0;     // scratch of mvr_cloud_denoise (one buffer, carved per call)
   double *h_table = nullptr; size_t h_table_cap = 0;     // pinned host memory the final kernels of mvr_ring_step write straight into (zero-copy)
   // workspace of the fused batch (culled mode): forward keys of all pairs, reverse keys + flags, per-pair partial rows
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;

@@ -26,4 +26,4 @@ with mvr.Context(0) as ctx:
     assert np.array_equal(keep, okeep) and ncomp == oncomp
     print(json.dumps(dict(points=len(pts), kept=int(len(keep)), components=int(ncomp), gpu_ms=1e3 * float(np.median(times[1:])),
                           gpu_ms_first_call=1e3 * times[0], cpu_oracle_ms=1e3 * cpu, points_per_s_gpu=len(pts) / float(np.median(times[1:])),
-                          note="GPU time includes 12 scratch hipMalloc/hipFree, two radix sorts, the union-find pass and the D2H of the kept index list")))
+                          note="GPU time includes two radix sorts, the union-find pass and the D2H of the kept index list")))
