@@ -110,3 +110,54 @@ def test_two_query_groups_per_set(gpu, orc):
             assert np.array_equal(gq, c["query"]) and np.array_equal(gm, c["match"]) and np.array_equal(bits(gdd), bits(c["dist2"])), trial
     finally:
         gpu.tune(cull_q=0)
+
+
+def test_fused_batch_random_graphs(gpu, mvr):
+    """The fused pass (keys by Hilbert position, seeded reverse searches, pair groups, posed index refresh) against
+    one-pair calls on random view graphs: random cloud sizes (empty ones included), duplicated points, self pairs,
+    repeated pairs, query sub-ranges, caps.  Bit for bit.  MVR_FUZZ_TRIALS scales it (default 12)."""
+    import os
+    trials = int(os.environ.get("MVR_FUZZ_TRIALS", "12"))
+    rng = np.random.default_rng(101)
+    try:
+        for trial in range(trials):
+            V = int(rng.integers(2, 8))
+            scale = float(rng.choice([0.5, 5.0, 40.0]))
+            big = int(os.environ.get("MVR_FUZZ_MAX_POINTS", "5000"))          # > 16384: several ballot blocks / super boxes per cloud
+            sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 255, 256, 257, int(rng.integers(1, 5000)), int(rng.integers(1, big))]))
+                     for _ in range(V)]
+            if all(s == 0 for s in sizes):
+                sizes[0] = 100
+            raw = []
+            for v in range(V):
+                p = cloud(rng.standard_normal((sizes[v], 3)) * scale + [0, 0, 900])
+                if sizes[v] > 10 and trial % 3 == 0:
+                    p[rng.integers(0, sizes[v], sizes[v] // 8)] = p[rng.integers(0, sizes[v], sizes[v] // 8)]
+                raw.append(p)
+                gpu.upload(20 + v, p)
+            poses = []
+            for v in range(V):
+                T = np.eye(4); T[:3, 3] = rng.standard_normal(3) * 0.2 * scale
+                a = rng.standard_normal() * 0.05
+                T[0, 0], T[0, 1], T[1, 0], T[1, 1] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+                poses.append(T)
+            gpu.tune(pair_groups=int(rng.choice([1, 2, 4])), posed_refresh=int(rng.integers(0, 2)))
+            gpu.transform_batch(list(range(V)), [20 + v for v in range(V)], poses)
+            npairs = int(rng.integers(1, 20))
+            pairs = [(int(rng.integers(0, V)), int(rng.integers(0, V))) for _ in range(npairs)]
+            ranges = None
+            if trial % 2:
+                ranges = []
+                for s, _ in pairs:
+                    b = int(rng.integers(0, sizes[s] + 1))
+                    ranges.append((b, None if rng.integers(0, 3) == 0 else int(rng.integers(0, sizes[s] - b + 1))))
+            md = float(rng.choice([0.05, 0.5, 4.0])) * scale
+            origin = np.array([0.0, 0.0, 900.0])
+            rec = bool(rng.integers(0, 4))
+            batch = gpu.pair_moments2_batch(pairs, md, origin, ranges=ranges, reciprocal=rec)
+            for k, (s, t) in enumerate(pairs):
+                one = gpu.pair_moments2(s, t, md, origin, q_begin=0 if ranges is None else ranges[k][0],
+                                        q_count=None if ranges is None else ranges[k][1], reciprocal=rec)
+                assert bytes(one) == bytes(batch[k]), (trial, k, pairs[k], sizes, one.n, batch[k].n)
+    finally:
+        gpu.tune(pair_groups=2, posed_refresh=1)
