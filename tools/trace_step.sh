@@ -10,5 +10,6 @@ idx=[i for i,r in enumerate(rows) if 'refresh_sorted' in r['Kernel_Name']]
 w=int(sys.argv[2]); i0,i1=idx[w],idx[w+1]; t0=int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1+1]:
     s=int(r['Start_Timestamp'])-t0; e=int(r['End_Timestamp'])-t0
-    print("%8.1f %8.1f  dur %7.1f  q%s %s" % (s/1e3, e/1e3, (e-s)/1e3, r.get('Queue_Id','?'), r['Kernel_Name'].split('(')[0].split('::')[-1][:40]))
+    name=r['Kernel_Name'].replace('mvr::(anonymous namespace)::','').replace('void ','').split('(')[0][:44]
+    print("%8.1f %8.1f  dur %7.1f  q%s %s" % (s/1e3, e/1e3, (e-s)/1e3, r.get('Queue_Id','?'), name))
 P
