@@ -867,6 +867,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
     fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, w->bkeys + off_s[k]);
     fwd[k].key_by_pos = 1;       // forward keys live in the source's Hilbert order from here on (coalesced for every consumer below)
+    if (reciprocal && qn[k]) { fwd[k].clear = w->bbound + off_t[k]; fwd[k].clear_n = (uint32_t)t.n; }    // the forward launch presets the start bounds
     // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
     rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, w->brkeys + off_t[k]);
     rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
@@ -875,7 +876,6 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   if (phases & 1) { if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc; }
   if (!(phases & 2)) return MVR_OK;
   const bool recip = reciprocal != 0;
-  if (recip && off_t[n_pairs]) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, off_t[n_pairs] * sizeof(uint32_t), w->stream));
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
     const int m = std::min(kBatchPairs, n_pairs - base);
     GlueBatch gb;

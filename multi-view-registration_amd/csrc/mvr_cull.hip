@@ -712,6 +712,8 @@ __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q =
 nn_cull_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
 {
   const CullPair &a = batch.p[blockIdx.y];
+  if (a.clear)        // every block of the pair's row (also those past its last query set) clears its stride of the array
+    for (uint32_t i = blockIdx.x * (64u * W) + threadIdx.x; i < a.clear_n; i += gridDim.x * (64u * W)) a.clear[i] = 0xFFFFFFFFu;
   nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
                           a.keys, a.key_by_pos, a.qbound, evals);
 }

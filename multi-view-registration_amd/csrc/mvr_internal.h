@@ -260,6 +260,7 @@ struct CullPair {
   nnkey_t *keys = nullptr;
   uint32_t q_begin = 0, q_count = 0, nt = 0, n_tiles = 0;
   const uint32_t *qbound = nullptr;   // optional, by sorted position: bits of a distance (squared) within which the query is KNOWN to have a point -- the search starts from that bound instead of the cap
+  uint32_t *clear = nullptr; uint32_t clear_n = 0;   // optional: [clear_n] words this launch sets to ~0 on the side (the pair's start-bound array, before the flag stage: saves a memset launch in the chain of small kernels)
   uint32_t key_by_pos = 0;       // plain queries only: key slot = sorted position (coalesced stores) instead of the original index
 };
 struct CullBatch { CullPair p[kBatchPairs]; float cap2; };
