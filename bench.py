@@ -37,6 +37,49 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def visible_gpus():
+    """GPUs a child process would see, counted in a child so that THIS process never initialises HIP."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                       stderr=subprocess.DEVNULL, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, count_gpus=visible_gpus):
+    """Parent of `python bench.py --gpus N` (no WORLD_SIZE in the environment): N ranks under torch.distributed.run,
+    rank 0's single JSON line forwarded on stdout, non-zero exit if any rank fails.  Refuses when fewer than N GPUs
+    are visible.  MVR_BENCH_LAUNCH_CMD (tests): the command a rank runs instead of this file."""
+    import subprocess
+    have = count_gpus()
+    if have < n:
+        log("bench.py: --gpus %d asked for but only %d GPU(s) visible: refusing (no oversubscription, no CPU ranks)" % (n, have))
+        return 2
+    target = os.environ.get("MVR_BENCH_LAUNCH_CMD", os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), target] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("[bench] launching %d ranks: %s" % (n, " ".join(cmd)))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        log("bench.py: the %d-rank run failed (exit %d, %d JSON line(s))" % (n, r.returncode, len(lines)))
+        sys.stderr.write(r.stdout)
+        return r.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     # stdout carries exactly ONE line (the JSON): libraries that print banners to
     # fd 1 (RCCL prints its version there) are diverted to stderr until the end
@@ -55,7 +98,18 @@ def main():
     ap.add_argument("--nn-mode", type=int, default=1, help="1: exact culled search (default); 0: exact brute force")
     ap.add_argument("--no-bruteforce-pass", action="store_true",
                     help="skip the extra untimed brute-force ring pass that feeds roofline_bruteforce")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed K-step window is repeated this many times after the headline one: min/median/max as extra keys")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process stays a plain parent (it never imports torch nor
+        # touches HIP) and starts N fresh ranks, one per GPU
+        os.dup2(real_stdout, 1)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node equal to --gpus"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import torch
     import torch.distributed as dist

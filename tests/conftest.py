@@ -17,6 +17,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The first `import torch` on a fresh box pages in ~1.3 GB of shared objects (libtorch_hip, librccl, ...) and can
+    take minutes; round 1 met that cost in the middle of the session, inside the first ring test, and read it as a GPU
+    hang (the library's streams play no part, tools/hang_probe.py, profiles/r02_a_hang_probe.log).
+    Pay it here, where the log says what it is.  The library itself needs no import order: the `gpu` fixture no longer
+    touches torch."""
+    if "gpu" in (session.config.getoption("-m") or "") and "not gpu" not in (session.config.getoption("-m") or ""):
+        import time
+        t0 = time.time()
+        import torch  # noqa: F401
+        sys.stderr.write("[conftest] import torch took %.1f s\n" % (time.time() - t0))
+
+
 @pytest.fixture(scope="session")
 def built():
     """Build (or reuse) the in-tree native libraries."""
@@ -42,10 +55,6 @@ def gpu(mvr, request):
     """A GPU context; -m gpu tests fail loudly (no skip, no fallback) without one.
     Every parity test runs against both exact search kernels: the spatially
     culled one (default: waves per query set chosen by launch size; also forced to 1, 2 and 4) and the brute-force one."""
-    # torch (used by the ring tests for streams / the edge table) initialises its HIP state FIRST, as in bench.py:
-    # one full run hung for minutes at the first torch use after dozens of library streams already existed
-    import torch
-    torch.cuda.init()
     ctx = mvr.Context(0)
     ctx.tune(nn_mode=0 if request.param == "brute" else 1)
     if request.param.startswith("culled_w"):

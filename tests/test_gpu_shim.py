@@ -69,13 +69,13 @@ def test_registration_icp_driver(driver, mvr, orc):
     assert [e["view"] for e in out["log"]] == [e["view"] for e in log] == ref_driver.view_order(V) * repeat
     for g, e in zip(out["log"], log):
         assert g["iterations"] == e["iterations"] == 1
-        assert abs(g["n_corr"] - e["n_corr"]) <= 2 and abs(g["mse"] - e["mse"]) < 1e-4
+        assert g["n_corr"] == e["n_corr"] and abs(g["mse"] - e["mse"]) < 1e-9
         T = np.array(g["T"]).reshape(4, 4)
         assert np.abs(T[:3, :3] - e["T"][:3, :3]).max() <= ROT_TOL and np.abs(T[:3, 3] - e["T"][:3, 3]).max() <= TRANS_TOL
     fit = [e for e in log if "fitness" in e]
     gfit = [g["fitness"] for g in out["log"] if g["fitness"] is not None]
     assert len(gfit) == len(fit) == repeat and np.allclose(gfit, [e["fitness"] for e in fit], atol=1e-4)
-    assert_poses(out["poses"], poses, rot=5e-5, trans=5e-4)     # 22 chained aligns
+    assert_poses(out["poses"], poses)
     # refineAxis (registrator.cpp:402-455) moves the mis-calibrated prior towards the true axis
     true_ax = np.array(sp.axis) / np.linalg.norm(sp.axis)
     prior_ax = mvr.synth_prior(sp)[1]
@@ -91,7 +91,7 @@ def test_registration_lum_driver(driver, mvr, orc):
     sp, scans, poses0 = scene(mvr, orc, V, N, 3)
     new, P, corrs, its = ref_driver.lum_pass(orc, scans, poses0, max_d, 16)
     assert out["lum_ncorr"] == [len(c) for c in corrs]
-    assert_poses(out["poses"], new, rot=2e-5, trans=2e-3)
+    assert_poses(out["poses"], new)
 
 
 def test_registration_lum_device_resident(driver, mvr, orc):
@@ -103,8 +103,8 @@ def test_registration_lum_device_resident(driver, mvr, orc):
     sp, scans, poses0 = scene(mvr, orc, V, N, 3)
     new, P, corrs, its = ref_driver.lum_pass(orc, scans, poses0, max_d, 16)
     assert out["lum_ncorr"] == [len(c) for c in corrs] == ref["lum_ncorr"]
-    assert_poses(out["poses"], new, rot=2e-5, trans=2e-3)
-    assert_poses(out["poses"], [np.array(p).reshape(4, 4) for p in ref["poses"]], rot=2e-5, trans=2e-3)
+    assert_poses(out["poses"], new)
+    assert_poses(out["poses"], [np.array(p).reshape(4, 4) for p in ref["poses"]])
 
 
 def test_scan_cloud_denoise(driver, mvr, orc):
@@ -151,10 +151,10 @@ def test_automatic_registration_driver(driver, mvr, orc):
             source, T, st, rc = orc.icp_align(source, target, params)              # aliased: source advances in place
             poses[v] = orc.mat4d_mul(T.astype(np.float64), poses[v])
             g = out["log"][k]; k += 1
-            assert g["view"] == v and abs(g["n_corr"] - st["n_corr"]) <= 2
+            assert g["view"] == v and g["n_corr"] == st["n_corr"]
         target = np.concatenate([target, source])
     assert k == len(out["log"])
-    assert_poses(out["poses"], poses, rot=5e-5, trans=5e-4)
+    assert_poses(out["poses"], poses)
 
 
 def test_pcl_named_api_surface(driver):
