@@ -282,12 +282,22 @@ int  mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots
                   const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                   int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
                   int *lum_iters, double *rows, double *timing_ms);
+/* LUM::incidenceCorrection(pose) (inside lum.compute(), registrator.cpp:654): the 6x6 (row-major) matrix H with
+ * d(R p + t)/d pose = M(p') H for R = Rx Ry Rz and the M of LUM::computeEdge; exposed so that its sign pattern can be
+ * pinned by a numeric Jacobian without a GPU. */
+void mvr_lum_incidence(const double pose[6], double H[36]);
 /* pcl::getTransformation(x,y,z,roll,pitch,yaw) -> column-major 4x4. */
 void mvr_pose_to_mat4(const double pose[6], double T[16]);
 
 /* ---- turntable prior (PointCloud::initRotation point_cloud.cpp:400-413,
  *      Registrator::getRotationMatrix registrator.cpp:331-342) --------------- */
 double mvr_turntable_angle(int view, int n_views);
+/* Registrator::refineAxis (registrator.cpp:402-455, with math_solvers::least_squares, math_solvers.cpp:12-38): the
+ * turntable axis and pivot that best explain the poses of the n REGISTERED views (poses: n x 16, column-major,
+ * column-vector convention).  Axis: least squares of (R_i - I) x = 0 with the row u + v + w = 1, normalised; pivot:
+ * least squares of (R_i - I) p = -t_i with the row p_y = pivot_y (the current pivot's y).  Results are floats, as the
+ * reference's osg::Vec3.  MVR_E_ARG for n <= 0, MVR_E_SINGULAR for a rank-deficient system (outputs untouched). */
+int    mvr_refine_axis(int n, const double *poses, float pivot_y, float axis_out[3], float pivot_out[3]);
 void   mvr_axis_rotation(const double pivot[3], const double axis[3], double angle, double T[16]);
 void   mvr_mat4d_mul(const double A[16], const double B[16], double C[16]);
 void   mvr_mat4f_mul(const float A[16], const float B[16], float C[16]);

@@ -155,6 +155,8 @@ SIGNATURES = {
                                C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
                                C.POINTER(C.c_int), _dp, _dp]),
     "mvr_pose_to_mat4": (None, [_dp, _dp]),
+    "mvr_lum_incidence": (None, [_dp, _dp]),
+    "mvr_refine_axis": (C.c_int, [C.c_int, _dp, C.c_float, _fp, _fp]),
     "mvr_turntable_angle": (C.c_double, [C.c_int, C.c_int]),
     "mvr_axis_rotation": (None, [_dp, _dp, C.c_double, _dp]),
     "mvr_mat4d_mul": (None, [_dp, _dp, _dp]),
@@ -249,6 +251,20 @@ def pose_to_mat4(pose):
     p, T = np.ascontiguousarray(pose, np.float64), np.empty(16)
     _lib.mvr_pose_to_mat4(_p(p, C.c_double), _p(T, C.c_double))
     return from_cm(T)
+
+
+def lum_incidence(pose):
+    p, H = np.ascontiguousarray(pose, np.float64), np.empty(36)
+    _lib.mvr_lum_incidence(_p(p, C.c_double), _p(H, C.c_double))
+    return H.reshape(6, 6)
+
+
+def refine_axis(poses, pivot_y):
+    """Registrator::refineAxis on the registered views' (4,4) column-vector poses -> (rc, axis f32[3], pivot f32[3])."""
+    P = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1, 16)
+    ax, pv = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    rc = _lib.mvr_refine_axis(len(P), _p(P, C.c_double), float(np.float32(pivot_y)), _p(ax, C.c_float), _p(pv, C.c_float))
+    return rc, ax, pv
 
 
 def moments_to_dict(m: PairMoments):

@@ -433,25 +433,33 @@ static int lum_edge_from_moments_T(const mvr_pair_moments2_t *m2, const double T
   return MVR_OK;
 }
 
+// LUM::incidenceCorrection (pcl/registration/impl/lum.hpp): H(X) with
+//   d(R(theta) p + t)/dX = M(p') H(X),   p' = R p + t,   R = Rx Ry Rz (Borrmann et al.),
+// M = [I | ex x p', ez x p', ey x p'] being the matrix LUM::computeEdge builds its sums from (rotational unknowns in
+// the order x, z, y).  Rows 3..5: the rotation vector of the angle increments, w = dtx ex + dty Rx ey + dtz Rx Ry ez;
+// column 5 of the top block: t x (Rx Ry ez).  (SURVEY recalled that column with the pitch's sin/cos swapped; this is
+// the form for which the identity is exact -- tests/test_host.py checks it against a numeric Jacobian.)
 static void lum_incidence(const double pose[6], double out[36])
 {
   std::memset(out, 0, 36 * sizeof(double));
   for (int k = 0; k < 6; ++k) out[7 * k] = 1.0;
   const double cx = std::cos(pose[3]), sx = std::sin(pose[3]), cy = std::cos(pose[4]), sy = std::sin(pose[4]);
   out[4] = pose[1] * sx - pose[2] * cx;
-  out[5] = pose[1] * cx * sy + pose[2] * sx * sy;
+  out[5] = pose[1] * cx * cy + pose[2] * sx * cy;
   out[6 + 3] = pose[2];
   out[6 + 4] = -pose[0] * sx;
-  out[6 + 5] = -pose[0] * cx * sy + pose[2] * cy;
+  out[6 + 5] = -pose[0] * cx * cy + pose[2] * sy;
   out[12 + 3] = -pose[1];
   out[12 + 4] = pose[0] * cx;
-  out[12 + 5] = -pose[0] * sx * sy - pose[1] * cy;
+  out[12 + 5] = -pose[0] * sx * cy - pose[1] * sy;
   out[18 + 5] = sy;
   out[24 + 4] = sx;
   out[24 + 5] = cx * cy;
   out[30 + 4] = cx;
   out[30 + 5] = -sx * cy;
 }
+
+API void mvr_lum_incidence(const double pose[6], double H[36]) { lum_incidence(pose, H); }
 
 // LUM::compute (App. A.6) on per-edge moments.
 API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_pair_moments2_t *m2,
@@ -557,6 +565,66 @@ API int mvr_ring_host_step(int n_views, int ne, const int *es, const int *et, co
     mvr_mat4d_mul(Lf, poses + 16 * (size_t)v, P);
     std::memcpy(poses + 16 * (size_t)v, P, sizeof P);
   }
+  return MVR_OK;
+}
+
+// min |A x - b|, A rows x 3 (row-major), by Givens rotations: the rows are folded one at a time into a 3 x 4
+// triangular system [R | c] (a streaming QR: no storage beyond the triangle, any number of rows).
+namespace {
+struct Tri3 {
+  double r[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  void add(const double a[3], double rhs)
+  {
+    double row[4] = {a[0], a[1], a[2], rhs};
+    for (int k = 0; k < 3; ++k) {
+      if (row[k] == 0.0) continue;
+      const double h = std::hypot(r[k][k], row[k]), c = r[k][k] / h, s = row[k] / h;
+      for (int j = k; j < 4; ++j) {
+        const double t = c * r[k][j] + s * row[j];
+        row[j] = -s * r[k][j] + c * row[j];
+        r[k][j] = t;
+      }
+    }
+  }
+  bool solve(double x[3]) const
+  {
+    for (int k = 2; k >= 0; --k) {
+      if (std::fabs(r[k][k]) < 1e-300) return false;
+      double acc = r[k][3];
+      for (int j = k + 1; j < 3; ++j) acc -= r[k][j] * x[j];
+      x[k] = acc / r[k][k];
+    }
+    return true;
+  }
+};
+}  // namespace
+
+// Registrator::refineAxis (mvr/src/registrator.cpp:402-455; math_solvers::least_squares, math_solvers.cpp:12-38).
+// The turntable axis is the common fixed direction of the registered poses, (R_i - I) x = 0, made inhomogeneous by
+// the row u + v + w = 1 as the reference does; the pivot their common fixed point, (R_i - I) p = -t_i, with p_y
+// pinned to the current pivot's.  Both are 3-unknown least-squares problems: solved by a streaming Givens QR.
+API int mvr_refine_axis(int n, const double *poses, float pivot_y, float axis_out[3], float pivot_out[3])
+{
+  if (n <= 0 || !poses || !axis_out || !pivot_out) return MVR_E_ARG;
+  Tri3 ax, pv;
+  for (int i = 0; i < n; ++i) {
+    const double *P = poses + 16 * (size_t)i;            // column-major [R t]: R(j,k) = P[j + 4 k]
+    for (int j = 0; j < 3; ++j) {
+      const double row[3] = {P[j] - (j == 0), P[j + 4] - (j == 1), P[j + 8] - (j == 2)};
+      ax.add(row, 0.0);
+      pv.add(row, -P[12 + j]);
+    }
+  }
+  const double ones[3] = {1, 1, 1}, ey[3] = {0, 1, 0};
+  ax.add(ones, 1.0);
+  pv.add(ey, (double)pivot_y);
+  double a[3], p[3];
+  if (!ax.solve(a) || !pv.solve(p)) return MVR_E_SINGULAR;
+  // osg::Vec3 (float) semantics of the reference: the solution is stored as floats, the axis normalised in float
+  float v[3] = {(float)a[0], (float)a[1], (float)a[2]};
+  const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (nrm > 0.0f) { const float inv = 1.0f / nrm; v[0] *= inv; v[1] *= inv; v[2] *= inv; }
+  for (int k = 0; k < 3; ++k) { axis_out[k] = v[k]; pivot_out[k] = (float)p[k]; }
   return MVR_OK;
 }
 

@@ -107,6 +107,11 @@ def lib():
         L.orc_solve_dense.argtypes = [C.c_int, dp, dp]
         L.orc_invert6.restype = C.c_int
         L.orc_invert6.argtypes = [dp, dp]
+        L.orc_umeyama_f32.restype = C.c_int
+        L.orc_umeyama_f32.argtypes = [fp, fp, vp, C.c_size_t, C.c_int, fp]
+        L.orc_lum_incidence.argtypes = [dp, dp]
+        L.orc_refine_axis.restype = C.c_int
+        L.orc_refine_axis.argtypes = [C.c_int, dp, C.c_float, fp, fp]
         _lib = L
     return _lib
 
@@ -346,3 +351,26 @@ def solve_dense(A, b):
     x = np.array(b, np.float64)
     rc = lib().orc_solve_dense(len(x), _p(A, C.c_double), _p(x, C.c_double))
     return x if rc == 0 else None
+
+
+def umeyama_f32(src, tgt, corr, block=0):
+    """The estimate in Eigen's own float arithmetic (a model; see orc_umeyama_f32) -> T (4,4) float32 or None."""
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.ascontiguousarray(corr, dtype=CORR_DTYPE)
+    T = np.empty(16, np.float32)
+    rc = lib().orc_umeyama_f32(_p(src, C.c_float), _p(tgt, C.c_float), corr.ctypes.data, len(corr), int(block), _p(T, C.c_float))
+    return from_cm(T) if rc == 0 else None
+
+
+def lum_incidence(pose):
+    p, out = np.ascontiguousarray(pose, np.float64), np.empty(36)
+    lib().orc_lum_incidence(_p(p, C.c_double), _p(out, C.c_double))
+    return out.reshape(6, 6)
+
+
+def refine_axis(poses, pivot_y):
+    """Registrator::refineAxis on a list of registered (4,4) column-vector poses -> (rc, axis float32[3], pivot float32[3])."""
+    P = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(-1, 4, 4).transpose(0, 2, 1)).reshape(-1, 16)
+    ax, pv = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    rc = lib().orc_refine_axis(len(P), _p(P, C.c_double), float(np.float32(pivot_y)), _p(ax, C.c_float), _p(pv, C.c_float))
+    return rc, ax, pv

@@ -543,6 +543,59 @@ API int orc_umeyama(const float *src, const float *tgt, const orc_corr *c, size_
   return 0;
 }
 
+/* Eigen's ACTUAL arithmetic for the same estimate (Scalar = float throughout): a model of
+ * Eigen::umeyama as TransformationEstimationSVD calls it, used only to MEASURE how far the f64-accumulating oracle
+ * above sits from the f32 reference arithmetic (tests/test_oracle.py).
+ *   means : src.rowwise().sum() * (1/M) -- a row of a column-major 3xM matrix is strided, so Eigen's reduction is
+ *           the plain sequential one: ((p0 + p1) + p2) + ... in float;
+ *   sigma : (1/M) * dst_demean * src_demean^T in float; Eigen's product kernel accumulates over blocks of the inner
+ *           dimension: `block` = 0 models one sequential pass, > 0 sums partial products of `block` columns each
+ *           and adds the block sums in order (the kc blocking of the GEBP kernel);
+ *   SVD   : JacobiSVD<Matrix3f>; modelled by the f64 SVD of the float sigma (its own error, ~1e-7, is far below
+ *           the effects measured here), R rounded to float, t = mean_dst - R * mean_src in float. */
+API int orc_umeyama_f32(const float *src, const float *tgt, const orc_corr *c, size_t m, int block, float T[16])
+{
+  if (m < 3) return -1;
+  const float inv = 1.0f / (float)m;
+  float ms[3] = { 0, 0, 0 }, mt[3] = { 0, 0, 0 };
+  for (size_t k = 0; k < m; ++k) {
+    const float *p = src + 4 * (size_t)c[k].query, *q = tgt + 4 * (size_t)c[k].match;
+    for (int d = 0; d < 3; ++d) { ms[d] = ms[d] + p[d]; mt[d] = mt[d] + q[d]; }
+  }
+  for (int d = 0; d < 3; ++d) { ms[d] = ms[d] * inv; mt[d] = mt[d] * inv; }
+  float sig[9] = { 0 }, part[9] = { 0 };
+  size_t in_block = 0;
+  for (size_t k = 0; k < m; ++k) {
+    const float *p = src + 4 * (size_t)c[k].query, *q = tgt + 4 * (size_t)c[k].match;
+    const float dp[3] = { p[0] - ms[0], p[1] - ms[1], p[2] - ms[2] };
+    const float dq[3] = { q[0] - mt[0], q[1] - mt[1], q[2] - mt[2] };
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) { const float pr = dq[r] * dp[cc]; part[3 * r + cc] = part[3 * r + cc] + pr; }
+    if (block > 0 && ++in_block == (size_t)block) {
+      for (int j = 0; j < 9; ++j) { sig[j] = sig[j] + part[j]; part[j] = 0; }
+      in_block = 0;
+    }
+  }
+  for (int j = 0; j < 9; ++j) sig[j] = (sig[j] + part[j]) * inv;
+  double sd[9], U[9], S[3], V[9];
+  for (int j = 0; j < 9; ++j) sd[j] = sig[j];
+  orc_svd3(sd, U, S, V);
+  const double sgn = (det3(U) * det3(V) < 0) ? -1.0 : 1.0;
+  float R[9];
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc)
+      R[3 * r + cc] = (float)(U[3 * r] * V[3 * cc] + U[3 * r + 1] * V[3 * cc + 1] + sgn * U[3 * r + 2] * V[3 * cc + 2]);
+  memset(T, 0, 16 * sizeof(float));
+  for (int r = 0; r < 3; ++r) {
+    for (int cc = 0; cc < 3; ++cc) T[r + 4 * cc] = R[3 * r + cc];
+    float rp = R[3 * r] * ms[0];
+    rp = rp + R[3 * r + 1] * ms[1];
+    rp = rp + R[3 * r + 2] * ms[2];
+    T[r + 12] = mt[r] - rp;
+  }
+  T[15] = 1.0f;
+  return 0;
+}
+
 /* --------------------------------------------------------------------- ICP */
 
 /* a4 + a7 / App. A.1 + A.4.  Call sites mvr/src/registrator.cpp:569,920,1012,1024. */
@@ -766,25 +819,33 @@ API size_t orc_lum_edge(const float *src, const float *tgt, const orc_corr *c, s
   return oci;
 }
 
-static void lum_incidence(const double pose[6], double out[36])
+/* LUM::incidenceCorrection (App. A.6): H(X) with  d(R(theta) p + t)/dX = M(p') H(X),  p' = R p + t, for Borrmann et
+ * al.'s rotation R = Rx(tx) Ry(ty) Rz(tz) and the M of computeEdge above, M = [I | ex x p', ez x p', ey x p'] (the
+ * rotational unknowns are ordered x, z, y).  Rows 3..5 are the rotation vector (x, z, y components) of the three angle
+ * increments, w = dtx ex + dty Rx ey + dtz Rx Ry ez; column 5 of the top block is t x (Rx Ry ez).
+ * SURVEY App. A.6 recalled that column with sin/cos of the pitch swapped and marked the pattern "least certain";
+ * the form below is the one for which the identity holds exactly at any pose (tests/test_oracle.py pins it with a
+ * numeric Jacobian at z ~ 917 mm and non-zero poses). */
+API void orc_lum_incidence(const double pose[6], double out[36])
 {
   memset(out, 0, 36 * sizeof(double));
   for (int k = 0; k < 6; ++k) out[7 * k] = 1.0;
   double cx = cos(pose[3]), sx = sin(pose[3]), cy = cos(pose[4]), sy = sin(pose[4]);
   out[6 * 0 + 4] = pose[1] * sx - pose[2] * cx;
-  out[6 * 0 + 5] = pose[1] * cx * sy + pose[2] * sx * sy;
+  out[6 * 0 + 5] = pose[1] * cx * cy + pose[2] * sx * cy;
   out[6 * 1 + 3] = pose[2];
   out[6 * 1 + 4] = -pose[0] * sx;
-  out[6 * 1 + 5] = -pose[0] * cx * sy + pose[2] * cy;
+  out[6 * 1 + 5] = -pose[0] * cx * cy + pose[2] * sy;
   out[6 * 2 + 3] = -pose[1];
   out[6 * 2 + 4] = pose[0] * cx;
-  out[6 * 2 + 5] = -pose[0] * sx * sy - pose[1] * cy;
+  out[6 * 2 + 5] = -pose[0] * sx * cy - pose[1] * sy;
   out[6 * 3 + 5] = sy;
   out[6 * 4 + 4] = sx;
   out[6 * 4 + 5] = cx * cy;
   out[6 * 5 + 4] = cx;
   out[6 * 5 + 5] = -sx * cy;
 }
+#define lum_incidence orc_lum_incidence
 
 /* LUM::compute (App. A.6); driver call site mvr/src/registrator.cpp:653-654. */
 API int orc_lum_compute(int n, const float *const *clouds, int ne, const int *es,
@@ -840,4 +901,79 @@ API int orc_lum_compute(int n, const float *const *clouds, int ne, const int *es
   }
   free(G); free(B); free(cinv); free(cinvd);
   return it;
+}
+
+/* ------------------------------------------------------------ refineAxis */
+
+/* min |A x - b| for a full-rank rows x 3 system by Householder QR -- what LAPACK dgels does for the reference
+ * (math_solvers::least_squares, mvr/src/math_solvers.cpp:12-38).  A is rows x 3 row-major; both are overwritten. */
+static int lstsq3(double *A, double *b, int rows, double x[3])
+{
+  for (int k = 0; k < 3; ++k) {
+    double nrm = 0;
+    for (int r = k; r < rows; ++r) nrm += A[3 * r + k] * A[3 * r + k];
+    nrm = sqrt(nrm);
+    if (nrm == 0.0) return -1;
+    const double alpha = (A[3 * k + k] > 0) ? -nrm : nrm;
+    double *v = malloc((size_t)rows * sizeof(double));
+    double vn = 0;
+    for (int r = k; r < rows; ++r) { v[r] = A[3 * r + k]; if (r == k) v[r] -= alpha; vn += v[r] * v[r]; }
+    if (vn > 0) {
+      for (int cc = k; cc < 3; ++cc) {
+        double d = 0;
+        for (int r = k; r < rows; ++r) d += v[r] * A[3 * r + cc];
+        d = 2.0 * d / vn;
+        for (int r = k; r < rows; ++r) A[3 * r + cc] -= d * v[r];
+      }
+      double d = 0;
+      for (int r = k; r < rows; ++r) d += v[r] * b[r];
+      d = 2.0 * d / vn;
+      for (int r = k; r < rows; ++r) b[r] -= d * v[r];
+    }
+    free(v);
+  }
+  for (int k = 2; k >= 0; --k) {
+    double sacc = b[k];
+    for (int cc = k + 1; cc < 3; ++cc) sacc -= A[3 * k + cc] * x[cc];
+    if (A[3 * k + k] == 0.0) return -1;
+    x[k] = sacc / A[3 * k + k];
+  }
+  return 0;
+}
+
+/* Registrator::refineAxis (mvr/src/registrator.cpp:402-455).  poses: n registered views' 4x4 poses, column-major,
+ * column-vector convention [R t] (the transpose of the osg::Matrix the reference reads: its A(i*3+j, k) =
+ * matrices[i](k, j) - delta_jk is R - I).  Axis: (R_i - I) x = 0 for all i, plus the row u + v + w = 1, least squares,
+ * then normalised as an osg::Vec3 (float).  Pivot: (R_i - I) p = -t_i for all i, plus the row p_y = pivot_y (the
+ * current pivot's y, a float), least squares, stored as floats.  Returns 0, -1 when n == 0 or a system is rank
+ * deficient (outputs untouched). */
+API int orc_refine_axis(int n, const double *poses, float pivot_y, float axis_out[3], float pivot_out[3])
+{
+  if (n <= 0) return -1;
+  const int rows = 3 * n + 1;
+  double *A = malloc((size_t)rows * 3 * sizeof(double)), *b = malloc((size_t)rows * sizeof(double));
+  double x[3] = { 0, 0, 0 };
+  int rc = 0;
+  for (int pass = 0; pass < 2 && rc == 0; ++pass) {
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < 3; ++j) {
+        for (int k = 0; k < 3; ++k) A[3 * (3 * i + j) + k] = poses[16 * i + j + 4 * k] - ((j == k) ? 1.0 : 0.0);
+        b[3 * i + j] = pass ? -poses[16 * i + 12 + j] : 0.0;
+      }
+    if (pass == 0) { A[3 * (rows - 1)] = 1; A[3 * (rows - 1) + 1] = 1; A[3 * (rows - 1) + 2] = 1; b[rows - 1] = 1; }
+    else { A[3 * (rows - 1)] = 0; A[3 * (rows - 1) + 1] = 1; A[3 * (rows - 1) + 2] = 0; b[rows - 1] = (double)pivot_y; }
+    rc = lstsq3(A, b, rows, x);
+    if (rc) break;
+    if (pass == 0) {
+      /* osg::Vec3 normal(x0,x1,x2); normal.normalize(): float components, float norm */
+      float v[3] = { (float)x[0], (float)x[1], (float)x[2] };
+      float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (nrm > 0.0f) { float inv = 1.0f / nrm; v[0] *= inv; v[1] *= inv; v[2] *= inv; }
+      axis_out[0] = v[0]; axis_out[1] = v[1]; axis_out[2] = v[2];
+    } else {
+      pivot_out[0] = (float)x[0]; pivot_out[1] = (float)x[1]; pivot_out[2] = (float)x[2];
+    }
+  }
+  free(A); free(b);
+  return rc;
 }

@@ -94,6 +94,9 @@ size_t orc_correspondences_mt(const float *src, size_t ns, const float *tgt, siz
  * (dst*src^T / M), [17..19] = singular values. */
 int    orc_umeyama(const float *src, const float *tgt, const orc_corr *c, size_t m,
                    float T[16], double *mom);
+/* the same estimate in Eigen's own arithmetic (float sums, sequential means, optionally blocked product): a model
+ * used to measure the distance between the f64-accumulating oracle and the f32 reference arithmetic. */
+int    orc_umeyama_f32(const float *src, const float *tgt, const orc_corr *c, size_t m, int block, float T[16]);
 /* host-side part only: from the 17 moments to T. */
 void   orc_umeyama_from_moments(const double mean_src[3], const double mean_tgt[3],
                                 const double sigma[9], float T[16], double sv[3]);
@@ -157,6 +160,14 @@ int    orc_lum_compute(int n, const float *const *clouds, int ne, const int *es,
  * order; label (optional, n entries) the smallest index of each point's component.  Returns the number kept. */
 size_t orc_denoise(const float *pts, size_t n, int segment_threshold, double triangle_length,
                    uint32_t *out_index, uint32_t *label, size_t *n_components);
+
+/* LUM::incidenceCorrection (6x6 row-major): see the derivation at its definition. */
+void   orc_lum_incidence(const double pose[6], double out[36]);
+
+/* Registrator::refineAxis (mvr/src/registrator.cpp:402-455) with math_solvers::least_squares
+ * (LAPACK dgels = Householder QR; mvr/src/math_solvers.cpp:12-38).  poses: n registered poses, 4x4 column-major,
+ * column-vector convention.  Returns 0, or -1 (nothing written) for n == 0 / a rank-deficient system. */
+int    orc_refine_axis(int n, const double *poses, float pivot_y, float axis_out[3], float pivot_out[3]);
 
 /* dense solve helpers (exposed for tests) */
 int    orc_solve_dense(int n, double *A /*row-major, destroyed*/, double *b /*in: rhs, out: x*/);

@@ -150,6 +150,50 @@ def test_lum_compute_from_moments_matches_oracle(mvr, orc):
         assert np.abs(moved - base[:, :3]).max() < 0.5
 
 
+def test_product_lum_linearisation_is_the_jacobian_of_the_pose_map(mvr, orc):
+    """The product's own LUM pieces (mvr_lum_edge_from_moments, mvr_lum_incidence) against a numeric Jacobian of the
+    pose map -- no oracle involved (tests/lum_kat.py) -- and then equal to the oracle's."""
+    import lum_kat
+
+    def edge(src, tgt):
+        idx = np.arange(len(src))
+        m2 = mvr.moments2_from_row(_moments_numpy(src, tgt, idx, idx, np.array([0.0, 0.0, 900.0])))
+        rc, MM, MZ, ss = mvr.lum_edge_from_moments(m2, np.zeros(6), np.zeros(6))
+        assert rc == 0
+        return MM, MZ
+
+    rng = np.random.default_rng(78)
+    assert lum_kat.check(edge, mvr.lum_incidence, rng) < 1e-3
+    for _ in range(10):
+        X = np.concatenate([rng.normal(0, 5, 3), rng.normal(0, 0.3, 3)])
+        assert np.array_equal(mvr.lum_incidence(X), orc.lum_incidence(X))
+
+
+def test_refine_axis_matches_oracle(mvr, orc):
+    """mvr_refine_axis (streaming Givens QR) == the oracle's restatement of Registrator::refineAxis
+    (registrator.cpp:402-455, Householder QR as LAPACK dgels) on exact and on perturbed turntable poses, 12 and 36
+    views, any subset of registered views."""
+    rng = np.random.default_rng(79)
+    true_axis = np.array([-0.054323, -0.814921, -0.577020]); true_axis /= np.linalg.norm(true_axis)
+    true_pivot = np.array([-13.382786, 50.223461, 917.4776])
+    for V in (12, 36):
+        poses = [orc.axis_rotation(true_pivot, true_axis, orc.turntable_angle(v, V)) for v in range(1, V)]
+        noisy = []
+        for P in poses:
+            Q = P.copy(); Q[:3, 3] += rng.normal(0, 0.05, 3)
+            noisy.append(orc.mat4d_mul(orc.axis_rotation(true_pivot, rng.normal(0, 1, 3), rng.normal(0, 3e-4)), Q))
+        for ps in (poses, noisy, noisy[:3], noisy[4:5]):
+            rc, ax, pv = mvr.refine_axis(ps, true_pivot[1])
+            rco, axo, pvo = orc.refine_axis(ps, true_pivot[1])
+            assert rc == 0 and rco == 0
+            assert np.abs(ax - axo).max() <= 2e-7 and np.abs(pv - pvo).max() <= 1e-4 * max(1.0, np.abs(pvo).max() / 1000), (ax, axo, pv, pvo)
+        rc, ax, pv = mvr.refine_axis(poses, true_pivot[1])
+        assert abs(abs(ax.astype(np.float64) @ true_axis) - 1) < 1e-6 and np.abs(pv - true_pivot).max() < 1e-3
+    assert mvr.refine_axis([], 0.0)[0] == mvr.E_ARG
+    # identity poses: every direction is fixed -> rank deficient for the pivot (the regulariser rows alone)
+    assert mvr.refine_axis([np.eye(4)] * 3, 0.0)[0] == mvr.E_SINGULAR and orc.refine_axis([np.eye(4)] * 3, 0.0)[0] == -1
+
+
 def test_host_helpers_match_oracle(mvr, orc):
     rng = np.random.default_rng(23)
     for v in range(12):
