@@ -109,8 +109,10 @@ inline double field_value(const uint8_t *p, const PcdField &f)
 {
   switch (f.type) {
     case 'F': if (f.size == 4) { float v; std::memcpy(&v, p, 4); return v; } else { double v; std::memcpy(&v, p, 8); return v; }
-    case 'U': if (f.size == 1) return *p; if (f.size == 2) { uint16_t v; std::memcpy(&v, p, 2); return v; } { uint32_t v; std::memcpy(&v, p, 4); return v; }
-    default:  if (f.size == 1) return (int8_t)*p; if (f.size == 2) { int16_t v; std::memcpy(&v, p, 2); return v; } { int32_t v; std::memcpy(&v, p, 4); return v; }
+    case 'U': if (f.size == 1) return *p; if (f.size == 2) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+              if (f.size == 4) { uint32_t v; std::memcpy(&v, p, 4); return v; } { uint64_t v; std::memcpy(&v, p, 8); return (double)v; }
+    default:  if (f.size == 1) return (int8_t)*p; if (f.size == 2) { int16_t v; std::memcpy(&v, p, 2); return v; }
+              if (f.size == 4) { int32_t v; std::memcpy(&v, p, 4); return v; } { int64_t v; std::memcpy(&v, p, 8); return (double)v; }
   }
 }
 
@@ -161,6 +163,10 @@ inline bool loadPCDFile(const std::string &filename, RichCloud &cloud)
   for (auto &pf : fields) {
     if (pf.size != 1 && pf.size != 2 && pf.size != 4 && pf.size != 8) return false;
     if (pf.count < 1 || pf.count > 4096 || (pf.type != 'F' && pf.type != 'U' && pf.type != 'I')) return false;
+    // SIZE and TYPE must agree, or a decoder that trusts TYPE reads past the bytes SIZE reserved: a float is 4 or 8
+    // bytes (field_value reads exactly that many), the packed colour is one 4-byte value (assign reads 4)
+    if (pf.type == 'F' && pf.size != 4 && pf.size != 8) return false;
+    if ((pf.name == "rgb" || pf.name == "rgba") && pf.size != 4) return false;
     pf.offset = step; step += (size_t)pf.size * pf.count;
     hx |= pf.name == "x"; hy |= pf.name == "y"; hz |= pf.name == "z";
   }
@@ -270,6 +276,73 @@ inline bool savePointsASC(const std::string &filename, const RichCloud &cloud)
   if (file == NULL) return false;
   for (const RichPoint &p : cloud) std::fprintf(file, "%f %f %f %d %d %d\n", p.x, p.y, p.z, (int)p.r, (int)p.g, (int)p.b);
   std::fclose(file);
+  return true;
+}
+
+// pcl::PLYWriter::write<PointXYZ>(filename, cloud) as PointCloud::save uses it (point_cloud.cpp:99-113): ASCII PLY,
+// one vertex element with float x y z, followed by the one-row `camera` element PCL's writer appends (identity axes,
+// viewport = cloud width x height).  PCL is not in this image: the header is a restatement of the PLY format and of
+// PCL's published field list (parity with PCL's own file: unpinned); any header-driven PLY reader accepts it.
+inline bool savePLYFile(const std::string &filename, const PointCloud<PointXYZ> &cloud)
+{
+  FILE *file = std::fopen(filename.c_str(), "w");
+  if (file == NULL) return false;
+  std::fprintf(file, "ply\nformat ascii 1.0\ncomment PCL generated\nelement vertex %zu\n", cloud.size());
+  std::fprintf(file, "property float x\nproperty float y\nproperty float z\n");
+  std::fprintf(file, "element camera 1\nproperty float view_px\nproperty float view_py\nproperty float view_pz\n"
+                     "property float x_axisx\nproperty float x_axisy\nproperty float x_axisz\n"
+                     "property float y_axisx\nproperty float y_axisy\nproperty float y_axisz\n"
+                     "property float z_axisx\nproperty float z_axisy\nproperty float z_axisz\n"
+                     "property float focal\nproperty float scalex\nproperty float scaley\nproperty float centerx\nproperty float centery\n"
+                     "property int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n");
+  for (size_t i = 0; i < cloud.size(); ++i) std::fprintf(file, "%.9g %.9g %.9g\n", cloud.points[i].x, cloud.points[i].y, cloud.points[i].z);
+  std::fprintf(file, "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 %zu 1 0 0\n", cloud.size());
+  const bool ok = std::ferror(file) == 0;
+  std::fclose(file);
+  return ok;
+}
+
+// the matching reader (ASCII PLY, a vertex element that has float/double x y z among its properties; other elements
+// and properties are skipped).  false: malformed / binary / no x y z; the cloud is untouched.
+inline bool loadPLYFile(const std::string &filename, PointCloud<PointXYZ> &cloud)
+{
+  std::ifstream f(filename.c_str());
+  if (!f) return false;
+  std::string line;
+  if (!std::getline(f, line) || line.substr(0, 3) != "ply") return false;
+  struct Elem { std::string name; size_t count = 0; std::vector<std::string> props; };
+  std::vector<Elem> elems;
+  bool ascii = false, ended = false;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line[line.size() - 1] == '\r') line.erase(line.size() - 1);
+    std::istringstream ss(line);
+    std::string key; ss >> key;
+    if (key == "format") { std::string fmt; ss >> fmt; ascii = fmt == "ascii"; }
+    else if (key == "element") { Elem e; if (!(ss >> e.name >> e.count)) return false; elems.push_back(e); }
+    else if (key == "property") { std::string t, n; if (!(ss >> t >> n) || elems.empty()) return false; if (t == "list") return false; elems.back().props.push_back(n); }
+    else if (key == "end_header") { ended = true; break; }
+  }
+  if (!ended || !ascii) return false;
+  PointCloud<PointXYZ> out;
+  bool have = false;
+  for (const Elem &e : elems) {
+    int ix = -1, iy = -1, iz = -1;
+    for (size_t k = 0; k < e.props.size(); ++k) { if (e.props[k] == "x") ix = (int)k; if (e.props[k] == "y") iy = (int)k; if (e.props[k] == "z") iz = (int)k; }
+    const bool vertex = e.name == "vertex";
+    if (vertex && (ix < 0 || iy < 0 || iz < 0)) return false;
+    if (vertex && e.count > (1ull << 32)) return false;
+    for (size_t i = 0; i < e.count; ++i) {
+      if (!std::getline(f, line)) return false;
+      if (!vertex) continue;
+      std::istringstream ss(line);
+      std::vector<double> v(e.props.size());
+      for (size_t k = 0; k < v.size(); ++k) if (!(ss >> v[k])) return false;
+      out.push_back(PointXYZ((float)v[(size_t)ix], (float)v[(size_t)iy], (float)v[(size_t)iz]));
+    }
+    have |= vertex;
+  }
+  if (!have) return false;
+  cloud = out;
   return true;
 }
 

@@ -1,20 +1,18 @@
-// include/mvr/registrator.hpp -- the reference's registration DRIVER, re-hosted
-// on the shim classes of registration.hpp (so it runs on the GPU path).
+// include/mvr/registrator.hpp -- the registration driver on top of the C-ABI: scan objects (raw points + pose +
+// the reference's per-view text/PCD files) and a DEVICE-RESIDENT Registrator.
 //
-// Mirrors, call for call, the non-GUI part of class Registrator
-// (mvr/include/registrator.h:40-59, mvr/src/registrator.cpp):
-//   getRotationMatrix(angle)                       :331-342
-//   computeError(object)                           :466-515
-//   registrationICP(max_it, max_d, obj[, repeat])  :517-588
-//   registrationLUM(seg, max_it, max_d, obj)       :611-678
-//   automaticRegistration / automaticRegistrationICP / automaticRefineTransformation /
-//   refineTransformation                           :746-842, :877-990, :1008-1030
-//   refineAxis(object)                             :402-455 (+ math_solvers::least_squares, math_solvers.cpp:12-38)
-// and of class PointCloud (mvr/src/point_cloud.cpp): getTransformedPoints
-// :290-303, initRotation :400-413, set/getMatrix, isShown/isRegistered.
-// The Qt/OSG/file-tree plumbing (FileSystemModel, QtConcurrent, draggers,
-// rendering, dialogs) is out of scope: `TurntableModel` is an in-memory stand-in
-// for FileSystemModel::getPointCloud(object, view).
+// What it stands for in the reference (mvr/src/registrator.cpp, mvr/src/point_cloud.cpp):
+//   PointCloud::getTransformedPoints :290-303, initRotation :400-413, open :78-95, save :97-123,
+//     load/saveTransformation :305-347, denoise :423-465                     -> ScanCloud
+//   Registrator::getRotationMatrix :331-342, load/save (axis.txt) :258-308   -> Registrator (same formats)
+//   registrationICP :517-588        -> Registrator::registrationICPDevice   (target grows in a device slot)
+//   registrationLUM :611-664        -> Registrator::registrationLUMDevice   (all passes in one native call)
+//   computeError :466-515           -> Registrator::computeErrorDevice      (per-pair count + residual)
+//   refineAxis :402-455             -> Registrator::refineAxis              (mvr_refine_axis)
+//   saveRegisteredPoints :344-400, registration :719-744                    -> same names
+// The Qt/OSG/file-tree plumbing (FileSystemModel, QtConcurrent, draggers, rendering, dialogs) is out of scope:
+// `TurntableModel` is an in-memory stand-in for FileSystemModel::getPointCloud(object, view).
+// The reference's own loops replayed on the PCL-named shim (call-site compatibility): tests/cxx/reference_replay.hpp.
 #pragma once
 
 #include <cstdio>
@@ -23,6 +21,9 @@
 #include <utility>
 #include <vector>
 
+#include <memory>
+
+#include "io.hpp"
 #include "registration.hpp"
 
 namespace mvr {
@@ -36,12 +37,57 @@ class Registrator;
 // osg::MatrixTransform base) + the flags the driver consults.
 class ScanCloud {
  public:
-  PCLPointCloud points;
+  PCLPointCloud points;          // what the registration path sees (point_cloud.cpp:297-299 strips the rest)
+  io::RichCloud rich;            // the full PointXYZRGBNormal records when the scan came from a PCD file; may be empty
   int view = 0;
   bool shown = true;
   bool registered = false;
 
   size_t size() const { return points.size(); }
+  // a counter the device-resident Registrator watches: bump it (touch) after editing `points` by hand
+  unsigned long long revision() const { return revision_; }
+  void touch() { ++revision_; }
+
+  // PointCloud::open (point_cloud.cpp:78-95): the PCD file (ascii / binary / binary_compressed), the pose from the
+  // transformation.txt beside it, registered = view 0 or a non-identity pose.  false: nothing changed.
+  bool open(const std::string &filename)
+  {
+    io::RichCloud loaded;
+    if (!io::loadPCDFile(filename, loaded)) return false;
+    rich.swap(loaded);
+    io::toXYZ(rich, points);
+    filename_ = filename;
+    matrix_.makeIdentity();
+    loadTransformation(folder() + "/transformation.txt");
+    registered = (view == 0) || !matrix_.isIdentity();
+    touch();
+    return true;
+  }
+  // PointCloud::save (point_cloud.cpp:97-123): "*.ply" = the XYZ points in the turntable's canonical frame (pivot at
+  // the origin, axis along +z; the reference hard-codes its calibration there) as an ASCII PLY; anything else = the
+  // rich cloud as binary_compressed PCD.
+  bool save(const std::string &filename) const
+  {
+    if (filename.size() >= 3 && filename.compare(filename.size() - 3, 3, "ply") == 0) {
+      const RowMatrixd transformation = RowMatrixd::translate(13.382786, -50.223461, -917.477600) *
+                                        RowMatrixd::rotateFromTo(-0.054323, -0.814921, -0.577020, 0.0, 0.0, 1.0);
+      PCLPointCloud canon;
+      for (size_t i = 0; i < points.size(); ++i) {
+        const PCLPoint &p = points.points[i];
+        float o[3];
+        for (int k = 0; k < 3; ++k)
+          o[k] = (float)(transformation(0, k) * p.x + transformation(1, k) * p.y + transformation(2, k) * p.z + transformation(3, k));
+        canon.push_back(PCLPoint(o[0], o[1], o[2]));
+      }
+      return io::savePLYFile(filename, canon);
+    }
+    if (rich.size() == points.size()) return io::savePCDFile(filename, rich, io::PCD_BINARY_COMPRESSED);
+    io::RichCloud plain(points.size());
+    for (size_t i = 0; i < points.size(); ++i) { plain[i].x = points.points[i].x; plain[i].y = points.points[i].y; plain[i].z = points.points[i].z; }
+    return io::savePCDFile(filename, plain, io::PCD_BINARY_COMPRESSED);
+  }
+  const std::string &filename() const { return filename_; }
+  std::string folder() const { const size_t k = filename_.find_last_of('/'); return k == std::string::npos ? std::string(".") : filename_.substr(0, k); }
   const RowMatrixd &getMatrix() const { return matrix_; }
   void setMatrix(const RowMatrixd &m) { matrix_ = m; }
   bool isShown() const { return shown; }
@@ -70,8 +116,15 @@ class ScanCloud {
     const size_t before = points.size();
     d.upload(s.s, points);
     size_t kept = 0, comps = 0;
-    d.check(mvr_cloud_denoise(d.ctx(), s.s, segment_threshold, triangle_length, &kept, &comps, nullptr), "mvr_cloud_denoise");
+    std::vector<uint32_t> index(before ? before : 1);
+    d.check(mvr_cloud_denoise(d.ctx(), s.s, segment_threshold, triangle_length, &kept, &comps, index.data()), "mvr_cloud_denoise");
     d.download(s.s, points);
+    if (rich.size() == before) {                   // colours and normals follow their points
+      io::RichCloud r(kept);
+      for (size_t k = 0; k < kept; ++k) r[k] = rich[index[k]];
+      rich.swap(r);
+    }
+    touch();
     return before - kept;
   }
 
@@ -108,6 +161,8 @@ class ScanCloud {
 
  private:
   RowMatrixd matrix_;
+  std::string filename_;
+  unsigned long long revision_ = 0;
 };
 
 // stand-in for FileSystemModel::getPointCloud(object, view): views 0..V-1
@@ -119,9 +174,17 @@ struct TurntableModel {
 
 struct AlignLog { int view; Matrix4f T; int n_corr; double mse; int iterations; double fitness; bool has_fitness; };
 
+// The registration driver of this library: DEVICE-RESIDENT.  The scans of one object are uploaded once and stay in
+// device slots for the whole session; a registration pass moves poses (V x 16 doubles) and per-pair sums
+// (V x 32 doubles) across the bus, never points.  It covers the non-GUI duties of the reference's class Registrator
+// (mvr/include/registrator.h:40-59) -- which pairs are registered in which order with which parameters, and how the
+// result is composed into the views' poses -- without its PCL-shaped data flow (a host cloud rebuilt, re-uploaded and
+// re-indexed at every align).  The reference's own loops, replayed call for call on the PCL-named shim classes, are
+// test infrastructure: tests/cxx/reference_replay.hpp.
 class Registrator {
  public:
   explicit Registrator(TurntableModel *model) : model_(model) {}
+  virtual ~Registrator() {}
 
   // pivot / axis are osg::Vec3 (float) in the reference (registrator.h)
   void setPivotPoint(double x, double y, double z) { pivot_[0] = (float)x; pivot_[1] = (float)y; pivot_[2] = (float)z; }
@@ -163,293 +226,220 @@ class Registrator {
   // point_cloud.cpp:409 generalised from 12 views / 30 degrees
   double viewAngle(int view) const { return mvr_turntable_angle(view, model_->numViews()); }
 
-  // registrator.cpp:466-515: ring pairs (i,i+1) of shown views plus (0, V-1);
-  // returns per pair the reciprocal correspondences (the reference leaves the
-  // visualisation of them commented out, :504-511).
-  std::vector<std::pair<std::pair<int, int>, CorrespondencesPtr> > computeError(int object, double distance_threshold)
+  // ---- sequential registration against the growing model (what registrationICP computes, registrator.cpp:517-588):
+  // views in the order 1, V-1, 2, V-2, ..., V/2 (shown ones only), each aligned to the merged cloud of view 0 and all
+  // views before it, `repeat_times` sweeps.  Device form: the target grows IN PLACE in a reserved slot
+  // (mvr_cloud_append), a view is posed from its resident raw scan (mvr_cloud_transform), aligned (mvr_icp_align: one
+  // 4x4 comes back) and appended; the fitness score of the last view of a sweep is taken as the reference does.
+  void registrationICPDevice(int max_iterations, double max_distance, int object, int repeat_times = 1)
   {
     const int V = model_->numViews();
-    std::vector<bool> shown_flag(V, false);
-    shown_flag[0] = true;
-    for (int i = 1; i < V; ++i) {
-      ScanCloud &pc = model_->getPointCloud(object, i);
-      shown_flag[i] = pc.isShown();
-      if (shown_flag[i]) pc.initRotation(*this);
-    }
-    std::vector<std::pair<int, int> > neighbor_pairs;
-    for (int i = 0; i < V - 1; ++i) if (shown_flag[i] && shown_flag[i + 1]) neighbor_pairs.push_back(std::make_pair(i, i + 1));
-    if (shown_flag[0] && shown_flag[V - 1]) neighbor_pairs.push_back(std::make_pair(0, V - 1));
-    std::vector<std::pair<std::pair<int, int>, CorrespondencesPtr> > result;
-    PCLPointCloud::Ptr source(new PCLPointCloud), target(new PCLPointCloud);
-    for (size_t i = 0; i < neighbor_pairs.size(); ++i) {
-      model_->getPointCloud(object, neighbor_pairs[i].first).getTransformedPoints(*source);
-      model_->getPointCloud(object, neighbor_pairs[i].second).getTransformedPoints(*target);
-      registration::CorrespondenceEstimation<PCLPoint, PCLPoint, float> correspondence_estimation;
-      correspondence_estimation.setInputSource(source);
-      correspondence_estimation.setInputTarget(target);
-      CorrespondencesPtr correspondences(new Correspondences);
-      correspondence_estimation.determineReciprocalCorrespondences(*correspondences, distance_threshold);
-      result.push_back(std::make_pair(neighbor_pairs[i], correspondences));
-    }
-    return result;
-  }
-
-  // registrator.cpp:517-524
-  void registrationICP(int max_iterations, double max_distance, int object, int repeat_times)
-  {
-    for (int i = 0; i < repeat_times; i++) registrationICP(max_iterations, max_distance, object);
-  }
-
-  // registrator.cpp:526-588
-  void registrationICP(int max_iterations, double max_distance, int object)
-  {
-    const int V = model_->numViews();
-    std::vector<ScanCloud *> point_clouds;
-    for (int i = 1; i < V / 2; ++i) {
-      ScanCloud &front_cloud = model_->getPointCloud(object, i);
-      if (front_cloud.isShown()) point_clouds.push_back(&front_cloud);
-      ScanCloud &back_cloud = model_->getPointCloud(object, V - i);
-      if (back_cloud.isShown()) point_clouds.push_back(&back_cloud);
-    }
-    ScanCloud &center_cloud = model_->getPointCloud(object, V / 2);
-    if (center_cloud.isShown()) point_clouds.push_back(&center_cloud);
-    if (point_clouds.empty()) return;
-
-    for (size_t i = 0; i < point_clouds.size(); ++i) point_clouds[i]->initRotation(*this);
-
-    PCLPointCloud::Ptr source(new PCLPointCloud);
-    PCLPointCloud::Ptr target(new PCLPointCloud);
-
-    IterativeClosestPoint<PCLPoint, PCLPoint> icp;
-    icp.setUseReciprocalCorrespondences(true);
-    icp.setMaxCorrespondenceDistance(max_distance);
-    icp.setMaximumIterations(max_iterations);
-    icp.setTransformationEpsilon(0.000001);
-    icp.setEuclideanFitnessEpsilon(64);
-
-    model_->getPointCloud(object, 0).getTransformedPoints(*target);
-    for (size_t i = 0, i_end = point_clouds.size(); i < i_end; ++i) {
-      point_clouds[i]->getTransformedPoints(*source);
-      icp.setInputSource(source);
-      icp.setInputTarget(target);
-      PCLPointCloud transformed_source;
-      icp.align(transformed_source);
-
-      AlignLog entry{point_clouds[i]->getView(), icp.getFinalTransformation(), icp.getStats().n_corr, icp.getStats().mse,
-                     icp.getStats().iterations, 0.0, false};
-      if (i == i_end - 1) {
-        entry.fitness = icp.getFitnessScore(); entry.has_fitness = true;
-        if (verbose) std::cout << "i:" << i << " " << entry.fitness << std::endl;
-      }
-      log.push_back(entry);
-      RowMatrixd result_matrix = PclMatrixCaster<RowMatrixd>(icp.getFinalTransformation());
-      point_clouds[i]->setMatrix(point_clouds[i]->getMatrix() * result_matrix);
-
-      *target += transformed_source;
-    }
-  }
-
-  // registrator.cpp:611-678 (without saveRegisteredPoints / refineAxis / expire)
-  void registrationLUM(int /*segment_threshold*/, int max_iterations, double max_distance, int object)
-  {
-    const int V = model_->numViews();
-    for (int view = 0; view < V; ++view) {
-      ScanCloud &pc = model_->getPointCloud(object, view);
-      pc.initRotation(*this);
-      pc.setRegisterState(true);
-    }
-    int lum_max_iterations = 16;
-    int outer_loop_num = std::max(1, max_iterations / lum_max_iterations);
-    for (int loop = 0; loop < outer_loop_num; ++loop) {
-      registration::LUM<PCLPoint> lum;
-      for (int i = 0; i < V; ++i) {
-        ScanCloud &pc = model_->getPointCloud(object, i);
-        pc.initRotation(*this);
-        PCLPointCloud::Ptr transformed_cloud(new PCLPointCloud);
-        pc.getTransformedPoints(*transformed_cloud);
-        lum.addPointCloud(transformed_cloud);
-      }
-      lum_ncorr.clear();
-      for (int i = 0; i < V; ++i) {
-        int source_idx = i;
-        int target_idx = (i == V - 1) ? (0) : (i + 1);
-        registration::CorrespondenceEstimation<PCLPoint, PCLPoint, float> correspondence_estimation;
-        correspondence_estimation.setInputSource(lum.getPointCloud(source_idx));
-        correspondence_estimation.setInputTarget(lum.getPointCloud(target_idx));
-        CorrespondencesPtr correspondences(new Correspondences);
-        correspondence_estimation.determineReciprocalCorrespondences(*correspondences, max_distance);
-        lum.setCorrespondences(source_idx, target_idx, correspondences);
-        lum_ncorr.push_back((int)correspondences->size());
-      }
-      lum.setMaxIterations(lum_max_iterations);
-      lum.compute();
-      for (int i = 0; i < V; ++i) {
-        Affine3f transformation = lum.getTransformation(i);
-        RowMatrixd osg_transformation = PclMatrixCaster<RowMatrixd>(Matrix4f(transformation.data()));
-        ScanCloud &pc = model_->getPointCloud(object, i);
-        pc.setMatrix(pc.getMatrix() * osg_transformation);
-        pc.setRegisterState(true);
+    if (V < 2) return;
+    Device &d = Device::instance();
+    ensureResident(object);
+    std::vector<int> order;
+    for (int i = 1; i < V / 2; ++i) for (int v : {i, V - i}) if (model_->getPointCloud(object, v).isShown()) order.push_back(v);
+    if (model_->getPointCloud(object, V / 2).isShown() && (order.empty() || order.back() != V / 2) && V / 2 >= 1) order.push_back(V / 2);
+    if (order.empty()) return;
+    size_t total = model_->getPointCloud(object, 0).size();
+    for (int v : order) { model_->getPointCloud(object, v).initRotation(*this); total += model_->getPointCloud(object, v).size(); }
+    mvr_icp_params p = mvr_icp_params();
+    p.use_reciprocal = 1; p.max_corr_dist = max_distance; p.max_iterations = max_iterations;
+    p.transformation_epsilon = 0.000001; p.euclidean_fitness_eps = 64;       // registrator.cpp:558-560
+    SlotGuard target, source, moved;
+    for (int sweep = 0; sweep < repeat_times; ++sweep) {
+      d.check(mvr_cloud_transform(d.ctx(), target.s, raw_[0], model_->getPointCloud(object, 0).getMatrix().asColumnMajorColumnVector()), "mvr_cloud_transform");
+      d.check(mvr_cloud_reserve(d.ctx(), target.s, total), "mvr_cloud_reserve");
+      for (size_t k = 0; k < order.size(); ++k) {
+        ScanCloud &pc = model_->getPointCloud(object, order[k]);
+        d.check(mvr_cloud_transform(d.ctx(), source.s, raw_[(size_t)order[k]], pc.getMatrix().asColumnMajorColumnVector()), "mvr_cloud_transform");
+        float T[16];
+        mvr_icp_stats st = mvr_icp_stats();
+        const int rc = mvr_icp_align(d.ctx(), source.s, target.s, moved.s, &p, T, &st);
+        if (rc != MVR_OK && rc != MVR_E_NOCORR) d.check(rc, "mvr_icp_align");
+        AlignLog entry{pc.getView(), Matrix4f(T), st.n_corr, st.mse, st.iterations, 0.0, false};
+        if (k + 1 == order.size()) {
+          d.check(mvr_fitness(d.ctx(), source.s, target.s, T, DBL_MAX, 0, &entry.fitness), "mvr_fitness");
+          entry.has_fitness = true;
+        }
+        log.push_back(entry);
+        pc.setMatrix(pc.getMatrix() * RowMatrixd(PclMatrixCaster<RowMatrixd>(entry.T)));      // pose <- T_icp o pose
+        d.check(mvr_cloud_append(d.ctx(), target.s, moved.s), "mvr_cloud_append");
       }
     }
   }
 
-  // The same outer passes (registrator.cpp:611-678) with everything DEVICE-RESIDENT -- the form the
-  // reference's loop takes when no correspondence list has to reach the host: the scans are uploaded
-  // once; per outer pass all views are posed and re-indexed by one launch each
-  // (mvr_cloud_transform_batch), the V ring pairs are searched concurrently on worker HIP streams and
-  // reduced to raw second moments (mvr_pair_moments2_batch), and the per-pair solve + LUM + pose
-  // update run on the host from those V x 31 doubles (mvr_ring_host_step).  Same poses as
-  // registrationLUM up to float rounding of the intermediate PCL-style transforms.
+  // ---- global registration over the ring of views (what registrationLUM computes, registrator.cpp:611-664):
+  // max(1, max_iterations / 16) outer passes; a pass = pose all views, reciprocal correspondences + sums of every ring
+  // pair (i -> i+1), Lu-Milios relaxation (16 iterations) on the host from those sums, pose_v <- LUM_v o pose_v.
+  // One native call (mvr_ring_run) runs ALL the passes.
   void registrationLUMDevice(int max_iterations, double max_distance, int object)
   {
     const int V = model_->numViews();
     if (V < 2) return;
     Device &d = Device::instance();
-    std::vector<SlotGuard> raw((size_t)V), posed((size_t)V);
-    std::vector<int> raw_s((size_t)V), posed_s((size_t)V), es((size_t)V), et((size_t)V);
-    double origin[3] = {0.0, 0.0, 0.0};
+    ensureResident(object);
+    std::vector<int> es((size_t)V), et((size_t)V);
+    std::vector<double> poses((size_t)V * 16), rows((size_t)V * 32), pair_n((size_t)V), pair_mse((size_t)V), lum_pose((size_t)V * 6);
     for (int v = 0; v < V; ++v) {
       ScanCloud &pc = model_->getPointCloud(object, v);
-      d.upload(raw[v].s, pc.points);
-      raw_s[v] = raw[v].s; posed_s[v] = posed[v].s;
-      es[v] = v; et[v] = (v == V - 1) ? 0 : v + 1;
-    }
-    if (!model_->getPointCloud(object, 0).points.empty()) {
-      const PCLPoint &p = model_->getPointCloud(object, 0).points.points[0];
-      origin[0] = p.x; origin[1] = p.y; origin[2] = p.z;
-    }
-    const int lum_max_iterations = 16;
-    const int outer_loop_num = std::max(1, max_iterations / lum_max_iterations);
-    std::vector<double> poses((size_t)V * 16), rows((size_t)V * 32), pair_n((size_t)V), pair_mse((size_t)V), lum_pose((size_t)V * 6);
-    for (int loop = 0; loop < outer_loop_num; ++loop) {
-      for (int v = 0; v < V; ++v) {
-        ScanCloud &pc = model_->getPointCloud(object, v);
-        pc.initRotation(*this);
-        pc.setRegisterState(true);
-        std::memcpy(&poses[(size_t)v * 16], pc.getMatrix().asColumnMajorColumnVector(), 16 * sizeof(double));
-      }
-      // posing, reciprocal correspondences + moments of every ring edge, table copy and the LUM solve: one native call
-      int iters = 0;
-      d.check(mvr_ring_step(d.ctx(), V, posed_s.data(), raw_s.data(), V, es.data(), et.data(), max_distance, 1, 0, origin,
-                            lum_max_iterations, poses.data(), lum_pose.data(), nullptr, pair_n.data(), pair_mse.data(), &iters,
-                            rows.data(), nullptr), "mvr_ring_step");
-      lum_ncorr.clear();
-      for (int e = 0; e < V; ++e) lum_ncorr.push_back((int)pair_n[e]);
-      for (int v = 0; v < V; ++v) {
-        RowMatrixd m;
-        std::memcpy(&m(0, 0), &poses[(size_t)v * 16], 16 * sizeof(double));
-        ScanCloud &pc = model_->getPointCloud(object, v);
-        pc.setMatrix(m);
-        pc.setRegisterState(true);
-      }
-    }
-  }
-
-  // registrator.cpp:1020-1030 / :1008-1018: `icp_.align(*source_)` with the
-  // output aliasing the input, pose accumulated per repeat.
-  void refineTransformation(int repeat_times, int source_index)
-  {
-    for (int i = 0; i < repeat_times; i++) {
-      icp_.align(*source_);
-      RowMatrixd result_matrix = PclMatrixCaster<RowMatrixd>(icp_.getFinalTransformation());
-      point_clouds_[source_index]->setMatrix(point_clouds_[source_index]->getMatrix() * result_matrix);
-      log.push_back(AlignLog{point_clouds_[source_index]->getView(), icp_.getFinalTransformation(), icp_.getStats().n_corr,
-                             icp_.getStats().mse, icp_.getStats().iterations, 0.0, false});
-    }
-  }
-
-  // The evident intent of automaticRegistration (:746-842) + automaticRegistrationICP
-  // (:877-990): add the views one at a time, register each new view against the
-  // merged target of all earlier ones with `repeat_times` in-place aligns, append
-  // it.  (The original indexes point_clouds_ out of bounds for view >= 2 and
-  // re-registers earlier views cumulatively -- SURVEY App. C.1; never calls
-  // setTransformationEpsilon -- App. C.3.)
-  void automaticRegistration(int object, int max_iterations, int repeat_times, double max_distance,
-                             double euclidean_fitness_epsilon)
-  {
-    const int V = model_->numViews();
-    if (!target_) target_.reset(new PCLPointCloud);
-    if (!source_) source_.reset(new PCLPointCloud);
-    model_->getPointCloud(object, 0).getTransformedPoints(*target_);
-    point_clouds_.clear();
-    for (int view_number = 1; view_number < V; ++view_number) {
-      ScanCloud &pc = model_->getPointCloud(object, view_number);
-      point_clouds_.push_back(&pc);
-      const int source_index = (int)point_clouds_.size() - 1;
       pc.initRotation(*this);
       pc.setRegisterState(true);
-      icp_.setUseReciprocalCorrespondences(true);
-      icp_.setMaxCorrespondenceDistance(max_distance);
-      icp_.setMaximumIterations(max_iterations);
-      icp_.setEuclideanFitnessEpsilon(euclidean_fitness_epsilon);
-      pc.getTransformedPoints(*source_);
-      icp_.setInputSource(source_);
-      icp_.setInputTarget(target_);
-      refineTransformation(repeat_times, source_index);
-      *target_ += *source_;
+      std::memcpy(&poses[(size_t)v * 16], pc.getMatrix().asColumnMajorColumnVector(), 16 * sizeof(double));
+      es[(size_t)v] = v; et[(size_t)v] = (v + 1) % V;
+    }
+    const int lum_iterations = 16, passes = std::max(1, max_iterations / lum_iterations);     // registrator.cpp:623-624
+    int iters = 0;
+    d.check(mvr_ring_run(d.ctx(), passes, V, posed_.data(), raw_.data(), V, es.data(), et.data(), max_distance, 1, 0, origin_,
+                         lum_iterations, poses.data(), lum_pose.data(), nullptr, pair_n.data(), pair_mse.data(), &iters, rows.data(),
+                         nullptr), "mvr_ring_run");
+    lum_ncorr.clear();
+    for (int e = 0; e < V; ++e) lum_ncorr.push_back((int)pair_n[(size_t)e]);
+    for (int v = 0; v < V; ++v) {
+      RowMatrixd m;
+      std::memcpy(&m(0, 0), &poses[(size_t)v * 16], 16 * sizeof(double));
+      model_->getPointCloud(object, v).setMatrix(m);
     }
   }
 
-  // registrator.cpp:402-455: least-squares turntable axis from the registered
-  // poses: (R^T - I) x = 0 with u+v+w = 1, then pivot from (R^T - I) p = -t with
-  // p_y pinned.  math_solvers::least_squares (LAPACK dgels) -> normal equations here.
-  void refineAxis(int object)
+  // ---- residuals over the ring (what computeError gathers, registrator.cpp:466-515): neighbouring shown views
+  // (i, i+1) plus (0, V-1); per pair the number of reciprocal correspondences within the threshold and the sum of
+  // their squared distances.  All views are posed by one launch, all pairs searched by one launch per stage; only
+  // 32 doubles per pair reach the host.
+  struct PairResidual { int source, target; size_t n; double sum_d2; };
+  std::vector<PairResidual> computeErrorDevice(int object, double distance_threshold)
   {
     const int V = model_->numViews();
-    std::vector<RowMatrixd> matrices;
-    for (int i = 1; i < V; ++i) {
-      ScanCloud &pc = model_->getPointCloud(object, i);
-      if (!pc.isRegistered()) continue;
-      matrices.push_back(pc.getMatrix());
+    std::vector<PairResidual> out;
+    if (V < 2) return out;
+    Device &d = Device::instance();
+    ensureResident(object);
+    std::vector<char> shown((size_t)V, 0);
+    std::vector<int> dst, src;
+    std::vector<double> T;
+    for (int v = 0; v < V; ++v) {
+      ScanCloud &pc = model_->getPointCloud(object, v);
+      shown[(size_t)v] = v == 0 || pc.isShown();
+      if (!shown[(size_t)v]) continue;
+      if (v) pc.initRotation(*this);
+      dst.push_back(posed_[(size_t)v]); src.push_back(raw_[(size_t)v]);
+      T.insert(T.end(), pc.getMatrix().asColumnMajorColumnVector(), pc.getMatrix().asColumnMajorColumnVector() + 16);
     }
-    if (matrices.empty()) return;
-    const size_t rows = 3 * matrices.size() + 1;
-    std::vector<double> A(rows * 3, 0.0), b(rows, 0.0);
-    for (size_t i = 0; i < matrices.size(); ++i)
-      for (int j = 0; j < 3; ++j)
-        for (int k = 0; k < 3; ++k) A[(i * 3 + j) * 3 + k] = matrices[i](k, j) - ((j == k) ? 1.0 : 0.0);
-    const size_t idx = 3 * matrices.size();
-    A[idx * 3 + 0] = 1; A[idx * 3 + 1] = 1; A[idx * 3 + 2] = 1; b[idx] = 1;
-    double x[3];
-    if (!leastSquares3(A, b, x)) return;
-    const double n = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    setAxisNormal(x[0] / n, x[1] / n, x[2] / n);
-    for (size_t i = 0; i < matrices.size(); ++i) for (int j = 0; j < 3; ++j) b[i * 3 + j] = -matrices[i](3, j);
-    A[idx * 3 + 0] = 0; A[idx * 3 + 1] = 1; A[idx * 3 + 2] = 0; b[idx] = pivot_[1];
-    if (!leastSquares3(A, b, x)) return;
-    setPivotPoint(x[0], x[1], x[2]);
+    d.check(mvr_cloud_transform_batch(d.ctx(), (int)dst.size(), dst.data(), src.data(), T.data()), "mvr_cloud_transform_batch");
+    std::vector<int> ps, pt;
+    for (int i = 0; i + 1 < V; ++i) if (shown[(size_t)i] && shown[(size_t)i + 1]) { out.push_back(PairResidual{i, i + 1, 0, 0.0}); }
+    if (V > 2 && shown[0] && shown[(size_t)V - 1]) out.push_back(PairResidual{0, V - 1, 0, 0.0});
+    for (const PairResidual &r : out) { ps.push_back(posed_[(size_t)r.source]); pt.push_back(posed_[(size_t)r.target]); }
+    if (out.empty()) return out;
+    std::vector<mvr_pair_moments2_t> m2(out.size());
+    d.check(mvr_pair_moments2_batch(d.ctx(), (int)out.size(), ps.data(), pt.data(), distance_threshold, 1, 0, nullptr, nullptr, origin_,
+                                    m2.data(), nullptr), "mvr_pair_moments2_batch");
+    for (size_t k = 0; k < out.size(); ++k) { out[k].n = (size_t)m2[k].n; out[k].sum_d2 = m2[k].sum_d2; }
+    return out;
   }
 
+  // ---- turntable axis and pivot from the registered views' poses (registrator.cpp:402-455): mvr_refine_axis.
+  // Returns false (nothing changed) when no view but view 0 is registered or the poses do not determine an axis.
+  bool refineAxis(int object)
+  {
+    const int V = model_->numViews();
+    std::vector<double> poses;
+    for (int v = 1; v < V; ++v) {
+      const ScanCloud &pc = model_->getPointCloud(object, v);
+      if (!pc.isRegistered()) continue;
+      poses.insert(poses.end(), pc.getMatrix().asColumnMajorColumnVector(), pc.getMatrix().asColumnMajorColumnVector() + 16);
+    }
+    if (poses.empty()) return false;
+    float axis[3], pivot[3];
+    if (mvr_refine_axis((int)(poses.size() / 16), poses.data(), pivot_[1], axis, pivot) != MVR_OK) return false;
+    for (int k = 0; k < 3; ++k) { axis_[k] = axis[k]; pivot_[k] = pivot[k]; }
+    return true;
+  }
+
+  // ---- the merged object (registrator.cpp:344-400, the step registration() ends with, :719-744): every registered
+  // view's points (and normals) moved by its pose -- the normals by the FULL affine including the translation, as
+  // the reference does -- concatenated in view order and written as <folder>/points.pcd
+  // (binary_compressed) and <folder>/points.asc.  Views that only hold XYZ points contribute zero colour / normals.
+  // Returns the number of points written, 0 on failure.
+  size_t saveRegisteredPoints(int object, const std::string &folder, io::RichCloud *merged_out = nullptr)
+  {
+    const int V = model_->numViews();
+    io::RichCloud merged;
+    for (int v = 0; v < V; ++v) {
+      const ScanCloud &pc = model_->getPointCloud(object, v);
+      if (!pc.isRegistered()) continue;
+      const RowMatrixd &M = pc.getMatrix();
+      auto pre = [&M](float x, float y, float z, float out[3]) {              // osg::Matrixd::preMult(Vec3f): (x, y, z, 1) * M / w
+        const double w = 1.0 / (M(0, 3) * x + M(1, 3) * y + M(2, 3) * z + M(3, 3));
+        for (int k = 0; k < 3; ++k) out[k] = (float)((M(0, k) * x + M(1, k) * y + M(2, k) * z + M(3, k)) * w);
+      };
+      for (size_t j = 0; j < pc.size(); ++j) {
+        io::RichPoint q = j < pc.rich.size() ? pc.rich[j] : io::RichPoint();
+        const PCLPoint &p = pc.points.points[j];
+        float o[3];
+        pre(p.x, p.y, p.z, o); q.x = o[0]; q.y = o[1]; q.z = o[2];
+        pre(q.normal_x, q.normal_y, q.normal_z, o); q.normal_x = o[0]; q.normal_y = o[1]; q.normal_z = o[2];
+        merged.push_back(q);
+      }
+    }
+    const bool ok = io::savePCDFile(folder + "/points.pcd", merged, io::PCD_BINARY_COMPRESSED) && io::savePointsASC(folder + "/points.asc", merged);
+    const size_t n = merged.size();
+    if (merged_out) merged_out->swap(merged);
+    return ok ? n : 0;
+  }
+
+  // ---- Registrator::registration (registrator.cpp:719-744): denoise every view, give it its prior, mark it
+  // registered, save the merged cloud, refine the axis.
+  size_t registration(int object, int segment_threshold, double triangle_length, const std::string &folder)
+  {
+    for (int v = 0; v < model_->numViews(); ++v) {
+      ScanCloud &pc = model_->getPointCloud(object, v);
+      pc.denoise(segment_threshold, triangle_length);
+      pc.initRotation(*this);
+      pc.setRegisterState(true);
+    }
+    const size_t n = saveRegisteredPoints(object, folder);
+    refineAxis(object);
+    return n;
+  }
+
+  // the scans of the model changed on the host (loaded, denoised, edited): upload them again at the next use
+  void invalidate() { resident_object_ = -1; }
+
   std::vector<AlignLog> log;       // one entry per align (what the reference prints / writes to fitness_scores.txt)
-  std::vector<int> lum_ncorr;      // correspondences per ring edge of the last LUM pass
-  bool verbose = false;
+  std::vector<int> lum_ncorr;      // correspondences per ring edge of the last global pass
 
  private:
-  static bool leastSquares3(const std::vector<double> &A, const std::vector<double> &b, double x[3])
+  // raw scans -> device slots (once per object and per revision of its clouds); posed copies get slots of their own
+  void ensureResident(int object)
   {
-    double N[9] = {0}, r[3] = {0};
-    const size_t rows = b.size();
-    for (size_t i = 0; i < rows; ++i)
-      for (int j = 0; j < 3; ++j) {
-        r[j] += A[i * 3 + j] * b[i];
-        for (int k = 0; k < 3; ++k) N[3 * j + k] += A[i * 3 + j] * A[i * 3 + k];
-      }
-    const double det = N[0] * (N[4] * N[8] - N[5] * N[7]) - N[1] * (N[3] * N[8] - N[5] * N[6]) + N[2] * (N[3] * N[7] - N[4] * N[6]);
-    if (det == 0.0) return false;
-    const double inv[9] = {(N[4] * N[8] - N[5] * N[7]) / det, (N[2] * N[7] - N[1] * N[8]) / det, (N[1] * N[5] - N[2] * N[4]) / det,
-                           (N[5] * N[6] - N[3] * N[8]) / det, (N[0] * N[8] - N[2] * N[6]) / det, (N[2] * N[3] - N[0] * N[5]) / det,
-                           (N[3] * N[7] - N[4] * N[6]) / det, (N[1] * N[6] - N[0] * N[7]) / det, (N[0] * N[4] - N[1] * N[3]) / det};
-    for (int j = 0; j < 3; ++j) x[j] = inv[3 * j] * r[0] + inv[3 * j + 1] * r[1] + inv[3 * j + 2] * r[2];
-    return true;
+    const int V = model_->numViews();
+    unsigned long long rev = 0;
+    for (int v = 0; v < V; ++v) rev += model_->getPointCloud(object, v).revision() + (unsigned long long)model_->getPointCloud(object, v).size() * 1000003ull;
+    if (resident_object_ == object && resident_rev_ == rev && (int)raw_.size() == V) return;
+    Device &d = Device::instance();
+    raw_guard_.clear(); posed_guard_.clear(); raw_.clear(); posed_.clear();
+    for (int v = 0; v < V; ++v) {
+      raw_guard_.emplace_back(new SlotGuard); posed_guard_.emplace_back(new SlotGuard);
+      raw_.push_back(raw_guard_.back()->s); posed_.push_back(posed_guard_.back()->s);
+      d.upload(raw_.back(), model_->getPointCloud(object, v).points);
+    }
+    origin_[0] = origin_[1] = origin_[2] = 0.0;           // moments are taken about a point of the data: small magnitudes
+    if (V && !model_->getPointCloud(object, 0).points.empty()) {
+      const PCLPoint &p = model_->getPointCloud(object, 0).points.points[0];
+      origin_[0] = p.x; origin_[1] = p.y; origin_[2] = p.z;
+    }
+    resident_object_ = object; resident_rev_ = rev;
   }
 
   TurntableModel *model_;
   float pivot_[3] = {0, 0, 0};
   float axis_[3] = {0, 0, 1};
-  // members of the reference's Registrator (registrator.h:88-93)
-  std::vector<ScanCloud *> point_clouds_;
-  PCLPointCloud::Ptr source_, target_;
-  IterativeClosestPoint<PCLPoint, PCLPoint> icp_;
+  int resident_object_ = -1;
+  unsigned long long resident_rev_ = 0;
+  std::vector<std::unique_ptr<SlotGuard> > raw_guard_, posed_guard_;
+  std::vector<int> raw_, posed_;
+  double origin_[3] = {0, 0, 0};
 };
 
 // point_cloud.cpp:400-413

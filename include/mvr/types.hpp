@@ -152,6 +152,24 @@ struct RowMatrixd {
   // is exactly this object's row-major storage.
   const double *asColumnMajorColumnVector() const { return &m[0][0]; }
   static RowMatrixd translate(double x, double y, double z) { RowMatrixd r; r.m[3][0] = x; r.m[3][1] = y; r.m[3][2] = z; return r; }
+  // osg::Matrix::rotate(from, to): the shortest rotation that takes direction `from` to direction `to` (v' = v * M)
+  static RowMatrixd rotateFromTo(double fx, double fy, double fz, double tx, double ty, double tz)
+  {
+    const double fn = std::sqrt(fx * fx + fy * fy + fz * fz), tn = std::sqrt(tx * tx + ty * ty + tz * tz);
+    fx /= fn; fy /= fn; fz /= fn; tx /= tn; ty /= tn; tz /= tn;
+    const double cx = fy * tz - fz * ty, cy = fz * tx - fx * tz, cz = fx * ty - fy * tx;
+    const double sn = std::sqrt(cx * cx + cy * cy + cz * cz), cs = fx * tx + fy * ty + fz * tz;
+    if (sn < 1e-12) {
+      if (cs > 0) return RowMatrixd();
+      // opposite directions: half a turn about any axis orthogonal to `from`
+      double ax = 0, ay = -fz, az = fy;
+      if (std::fabs(fx) < std::fabs(fy) && std::fabs(fx) < std::fabs(fz)) { ax = 0; ay = -fz; az = fy; }
+      else if (std::fabs(fy) < std::fabs(fz)) { ax = -fz; ay = 0; az = fx; }
+      else { ax = -fy; ay = fx; az = 0; }
+      return rotate(3.14159265358979323846, ax, ay, az);
+    }
+    return rotate(std::atan2(sn, cs), cx, cy, cz);
+  }
   // right-handed rotation by `angle` about `axis`, acting as v' = v * M
   static RowMatrixd rotate(double angle, double ax, double ay, double az)
   {

@@ -99,7 +99,9 @@ typedef struct {
   double sp[3], sq[3];        /* sum p, sum q                               */
   double spp[6], sqq[6];      /* sum p p^T, sum q q^T : xx xy xz yy yz zz   */
   double spq[9];              /* sum p q^T, row-major                       */
-} mvr_pair_moments2_t;
+  double sum_d2;              /* sum of the accepted correspondences' squared distances (the f32 values the search
+                                 found, added in f64): the pair's residual; 0 when the caller supplied the pairs */
+} mvr_pair_moments2_t;       /* 32 doubles: exactly one row of the device edge table */
 
 /* ---- context -------------------------------------------------------------- */
 int  mvr_ctx_create(mvr_ctx **ctx, int device_id);
@@ -129,7 +131,9 @@ int  mvr_cloud_clear(mvr_ctx *ctx, int slot);
  * length: the Euclidean MST is a subgraph of the Delaunay triangulation), drop the components with fewer than
  * segment_threshold points; the cloud in `slot` is replaced by the kept points, component after component (ordered
  * by their smallest point index), points in index order -- the reference's output order.  kept_index (optional,
- * host, capacity = old size) receives the original indices of the kept points. */
+ * host, capacity = old size) receives the original indices of the kept points.  One documented difference: exact
+ * duplicate points are ordinary members of their component here, while CGAL's insert keeps only the first of them as a
+ * vertex (the later copies become isolated and are dropped by any segment_threshold > 1). */
 int  mvr_cloud_denoise(mvr_ctx *ctx, int slot, int segment_threshold, double triangle_length,
                        size_t *n_kept, size_t *n_components, uint32_t *kept_index);
 /* PointCloud::getTransformedPoints (point_cloud.cpp:290-303): f32 points times
@@ -137,7 +141,9 @@ int  mvr_cloud_denoise(mvr_ctx *ctx, int slot, int segment_threshold, double tri
  * dst_slot may equal src_slot. */
 int  mvr_cloud_transform(mvr_ctx *ctx, int dst_slot, int src_slot, const double T[16]);
 /* the same for `count` clouds in ONE launch (the loop over all scans that poses them before a
- * global iteration, registrator.cpp:630-637): T = count x 16 doubles. */
+ * global iteration, registrator.cpp:630-637): T = count x 16 doubles.  The entries run concurrently: a destination
+ * slot may not appear twice, nor be the source of ANOTHER entry (MVR_E_ARG); dst[k] == src[k] poses in place.
+ * mvr_ring_step / mvr_ring_run hand their posed_slots / raw_slots to this call and inherit the rule. */
 int  mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst_slots, const int *src_slots, const double *T);
 /* pcl transformPointCloud / ICP::transformCloud (inside align, App. A.1):
  * x' = ((T00 x + T01 y) + T02 z) + T03 in f32, no contraction. */

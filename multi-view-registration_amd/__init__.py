@@ -85,7 +85,7 @@ class PairMoments(C.Structure):
 class PairMoments2(C.Structure):
     _fields_ = [("n", C.c_double), ("origin", C.c_double * 3), ("sp", C.c_double * 3),
                 ("sq", C.c_double * 3), ("spp", C.c_double * 6), ("sqq", C.c_double * 6),
-                ("spq", C.c_double * 9)]
+                ("spq", C.c_double * 9), ("sum_d2", C.c_double)]
 
 
 class SynthParams(C.Structure):

@@ -607,18 +607,29 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
   if (!ctx || count < 0 || (count && (!dst || !src || !T))) return MVR_E_ARG;
   for (int k = 0; k < count; ++k) if (!slot_ok(dst[k]) || !slot_ok(src[k])) return MVR_E_ARG;
   Ctx *c = CTX(ctx);
+  // All entries run in ONE launch (blockIdx.y = cloud): a slot written twice, or written by one entry and read by
+  // another, would be a data race (and a destination that has to grow would free a buffer another entry still reads).
+  // Refused up front; dst[k] == src[k] (in place) is fine.
+  for (int j = 0; j < count; ++j)
+    for (int k = 0; k < count; ++k)
+      if (j != k && (dst[j] == dst[k] || dst[j] == src[k]))
+        return set_error(c, MVR_E_ARG, "mvr_cloud_transform_batch: a destination slot appears twice or is another entry's source");
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   std::vector<const float4 *> in((size_t)count);
   std::vector<float4 *> out((size_t)count);
   std::vector<size_t> n((size_t)count);
+  std::vector<char> single((size_t)count, 0);
   for (int k = 0; k < count; ++k) {
     if (c->slots[src[k]].has_normals) {          // normals ride along: the one-cloud path rotates them too
       if (int rc = mvr_cloud_transform(ctx, dst[k], src[k], T + (size_t)k * 16)) return rc;
-      n[k] = 0; in[k] = nullptr; out[k] = nullptr;
+      single[k] = 1;
       continue;
     }
     n[k] = c->slots[src[k]].n;
     if (dst[k] != src[k]) { c->slots[dst[k]].n = 0; if (int rc = cloud_reserve(c, c->slots[dst[k]], n[k], false)) return rc; }
+  }
+  for (int k = 0; k < count; ++k) {              // pointers are taken only after every reserve is done
+    if (single[k]) { n[k] = 0; in[k] = nullptr; out[k] = nullptr; continue; }
     in[k] = c->slots[src[k]].pts; out[k] = c->slots[dst[k]].pts;
   }
   // bookkeeping first (host side only): the destinations are posed copies of their sources' point sets
@@ -637,10 +648,7 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
   if (c->nn_mode != 0 && c->posed_refresh)
     for (int k = 0; k < count; ++k) {
       if (!in[k] || dst[k] == src[k] || n[k] == 0) continue;
-      bool again = false;                                   // a slot written twice keeps its LAST pose: leave it to the lazy path
-      for (int j = 0; j < count; ++j) again |= (j != k && dst[j] == dst[k]);
-      for (int j = 0; j < count; ++j) again |= (dst[j] == src[k]);          // ... and so does a source that is also written
-      if (!again) cand.push_back(k);
+      cand.push_back(k);
     }
   std::vector<char> done((size_t)count, 0);
   for (int pass = 0; pass < 2; ++pass) {                    // pass 0: with the points, before the transform launch; pass 1: the rest, after it
@@ -805,7 +813,7 @@ API int mvr_pair_moments2(mvr_ctx *ctx, int ss, int ts, double max_dist, int rec
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   if (int rc = moments2_impl(c, ss, ts, max_dist, reciprocal, fma, qb, qn, origin, c->moments)) return rc;
   if (int rc = read_moments(c, 32)) return rc;
-  static_assert(sizeof(mvr_pair_moments2_t) == 31 * sizeof(double), "moments2 layout");
+  static_assert(sizeof(mvr_pair_moments2_t) == 32 * sizeof(double), "moments2 layout");
   std::memcpy(out, c->h_moments, sizeof *out);
   return MVR_OK;
 }
@@ -997,7 +1005,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
   }
   if (status != MVR_OK) return status;
   if (out) {
-    static_assert(sizeof(mvr_pair_moments2_t) == 31 * sizeof(double), "moments2 layout");
+    static_assert(sizeof(mvr_pair_moments2_t) == 32 * sizeof(double), "moments2 layout");
     std::vector<double> h((size_t)n_pairs * 32);
     MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -140,14 +140,18 @@ __global__ void jump_kernel(uint32_t *__restrict__ parent, size_t n)
   if (gp != p) __atomic_store_n(&parent[i], gp, __ATOMIC_RELAXED);       // any ancestor is a valid parent
 }
 
-__global__ void label_kernel(uint32_t *__restrict__ parent, size_t n, uint32_t *__restrict__ size, uint32_t *__restrict__ counters)
+__global__ void label_kernel(uint32_t *__restrict__ parent, size_t n, uint32_t *__restrict__ label, uint32_t *__restrict__ size,
+                             uint32_t *__restrict__ counters)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   uint32_t r = 0;
   if (live) {
     r = uf_find(parent, (uint32_t)i);      // (whatever depth the jumping rounds left: correctness does not depend on their number)
-    parent[i] = r;               // roots are final here (no unions run concurrently): label = smallest index of the component
+    // The label goes to its OWN array: other threads' finds are still halving paths through node i, and one of them
+    // could store a non-root ancestor into parent[i] after a root written there (then read back as a label of size 0).
+    // Roots are final here (no unions run concurrently): label = smallest index of the component.
+    label[i] = r;
     if (r == (uint32_t)i) atomicAdd(&counters[0], 1u);          // number of components
   }
   // component sizes: the lanes of a wave that share a root add once (most of a wave belongs to the one big component)
@@ -247,10 +251,11 @@ int denoise_cloud(Ctx *c, Cloud &cl, int segment_threshold, double triangle_leng
   MVR_HIP_TRY(c, hipMemsetAsync(size, 0, n * sizeof(uint32_t), c->stream));
   MVR_HIP_TRY(c, hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), c->stream));
   for (int round = 0; round < 16; ++round) hipLaunchKernelGGL(jump_kernel, dim3(nb), dim3(256), 0, c->stream, parent, n);
-  hipLaunchKernelGGL(label_kernel, dim3(nb), dim3(256), 0, c->stream, parent, n, size, counters);
+  uint32_t *label = key_a;          // the unsorted keys are dead since the sort
+  hipLaunchKernelGGL(label_kernel, dim3(nb), dim3(256), 0, c->stream, parent, n, label, size, counters);
   // 3. keep and order
   const uint32_t thr = segment_threshold > 0 ? (uint32_t)segment_threshold : 0u;
-  hipLaunchKernelGGL(order_kernel, dim3(nb), dim3(256), 0, c->stream, parent, size, n, thr, okey_a, counters);
+  hipLaunchKernelGGL(order_kernel, dim3(nb), dim3(256), 0, c->stream, label, size, n, thr, okey_a, counters);
   MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortKeys(tmp, bytes2, okey_a, okey_b, (int)n, 0, 64, c->stream));
   uint32_t hc[4];
   MVR_HIP_TRY(c, hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, c->stream));

@@ -2,7 +2,9 @@
 // a GPU: the reference's text formats (transformation.txt, axis.txt), the
 // OSG <-> Eigen matrix bridge (PclMatrixCaster), the turntable prior and
 // Registrator::refineAxis.  Prints JSON for tests/test_shim_host.py.
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "mvr/io.hpp"
@@ -124,7 +126,68 @@ int main(int argc, char **argv)
   std::printf("\"path\":\"%s\"},", io::pointsFilename("/data/ws", 7, 3).c_str());
   PointCloud<PointXYZ> xyz;
   io::toXYZ(cloud, xyz);
-  std::printf("\"xyz\":[%zu,%.9g,%.9g]", xyz.size(), xyz.points[5].x, xyz.points[5].data[3]);
+  std::printf("\"xyz\":[%zu,%.9g,%.9g],", xyz.size(), xyz.points[5].x, xyz.points[5].data[3]);
+
+  // ---- ScanCloud::open / save (point_cloud.cpp:78-123): PCD + the transformation.txt beside it; "*.ply" writes the
+  // XYZ points in the turntable's canonical frame (pivot -> origin, axis -> +z)
+  {
+    ScanCloud sc; sc.view = 1;
+    const bool missing = sc.open(dir + "/nope.pcd");
+    io::RichCloud three(3);
+    const double a = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    three[0].x = (float)piv[0]; three[0].y = (float)piv[1]; three[0].z = (float)piv[2];
+    three[1].x = (float)(piv[0] + 10.0 * ax[0] / a); three[1].y = (float)(piv[1] + 10.0 * ax[1] / a); three[1].z = (float)(piv[2] + 10.0 * ax[2] / a);
+    three[2].x = (float)(piv[0] + 5.0); three[2].y = (float)piv[1]; three[2].z = (float)piv[2]; three[2].r = 9;
+    io::savePCDFile(dir + "/points.pcd", three, io::PCD_BINARY_COMPRESSED);       // dir also holds view 1's transformation.txt (saved above)
+    const bool opened = sc.open(dir + "/points.pcd");
+    std::printf("\"open\":[%d,%d,%zu,%zu,%d,%d],", (int)missing, (int)opened, sc.size(), sc.rich.size(), (int)sc.isRegistered(), (int)sc.rich[2].r);
+    print16("opened_pose", sc.getMatrix());
+    const bool ply = sc.save(dir + "/canon.ply"), pcd = sc.save(dir + "/copy.pcd");
+    PointCloud<PointXYZ> canon;
+    const bool plyback = io::loadPLYFile(dir + "/canon.ply", canon);
+    io::RichCloud copy;
+    const bool pcdback = io::loadPCDFile(dir + "/copy.pcd", copy);
+    std::printf("\"ply\":[%d,%d,%d,%d,%zu,%zu,%d],\"canon\":[", (int)ply, (int)pcd, (int)plyback, (int)pcdback, canon.size(), copy.size(), (int)copy[2].r);
+    for (size_t i = 0; i < canon.size(); ++i) std::printf("%.9g,%.9g,%.9g%s", canon.points[i].x, canon.points[i].y, canon.points[i].z, i + 1 < canon.size() ? "," : "");
+    std::printf("],");
+    // a PLY another writer could have produced: double coordinates, an extra property, a face element
+    { FILE *f = std::fopen((dir + "/foreign.ply").c_str(), "w");
+      std::fprintf(f, "ply\nformat ascii 1.0\nelement vertex 2\nproperty double z\nproperty uchar q\nproperty double x\nproperty double y\nelement face 0\nproperty int n\nend_header\n3 7 1 2\n6 8 4 5\n");
+      std::fclose(f); }
+    PointCloud<PointXYZ> fp;
+    const bool fok = io::loadPLYFile(dir + "/foreign.ply", fp);
+    { FILE *f = std::fopen((dir + "/binary.ply").c_str(), "w"); std::fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n"); std::fclose(f); }
+    PointCloud<PointXYZ> keep; keep.push_back(PointXYZ(1, 2, 3));
+    const bool bok = io::loadPLYFile(dir + "/binary.ply", keep);
+    std::printf("\"foreign_ply\":[%d,%zu,%.9g,%.9g,%.9g,%d,%zu],", (int)fok, fp.size(), fok ? fp.points[1].x : 0.f, fok ? fp.points[1].y : 0.f, fok ? fp.points[1].z : 0.f, (int)bok, keep.size());
+  }
+  // ---- Registrator::saveRegisteredPoints (registrator.cpp:344-400): registered views only, points AND normals moved
+  // by the full pose (translation included, App. C.5), colours kept; points.pcd + points.asc
+  {
+    TurntableModel m2; m2.views.resize(3);
+    for (int v = 0; v < 3; ++v) {
+      ScanCloud &pc = m2.views[v]; pc.view = v;
+      for (int i = 0; i < 4 + v; ++i) {
+        pc.points.push_back(PointXYZ(10.f * v + i, -3.f + i, 900.f + v));
+        io::RichPoint q; q.x = pc.points.points[i].x; q.y = pc.points.points[i].y; q.z = pc.points.points[i].z;
+        q.r = (uint8_t)(40 + v); q.g = (uint8_t)i; q.b = 7; q.normal_x = 0.f; q.normal_y = 0.6f; q.normal_z = 0.8f;
+        pc.rich.push_back(q);
+      }
+    }
+    m2.views[1].setMatrix(model.views[1].getMatrix());
+    m2.views[0].setRegisterState(true); m2.views[1].setRegisterState(true);      // view 2 is NOT registered: left out
+    Registrator r2(&m2);
+    const std::string out_dir = dir + "/merged";
+    std::string cmd = "mkdir -p '" + out_dir + "'";
+    if (std::system(cmd.c_str()) != 0) return 9;
+    io::RichCloud merged;
+    const size_t n = r2.saveRegisteredPoints(0, out_dir, &merged);
+    io::RichCloud back;
+    const bool ok = io::loadPCDFile(out_dir + "/points.pcd", back);
+    std::printf("\"merged\":[%zu,%d,%zu,%d,%d],", n, (int)ok, back.size(), (int)back[4].r, (int)back[4].g);
+    std::printf("\"merged_p4\":[%.9g,%.9g,%.9g,%.9g,%.9g,%.9g],", back[4].x, back[4].y, back[4].z, back[4].normal_x, back[4].normal_y, back[4].normal_z);
+    std::printf("\"merged_p0\":[%.9g,%.9g,%.9g,%.9g,%.9g,%.9g]", back[0].x, back[0].y, back[0].z, back[0].normal_x, back[0].normal_y, back[0].normal_z);
+  }
   std::printf("}\n");
   return 0;
 }

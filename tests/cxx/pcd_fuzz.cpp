@@ -61,6 +61,49 @@ int main(int argc, char **argv)
     mvr::io::RichCloud c2;
     if (mvr::io::loadPCDFile(fb, c2)) return 5;
     ++rejected; }
+  // SIZE / TYPE cross-mutations: every combination of the header's sizes and types on a body that is
+  // exactly points * step bytes long -- a decoder that trusts TYPE over SIZE reads past the end of the last record
+  // (ASan reports it); float fields of 1 or 2 bytes and a colour that is not 4 bytes wide must be refused.
+  {
+    const int sizes[4] = {1, 2, 4, 8};
+    const char types[3] = {'F', 'U', 'I'};
+    size_t combos = 0;
+    for (const char *data : {"binary", "binary_compressed"})
+      for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) for (int c = 0; c < 12; ++c) for (int last = 0; last < 2; ++last) {
+        const int sz[3] = {sizes[a % 4], sizes[b % 4], sizes[c % 4]};
+        const char ty[3] = {types[a / 4], types[b / 4], types[c / 4]};
+        const char *third = last ? "rgb" : "z";           // the colour field is decoded as 4 bytes whatever TYPE says
+        const std::string fields = last ? std::string("x y z rgb") : std::string("x y z");
+        const size_t step = (size_t)sz[0] + sz[1] + (last ? 4 + (size_t)sz[2] : (size_t)sz[2]);
+        const size_t npts = 3;
+        std::vector<uint8_t> body(npts * step, 0x3f);
+        const std::string fb = dir + "/cross.pcd";
+        { std::ofstream out(fb, std::ios::binary);
+          out << "VERSION .7\nFIELDS " << fields << "\nSIZE " << sz[0] << " " << sz[1] << " " << (last ? 4 : sz[2]);
+          if (last) out << " " << sz[2];
+          out << "\nTYPE " << ty[0] << " " << ty[1] << " " << (last ? 'F' : ty[2]);
+          if (last) out << " " << ty[2];
+          out << "\nCOUNT 1 1 1" << (last ? " 1" : "") << "\nWIDTH " << npts << "\nHEIGHT 1\nPOINTS " << npts << "\nDATA " << data << "\n";
+          if (std::string(data) == "binary") out.write((const char *)body.data(), (std::streamsize)body.size());
+          else {
+            std::vector<uint8_t> comp;
+            mvr::io::lzf_compress(body.data(), body.size(), comp);
+            const uint32_t cs = (uint32_t)comp.size(), us = (uint32_t)body.size();
+            out.write((const char *)&cs, 4); out.write((const char *)&us, 4); out.write((const char *)comp.data(), (std::streamsize)comp.size());
+          } }
+        (void)third;
+        mvr::io::RichCloud c2;
+        const bool ok = mvr::io::loadPCDFile(fb, c2);
+        bool must_reject = false;
+        for (int k = 0; k < 3; ++k) must_reject |= (ty[k] == 'F' && sz[k] != 4 && sz[k] != 8);
+        if (last && sz[2] != 4) must_reject = true;
+        if (ok && must_reject) { std::printf("accepted SIZE %d %d %d TYPE %c %c %c (%s)\n", sz[0], sz[1], sz[2], ty[0], ty[1], ty[2], data); return 6; }
+        if (!ok && !must_reject) { std::printf("refused a consistent header SIZE %d %d %d TYPE %c %c %c (%s)\n", sz[0], sz[1], sz[2], ty[0], ty[1], ty[2], data); return 7; }
+        if (ok) ++accepted; else ++rejected;
+        ++combos;
+      }
+    std::printf("size/type combinations=%zu\n", combos);
+  }
   std::printf("accepted=%zu rejected=%zu\n", accepted, rejected);
   return 0;
 }

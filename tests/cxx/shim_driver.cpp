@@ -4,16 +4,19 @@
 // to compare with the oracle-based restatement of the same driver loops.
 //
 // usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
-//   mode: seq | lum | lumdev | denoise | auto | err | api
+//   mode: seq | lum | auto | err | api          the reference's loops on the PCL-named shim (reference_replay.hpp)
+//         seqdev | lumdev | errdev | register      the product's device-resident drivers (mvr/registrator.hpp)
+//         denoise
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
 #define MVR_ALIAS_PCL
-#include "mvr/registrator.hpp"
+#include "reference_replay.hpp"
 
 using namespace mvr;
+using mvr_replay::ReplayRegistrator;
 
 static void print_pose(const RowMatrixd &m, bool last)
 {
@@ -49,7 +52,7 @@ int main(int argc, char **argv)
       model.views[v].points.resize(N);
       if (mvr_synth_view(&sp, v, N, model.views[v].points.points[0].data, nullptr) != MVR_OK) return 3;
     }
-    Registrator reg(&model);
+    ReplayRegistrator reg(&model);       // is-a mvr::Registrator: the device-resident drivers are reachable through it too
     double piv[3], ax[3];
     mvr_synth_prior(&sp, piv, ax);
     reg.setPivotPoint(piv[0], piv[1], piv[2]);
@@ -62,6 +65,33 @@ int main(int argc, char **argv)
       reg.registrationLUM(10, 16 * repeat, max_d, 0);
       std::printf("\"lum_ncorr\":[");
       for (size_t i = 0; i < reg.lum_ncorr.size(); ++i) std::printf("%d%s", reg.lum_ncorr[i], i + 1 < reg.lum_ncorr.size() ? "," : "");
+      std::printf("],");
+    } else if (mode == "seqdev") {
+      reg.registrationICPDevice(1000, max_d, 0, repeat);
+    } else if (mode == "errdev") {
+      auto pairs = reg.computeErrorDevice(0, max_d);
+      std::printf("\"pairs\":[");
+      for (size_t i = 0; i < pairs.size(); ++i)
+        std::printf("[%d,%d,%zu,%.17g]%s", pairs[i].source, pairs[i].target, pairs[i].n, pairs[i].sum_d2, i + 1 < pairs.size() ? "," : "");
+      std::printf("],");
+    } else if (mode == "register") {
+      // Registrator::registration: denoise + prior + merged cloud on disk (points.pcd / points.asc) + refined axis;
+      // argv[7] = output folder
+      const std::string folder = argc > 7 ? argv[7] : ".";
+      for (int v = 0; v < V; ++v) {       // colours / normals ride along: view v is painted (v, 2v, 255 - v)
+        ScanCloud &pc = model.views[v];
+        pc.rich.resize(pc.points.size());
+        for (size_t i = 0; i < pc.points.size(); ++i) {
+          io::RichPoint &q = pc.rich[i];
+          q.x = pc.points.points[i].x; q.y = pc.points.points[i].y; q.z = pc.points.points[i].z;
+          q.r = (uint8_t)v; q.g = (uint8_t)(2 * v); q.b = (uint8_t)(255 - v); q.normal_x = 0.f; q.normal_y = 0.f; q.normal_z = 1.f;
+        }
+      }
+      const size_t n = reg.registration(0, 10, 2.5, folder);
+      io::RichCloud back;
+      const bool ok = io::loadPCDFile(folder + "/points.pcd", back);
+      std::printf("\"merged\":%zu,\"reloaded\":%zu,\"ok\":%d,\"sizes\":[", n, back.size(), (int)ok);
+      for (int v = 0; v < V; ++v) std::printf("%zu%s", model.views[v].size(), v + 1 < V ? "," : "");
       std::printf("],");
     } else if (mode == "lumdev") {
       reg.registrationLUMDevice(16 * repeat, max_d, 0);
@@ -132,9 +162,9 @@ int main(int argc, char **argv)
       std::printf("}%s", i + 1 < reg.log.size() ? "," : "");
     }
     std::printf("],");
-    if (mode == "seq" || mode == "auto" || mode == "lum" || mode == "lumdev") {
+    if (mode == "seq" || mode == "auto" || mode == "lum" || mode == "lumdev" || mode == "seqdev") {
       for (int v = 0; v < V; ++v) model.views[v].setRegisterState(true);
-      reg.refineAxis(0);
+      if (mode == "lumdev" || mode == "seqdev") reg.mvr::Registrator::refineAxis(0); else reg.refineAxis(0);
       std::printf("\"refined_pivot\":[%.9g,%.9g,%.9g],\"refined_axis\":[%.9g,%.9g,%.9g],", reg.getPivotPoint()[0], reg.getPivotPoint()[1],
                   reg.getPivotPoint()[2], reg.getAxisNormal()[0], reg.getAxisNormal()[1], reg.getAxisNormal()[2]);
     }

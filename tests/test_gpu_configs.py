@@ -68,7 +68,7 @@ def test_config2_point_to_plane_200k_vs_oracle(gpu, orc, mvr):
         T, st, rc = gpu.icp_align(1, 0, 2, mvr.icp_params(point_to_plane=True, **kw))
         out, To, sto, _ = orc.icp_align_p2plane(src, tgt, tn, orc.make_params(**kw))
         assert rc == 0 and st["iterations"] == sto["iterations"] and st["state"] == sto["state"]
-        assert st["n_corr"] == sto["n_corr"] and st["n_corr"] > 100000
+        assert st["n_corr"] == sto["n_corr"] and st["n_corr"] > 30000
         assert abs(st["mse"] - sto["mse"]) < 1e-9
         assert_pose_close(T, To, kw)
         assert np.array_equal(bits(gpu.download(2)), bits(orc.transform_f32(T, src)))
@@ -167,7 +167,7 @@ def test_config5_fused_step_36x1M_properties(mvr, ring):
         for e in (0, 17, 35):                                  # one pair of every launch of <= 16 pairs
             s, t = edges[e]
             single = ctx.pair_moments2(s, t, max_d, origin)
-            assert np.array_equal(np.frombuffer(bytes(single), np.float64), rows[e, :31]), e
+            assert np.array_equal(np.frombuffer(bytes(single), np.float64), rows[e, :32]), e
             q, m, d = ctx.correspondences(s, t, max_d)
             assert len(q) == int(rows[e, 0]) and len(np.unique(m)) == len(m) and np.all(np.diff(q) > 0)
             assert np.all(d <= np.float32(max_d * max_d))

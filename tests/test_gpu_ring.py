@@ -144,6 +144,28 @@ def test_transform_batch_equals_single_transforms(gpu, mvr):
     assert bytes(a) == bytes(b) and a.n > 100
 
 
+def test_transform_batch_refuses_aliased_slots(gpu, mvr):
+    """The entries of mvr_cloud_transform_batch run in one launch: a destination that appears twice, or that is another
+    entry's source, is an argument error (ADVICE r1) -- also through mvr_ring_step, which forwards its slot lists;
+    nothing is written in that case."""
+    g = load_golden("ring_12x2048.npz")
+    scans, poses0 = list(g["scans"]), list(g["poses0"])
+    for v in range(3):
+        gpu.upload(30 + v, scans[v])
+    gpu.transform_batch([33, 34], [30, 31], poses0[:2])
+    before = gpu.download(33).copy()
+    for dst, src in (([33, 33], [30, 31]), ([33, 30], [30, 31]), ([31, 34], [30, 31]), ([33, 34, 33], [30, 31, 32])):
+        with pytest.raises(mvr.MvrError) as e:
+            gpu.transform_batch(dst, src, poses0[:len(dst)])
+        assert e.value.status == mvr.E_ARG
+    assert np.array_equal(gpu.download(33), before)
+    with pytest.raises(mvr.MvrError) as e:      # posed slot of view 1 == raw slot of view 0
+        gpu.ring_step([33, 30, 34], [30, 31, 32], [(0, 1), (1, 2), (2, 0)], poses0[:3], 8.0, np.zeros(3))
+    assert e.value.status == mvr.E_ARG
+    gpu.transform_batch([30, 34], [30, 31], poses0[:2])          # in place + a plain entry: fine
+    assert np.array_equal(gpu.download(30).view(np.uint32), before.view(np.uint32))
+
+
 def test_posed_index_refresh_equals_lazy_refresh(gpu, mvr):
     """In culled mode mvr_cloud_transform_batch also brings the posed copies' index up to date, straight from the
     sources' sorted copies (tune key posed_refresh).  Same searches, bit for bit, as the lazy gather refresh --

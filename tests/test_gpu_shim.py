@@ -1,8 +1,10 @@
-"""GPU tests of the C++ drop-in shim (include/mvr/*.hpp): the reference's own
-driver loops (Registrator::registrationICP / registrationLUM / computeError /
-automaticRegistration, mvr/src/registrator.cpp) compiled against the PCL-named
-shim classes, run on the GPU, and compared with the same loops restated on the
-CPU oracle (tests/ref_driver.py) on identical synthetic scans."""
+"""GPU tests of the C++ layer (include/mvr/*.hpp) through tests/cxx/shim_driver:
+  * the reference's own driver loops (Registrator::registrationICP / registrationLUM / computeError /
+    automaticRegistration, mvr/src/registrator.cpp), replayed call for call on the PCL-named shim classes
+    (tests/cxx/reference_replay.hpp -- call-site compatibility), and
+  * the product's device-resident drivers (mvr::Registrator::registrationICPDevice / registrationLUMDevice /
+    computeErrorDevice / registration),
+both compared with the same loops restated on the CPU oracle (tests/ref_driver.py) on identical synthetic scans."""
 import json
 import os
 import subprocess
@@ -37,8 +39,8 @@ def nn_mode_env(request):
         os.environ["MVR_NN_MODE"] = old
 
 
-def run(exe, mode, V, N, max_d, repeat, config):
-    r = subprocess.run([exe, mode, str(V), str(N), str(max_d), str(repeat), str(config)], stdout=subprocess.PIPE,
+def run(exe, mode, V, N, max_d, repeat, config, *extra):
+    r = subprocess.run([exe, mode, str(V), str(N), str(max_d), str(repeat), str(config)] + [str(e) for e in extra], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ))
     assert r.returncode == 0, r.stderr
     return json.loads(r.stdout), r.stderr
@@ -164,3 +166,62 @@ def test_pcl_named_api_surface(driver):
     assert "Not enough correspondences" in err
     assert out["n_oneway"] > out["n_recip"] > 100
     assert np.isfinite(out["fitness_after_alias"])
+
+
+def test_registration_icp_device_resident(driver, mvr, orc):
+    """Registrator::registrationICPDevice (scans uploaded once, target grown in a device slot, one 4x4 per align
+    back) == the oracle-driven restatement of registrationICP (registrator.cpp:517-588), align by align."""
+    V, N, max_d, repeat = 12, 3000, 8.0, 2
+    out, _ = run(driver, "seqdev", V, N, max_d, repeat, 3)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 3)
+    poses, log = ref_driver.sequential_icp(orc, scans, poses0, orc.make_params(max_dist=max_d, max_iter=1000), V, repeat=repeat)
+    assert [e["view"] for e in out["log"]] == [e["view"] for e in log]
+    for g, e in zip(out["log"], log):
+        assert g["iterations"] == e["iterations"] == 1 and g["n_corr"] == e["n_corr"] and abs(g["mse"] - e["mse"]) < 1e-9
+        T = np.array(g["T"]).reshape(4, 4)
+        assert np.abs(T[:3, :3] - e["T"][:3, :3]).max() <= ROT_TOL and np.abs(T[:3, 3] - e["T"][:3, 3]).max() <= TRANS_TOL
+    gfit = [g["fitness"] for g in out["log"] if g["fitness"] is not None]
+    assert np.allclose(gfit, [e["fitness"] for e in log if "fitness" in e], atol=1e-6)
+    assert_poses(out["poses"], poses)
+    # the refined axis (mvr_refine_axis) equals the oracle's refineAxis on the final poses
+    piv32 = np.float32(mvr.synth_prior(sp)[0][1])
+    rc, ax, pv = orc.refine_axis(poses[1:], piv32)
+    assert rc == 0 and np.abs(np.array(out["refined_axis"]) - ax).max() < 1e-6 and np.abs(np.array(out["refined_pivot"]) - pv).max() < 2e-3
+
+
+def test_compute_error_device_resident(driver, mvr, orc):
+    """Registrator::computeErrorDevice: per ring pair (+ (0, V-1)) the count and the residual sum of the reciprocal
+    correspondences -- equal to the oracle's lists (registrator.cpp:466-515)."""
+    V, N, max_d = 12, 2500, 6.0
+    out, _ = run(driver, "errdev", V, N, max_d, 1, 5)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 5)
+    clouds = [orc.transform_f64(poses0[v], scans[v]) for v in range(V)]
+    exp_pairs = [(i, i + 1) for i in range(V - 1)] + [(0, V - 1)]
+    assert [(p[0], p[1]) for p in out["pairs"]] == exp_pairs
+    for (s, t), p in zip(exp_pairs, out["pairs"]):
+        c = orc.correspondences(clouds[s], clouds[t], max_d)
+        assert p[2] == len(c) and abs(p[3] - float(c["dist2"].astype(np.float64).sum())) < 1e-9 * max(1.0, p[3])
+
+
+def test_registration_writes_the_merged_cloud(driver, mvr, orc, tmp_path):
+    """Registrator::registration (registrator.cpp:719-744): every view denoised, posed by its prior, merged into
+    points.pcd / points.asc (saveRegisteredPoints, :344-400)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pcd_py
+    V, N = 4, 5000
+    out, _ = run(driver, "register", V, N, 4.0, 1, 3, tmp_path)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 3)
+    keeps = [orc.denoise(scans[v], 10, 2.5)[0] for v in range(V)]
+    assert out["sizes"] == [len(k) for k in keeps] and out["merged"] == sum(out["sizes"]) == out["reloaded"] and out["ok"] == 1
+    hdr, rec = pcd_py.read_pcd(os.path.join(tmp_path, "points.pcd"))
+    assert len(rec["x"]) == out["merged"]
+    off = 0
+    for v in range(V):
+        exp = orc.transform_f64(poses0[v], scans[v][keeps[v]])
+        got = np.stack([rec["x"][off:off + len(exp)], rec["y"][off:off + len(exp)], rec["z"][off:off + len(exp)]], 1)
+        assert np.array_equal(got.astype(np.float32).view(np.uint32), np.ascontiguousarray(exp[:, :3]).view(np.uint32)), v
+        rgb = rec["rgb"].view(np.uint32)[off:off + len(exp)]
+        assert np.all(rgb == ((v << 16) | ((2 * v) << 8) | (255 - v)))
+        off += len(exp)
+    assert len(open(os.path.join(tmp_path, "points.asc")).read().strip().split("\n")) == out["merged"]

@@ -71,3 +71,4 @@ def test_pcd_reader_survives_damaged_files_under_asan(tmp_path):
     assert r.returncode == 0, out[-2000:]
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-2000:]
     assert "accepted=" in r.stdout and "rejected=" in r.stdout
+    assert "size/type combinations=6912" in r.stdout        # 2 encodings x 12^3 SIZE/TYPE triples x {z, z + rgb}

@@ -119,3 +119,39 @@ def test_pcd_bytes_against_independent_reader(host):
     assert out["pcd"]["asc"] == 1 and len(lines) == 1037
     x, y, z, r, g, b = lines[5].split()
     assert abs(float(x) - recs["binary"]["x"][5]) < 1e-6 and len(x.split(".")[1]) == 6 and int(g) == 5 and int(b) == 35
+
+
+def test_scan_cloud_open_and_save(host):
+    """ScanCloud::open (point_cloud.cpp:78-95): PCD + transformation.txt beside it, registered = non-identity pose;
+    ScanCloud::save: "*.ply" = XYZ in the turntable's canonical frame (point_cloud.cpp:99-113: pivot -> origin,
+    axis -> +z) as ASCII PLY, anything else = binary_compressed PCD with colours / normals."""
+    out, d = host
+    assert out["open"] == [0, 1, 3, 3, 1, 9]          # missing file refused; 3 points, rich records, registered, colour kept
+    file_T = np.array([[float(x) for x in r.split()] for r in open(os.path.join(d, "transformation.txt")).read().strip("\n").split("\n")])
+    assert np.abs(colvec(out["opened_pose"]) - file_T).max() == 0
+    assert out["ply"] == [1, 1, 1, 1, 3, 3, 9]
+    canon = np.array(out["canon"]).reshape(3, 3)
+    assert np.abs(canon[0]).max() < 1e-4                                            # the pivot goes to the origin
+    assert np.abs(canon[1] - [0, 0, 10]).max() < 1e-4                               # 10 mm along the axis -> +z
+    assert abs(np.linalg.norm(canon[2]) - 5.0) < 1e-4                               # a rigid motion
+    head = open(os.path.join(d, "canon.ply")).read().split("end_header")[0].split("\n")
+    assert head[0] == "ply" and head[1] == "format ascii 1.0" and "element vertex 3" in head and "element camera 1" in head
+    assert [l for l in head if l.startswith("property")][:3] == ["property float x", "property float y", "property float z"]
+    # a foreign PLY (double coordinates in z, q, x, y order, an empty face element) and a binary one (refused, cloud untouched)
+    assert out["foreign_ply"] == [1, 2, 4.0, 5.0, 6.0, 0, 1]
+
+
+def test_save_registered_points(host, orc):
+    """Registrator::saveRegisteredPoints (registrator.cpp:344-400): registered views only, in view order; points and
+    normals both go through the full pose (the reference translates its normals too)."""
+    out, d = host
+    assert out["merged"] == [9, 1, 9, 41, 0]           # views 0 (4 pts) + 1 (5 pts); view 2 is not registered
+    # view 0 has the identity pose: untouched
+    assert out["merged_p0"] == [0.0, -3.0, 900.0, 0.0, np.float32(0.6), np.float32(0.8)]
+    T = colvec(out["prior_view1"])
+    p = np.array([10.0, -3.0, 901.0]); n = np.array([0.0, np.float32(0.6), np.float32(0.8)])
+    exp_p, exp_n = T[:3, :3] @ p + T[:3, 3], T[:3, :3] @ n + T[:3, 3]
+    got = np.array(out["merged_p4"])
+    assert np.abs(got[:3] - exp_p).max() < 1e-4 and np.abs(got[3:] - exp_n).max() < 1e-4
+    lines = open(os.path.join(d, "merged", "points.asc")).read().strip().split("\n")
+    assert len(lines) == 9 and lines[4].split()[3:] == ["41", "0", "7"]
