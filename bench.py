@@ -153,8 +153,21 @@ def main():
     ctx = backend.ctx
     ctx.sync()
     h2d = time.time() - h2d0
+    # N > 1: the RCCL communicator belongs to the LIBRARY (mvr_ctx_comm_init = ncclCommInitRank); torch.distributed only
+    # carries rank 0's 128-byte unique id to the other ranks and provides the barrier of the timing contract.  The whole
+    # sharded loop -- posing, searches, ncclAllReduce of the edge table, host solve -- is one native call per rank.
+    torch_allreduce = os.environ.get("MVR_BENCH_TORCH_ALLREDUCE", "0") == "1"      # the round-1 path, kept for comparison
+    rccl_ranks = 1
+    if use_dist and not torch_allreduce:
+        ids = [mvr.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, device=torch.device("cuda", local_rank))
+        ctx.comm_init(ids[0], rank, world)
+        rccl_ranks = ctx.comm_info()[2]
+        if rccl_ranks != world:
+            raise SystemExit("bench.py: RCCL reports %d ranks, expected %d" % (rccl_ranks, world))
     reg = ring.RingLUM(backend, V, [N] * V, args.max_dist, origin, rank=rank, world=world,
-                       all_reduce=(dist.all_reduce if use_dist else None))
+                       all_reduce=(dist.all_reduce if (use_dist and torch_allreduce) else None),
+                       native_comm=(use_dist and not torch_allreduce))
     if rank == 0:
         log("[bench] synth %dx%d in %.2fs; rank0 segments %s" % (V, N, time.time() - t0, reg.segments))
     state = {"poses": [p.copy() for p in poses0]}
@@ -190,10 +203,24 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
+    # the same K-step window again, `--repeats` times (each from the prior, like the headline one): spread of the number
+    rep_s = []
+    for _ in range(max(args.repeats, 0)):
+        reset()
+        barrier()
+        tr = time.perf_counter()
+        run(args.steps)
+        barrier()
+        rep_s.append(time.perf_counter() - tr)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed] + rep_s, dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, rep_s = float(tt[0].item()), [float(v) for v in tt[1:].tolist()]
+    rank_segments = [reg.segments]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, reg.segments)
+        rank_segments = gathered
 
     nn_launches, nn_ms, nn_evals = ctx.prof_get(mvr.K_NN)
     rd_launches, rd_ms, rd_bytes = ctx.prof_get(mvr.K_REDUCE)
@@ -208,6 +235,8 @@ def main():
         "value": V * N * args.steps / elapsed,
         "unit": "correspondences/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ranks": world, "rccl_ranks": rccl_ranks,
+        "rank_query_ranges": [[list(map(int, sg)) for sg in segs] for segs in rank_segments],     # per rank: (edge, first query, count)
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -221,25 +250,42 @@ def main():
         "accepted_correspondences_per_step": reg.last["n_corr"], "mse": reg.last["mse"],
         "device": name, "n_cu": n_cu,
         "step_breakdown_ms": {"enqueue": reg.last["ms_enqueue"], "gpu_drain": reg.last["ms_drain"],
-                              "host_solve": reg.last["ms_host_solve"]},
+                              "host_solve": reg.last["ms_host_solve"],
+                              # nothing is queued on the GPU while the host solves and before the next pass's first
+                              # launch lands: wall time per step minus the time the host spent feeding or awaiting it
+                              "gpu_idle_ms": max(0.0, 1e3 * elapsed / args.steps - reg.last["ms_enqueue"] - reg.last["ms_drain"])},
     }
+    if rep_s:
+        per = sorted(1e3 * t / args.steps for t in rep_s)
+        out["repeats"] = {"n": len(per), "ms_per_step_min": per[0], "ms_per_step_median": per[len(per) // 2], "ms_per_step_max": per[-1],
+                          "value_median": V * N / (per[len(per) // 2] * 1e-3),
+                          "note": "the same K-step window repeated after the headline one (each from the prior); `value` is the first window"}
 
-    def traffic_of(fname):
+    def traffic_of(fname, kernel_source):
+        """HBM-side bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+        tools/measure_traffic.sh -> profiles/<fname>): counters cannot be collected inside this run, so the figure is
+        only reported while the kernel source it was measured on is the one in the tree (sha256), else null."""
+        import hashlib
         tp = os.path.join(ROOT, "profiles", fname)
         try:
-            return json.load(open(tp)).get("hbm_bytes_per_launch")
+            rec = json.load(open(tp))
+            if kernel_source and rec.get("kernel_source_sha256"):
+                now = hashlib.sha256(open(os.path.join(ROOT, g.PKG, "csrc", kernel_source), "rb").read()).hexdigest()
+                if now != rec["kernel_source_sha256"]:
+                    return None, "profiles/%s is stale (measured on another version of %s)" % (fname, kernel_source)
+            return rec.get("hbm_bytes_per_launch"), "profiles/%s (PMC, %s)" % (fname, rec.get("source", "")[:120])
         except Exception:
-            return None
+            return None, "no profiles/%s" % fname
 
     def nn_roofline(kernel, launches, ms, evals, traffic, extra=None):
         if not launches:
             return None
         avg_s = ms * 1e-3 / launches
         achieved = FLOP_PER_EVAL * (evals / launches) / avg_s / 1e12
-        r = {"kernel": kernel, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-             "note": "compute-bound on the FP32 vector ALUs: gfx950's dense FP32 matrix peak equals its FP32 vector "
-                     "peak (157.3 TFLOP/s) and no MFMA is issued (no dense contraction in a 3-D distance); achieved = "
+        r = {"kernel": kernel, "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+             "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic[0], "traffic_source": traffic[1],
+             "note": "priced against the FP32 VECTOR ALUs (157.3 TFLOP/s; gfx950's dense FP32 matrix peak is the same "
+                     "figure, but no MFMA is issued: a 3-D distance has no dense contraction); achieved = "
                      "8 flop x point-pair evaluations EXECUTED per launch / mean launch time from HIP events",
              "launches": launches, "avg_launch_ms": ms / launches, "evals_per_launch": evals / launches,
              "evals_per_s": evals / (ms * 1e-3)}
@@ -279,9 +325,9 @@ def main():
         if bl:
             brute_equiv = bev
             bf = nn_roofline("nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal; one untimed ring pass, one stream)", bl, bms,
-                             bev, traffic_of("nn_traffic.json"))
+                             bev, traffic_of("nn_traffic.json", None))
     kname = "nn_cull_kernel (exact culled 1-NN; one fused launch per direction for all scan pairs of a step)" if culled else "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)"
-    ktraffic = traffic_of("nn_cull_traffic.json" if culled else "nn_traffic.json")
+    ktraffic = traffic_of("nn_cull_traffic.json", "mvr_cull.hip") if culled else traffic_of("nn_traffic.json", None)
     if iso and iso["nn"][0]:
         il, ims, iev = iso["nn"]
         extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; one launch = "
@@ -307,10 +353,42 @@ def main():
             "kernel": "pass1 + moments2 reductions (K5/K8)", "bound": "hbm",
             "achieved": rd_bytes / (rd_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": rd_bytes / (rd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "launches": rd_launches,
-            "avg_launch_ms": rd_ms / rd_launches,
-            "note": "launch-latency bound at 200k points per scan (4 MB per launch); one-stream pass",
+            "avg_launch_ms": rd_ms / rd_launches, "traffic": None,
+            "note": "bytes are MODELLED (the launchers' algorithmic byte counts), not counters; launch-latency bound at "
+                    "200k points per scan (4 MB per launch); one-stream pass",
         }
     out["pcie"] = {"h2d_s": h2d, "h2d_bytes": V * N * 16}
+
+    # BASELINE configs[2] beside the headline: the SEQUENTIAL mode (Registrator::registrationICP, registrator.cpp:526-588:
+    # views 1, V-1, 2, ... each aligned to the growing merged target), device-resident, same scans -- ms per align
+    def sequential_sweep():
+        order = []
+        for i in range(1, V // 2):
+            order += [i, V - i]
+        order.append(V // 2)
+        RAW, TARGET, SOURCE, OUT = V, 2 * V, 2 * V + 1, 2 * V + 2          # the raw scans already sit in slots V .. 2V-1
+        params = mvr.icp_params(max_dist=args.max_dist, max_iter=1000, fma=bool(args.fma))
+        poses, ncorr = [p.copy() for p in poses0], []
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.transform(TARGET, RAW + 0, poses[0]); ctx.reserve(TARGET, V * N)
+        for v in order:
+            ctx.transform(SOURCE, RAW + v, poses[v])
+            T, st, rc = ctx.icp_align(SOURCE, TARGET, OUT, params)
+            poses[v] = mvr.mat4d_mul(T.astype(np.float64), poses[v])
+            ctx.append(TARGET, OUT)
+            ncorr.append(st["n_corr"])
+        ctx.sync()
+        return poses, ncorr, time.perf_counter() - t0, order
+    seq = None
+    if world == 1 and V >= 4:
+        ctx.tune(nn_mode=args.nn_mode, pair_streams=6, pair_groups=2)
+        sequential_sweep()                                              # warm-up: allocations, orderings
+        seq_poses, seq_ncorr, seq_dt, seq_order = sequential_sweep()
+        seq = {"config": "%d-view ring, %d pts/scan, sequential pairwise ICP against the growing target (1 sweep, %d aligns, "
+                         "target grows to %d points)" % (V, N, len(seq_order), V * N),
+               "ms_per_align": 1e3 * seq_dt / len(seq_order), "queries_per_s": N * len(seq_order) / seq_dt, "n_corr": seq_ncorr}
+        out["secondary_sequential"] = seq
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as orc    # checker only: the CPU restatement timed beside the GPU path
@@ -341,6 +419,18 @@ def main():
                 orc.umeyama(clouds[s], clouds[t], c)
                 nq += len(clouds[s])
         dt = time.perf_counter() - t0
+        if seq is not None and V * N <= 3_000_000:
+            # the oracle's restatement of the same sequential sweep: its ms per align, and how far the GPU's final poses are from it
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import ref_driver
+            t0 = time.perf_counter()
+            oposes, olog = ref_driver.sequential_icp(orc, scans, poses0, orc.make_params(max_dist=args.max_dist, max_iter=1000, fma=bool(args.fma)),
+                                                     V, fitness_last=False)
+            dt = time.perf_counter() - t0
+            seq["cpu_oracle_ms_per_align"] = 1e3 * dt / len(olog)
+            seq["pose_delta_vs_oracle"] = {"rot": max(float(np.abs(seq_poses[v][:3, :3] - oposes[v][:3, :3]).max()) for v in range(V)),
+                                           "trans_mm": max(float(np.abs(seq_poses[v][:3, 3] - oposes[v][:3, 3]).max()) for v in range(V)),
+                                           "n_corr_equal": seq_ncorr == [e["n_corr"] for e in olog]}
         out["cpu_baseline_openmp"] = {"value": nq / dt, "unit": "correspondences/s", "cores": threads, "kind": "port",
                                       "sample": "%d ring pairs, kd-trees built serially, per-query searches on %d OpenMP threads, %.1f s"
                                                 % (nq // N, threads, dt)}

@@ -44,7 +44,8 @@ typedef enum {
   MVR_E_NOCORR  = -3,   /* < 3 correspondences (PCL min_number_correspondences_ = 3;
                            "Not enough correspondences found", App. A.1)   */
   MVR_E_NOMEM   = -4,
-  MVR_E_SINGULAR= -5    /* singular system in a host solve (LUM)            */
+  MVR_E_SINGULAR= -5,   /* singular system in a host solve (LUM)            */
+  MVR_E_RCCL    = -6    /* RCCL failure, or librccl not loadable (multi-GPU entry points only) */
 } mvr_status;
 
 #define MVR_MAX_SLOTS 256
@@ -292,6 +293,49 @@ int  mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots
  * d(R p + t)/d pose = M(p') H for R = Rx Ry Rz and the M of LUM::computeEdge; exposed so that its sign pattern can be
  * pinned by a numeric Jacobian without a GPU. */
 void mvr_lum_incidence(const double pose[6], double H[36]);
+/* ---- multi-GPU: the outer passes of registrationLUM (registrator.cpp:625-664) sharded over the GPUs of one node ----
+ * The shardable unit is the scan pair of the loop at registrator.cpp:640-651.  The V * Ns source queries of all pairs
+ * are dealt to the ranks in contiguous equal ranges (mvr_ring_segments; a pair may be split between two ranks, its
+ * sums are additive); every rank holds every scan, no point crosses the fabric.  Per pass each rank runs its share
+ * of the fused searches + sums, then ONE ncclAllReduce(sum) of the [edges][32] f64 table over RCCL/xGMI on the
+ * context's stream, then the (tiny) host solve -- redundantly on every rank from identical bits, so no broadcast.
+ * RCCL is loaded at run time (dlopen: a copy the process already holds, e.g. PyTorch-ROCm's, else the system one,
+ * else $MVR_RCCL_LIB); without it these entry points return MVR_E_RCCL and nothing else is affected.
+ *
+ * (a) one process per GPU (the usual launcher shape): rank 0 calls mvr_comm_unique_id, the 128 bytes travel to the
+ *     other ranks by the launcher's own means, every rank calls mvr_ctx_comm_init on its context, then all ranks
+ *     call mvr_ring_run_sharded with the same arguments.  A context without a communicator is a world of one
+ *     (mvr_ring_run_sharded == mvr_ring_run). */
+#define MVR_UNIQUE_ID_BYTES 128
+int  mvr_comm_unique_id(char id[MVR_UNIQUE_ID_BYTES]);
+int  mvr_ctx_comm_init(mvr_ctx *ctx, const char id[MVR_UNIQUE_ID_BYTES], int rank, int world);   /* ncclCommInitRank: collective */
+int  mvr_ctx_comm_destroy(mvr_ctx *ctx);
+/* rank / world of the context and the rank count RCCL itself reports for its communicator (0: none) */
+int  mvr_ctx_comm_info(mvr_ctx *ctx, int *rank, int *world, int *rccl_ranks);
+const char *mvr_rccl_library(void);      /* what was loaded, or why nothing was */
+/* the partition: edge_queries[e] = source points of edge e; rank's ranges (edge, first query, count), at most ne of them */
+int  mvr_ring_segments(int ne, const size_t *edge_queries, int world, int rank, int *seg_edge, size_t *seg_begin, size_t *seg_count, int *n_seg);
+/* arguments as mvr_ring_run; every rank passes the same poses in and gets the same poses out.  timing_ms = {enqueue,
+ * wait for the GPU incl. the all-reduce, host solve}, summed over the passes.  A rank that fails before a pass's
+ * all-reduce leaves its peers waiting in theirs (RCCL has no peer-failure detection): treat any error as fatal. */
+int  mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                          const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                          int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
+                          int *lum_iters, double *rows, double *timing_ms);
+/* (b) ONE process, all GPUs: n_dev contexts (device_ids NULL: 0 .. n_dev-1) + ncclCommInitAll;
+ *     mvr_world_ring_run drives one host thread per device through mvr_ring_run_sharded and checks that every rank
+ *     arrived at bit-identical poses.  mvr_world_upload puts a cloud into the same slot of every rank. */
+typedef struct mvr_world mvr_world;
+int  mvr_world_create(mvr_world **w, int n_dev, const int *device_ids);
+int  mvr_world_destroy(mvr_world *w);
+int  mvr_world_size(const mvr_world *w);
+mvr_ctx *mvr_world_ctx(mvr_world *w, int rank);
+const char *mvr_world_last_error(const mvr_world *w);
+int  mvr_world_upload(mvr_world *w, int slot, const float *xyz, size_t n, size_t stride_bytes);
+int  mvr_world_ring_run(mvr_world *w, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
+                        const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
+                        double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters, double *rows,
+                        double *timing_ms);
 /* pcl::getTransformation(x,y,z,roll,pitch,yaw) -> column-major 4x4. */
 void mvr_pose_to_mat4(const double pose[6], double T[16]);
 
@@ -325,7 +369,11 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_CO
  * another's searches; also MVR_PAIR_GROUPS),
  * "pair_streams" (worker streams, 1..16; also MVR_PAIR_STREAMS); "posed_refresh" (1, default: in culled mode
  * mvr_cloud_transform_batch also refreshes the index of the posed copies, from the sources' sorted copies;
- * 0: at the first search, by a gather; also MVR_POSED_REFRESH).
+ * 0: at the first search, by a gather; also MVR_POSED_REFRESH); "cull_slices" (1, 2, 4, 8; 0 = auto: a fused
+ * launch deals each pair's query sets to the XCDs in that many interleaved slices, so that a pair's target is read
+ * through that many of the eight L2s instead of all of them; 8 = every XCD visits every pair; also MVR_CULL_SLICES);
+ * "seed_forward" (1, default: when a fused pass searches the very same point sets as the previous one on this context,
+ * every forward search starts from the distance of its previous match; also MVR_SEED_FORWARD).
  * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,

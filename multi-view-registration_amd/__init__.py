@@ -20,6 +20,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvr_hip.so")
+if os.environ.get("MVR_LIB_VARIANT"):      # tuning experiments only (tools/build_variant.sh): build/libmvr_hip_<name>.so
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "build", "libmvr_hip_%s.so" % os.environ["MVR_LIB_VARIANT"])
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -46,13 +48,17 @@ def _share_hip_runtime_with_torch():
         p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
         if os.path.exists(p):
             C.CDLL(p, mode=C.RTLD_GLOBAL)
+            # ... and one RCCL: the copy built for that runtime (loaded only when a multi-GPU entry point is used)
+            r = os.path.join(os.path.dirname(p), "librccl.so")
+            if os.path.exists(r):
+                os.environ.setdefault("MVR_RCCL_LIB", r)
 
 
 _share_hip_runtime_with_torch()
 _lib = C.CDLL(LIB_PATH)
 
 MAX_SLOTS = 256
-OK, E_ARG, E_HIP, E_NOCORR, E_NOMEM, E_SINGULAR = 0, -1, -2, -3, -4, -5
+OK, E_ARG, E_HIP, E_NOCORR, E_NOMEM, E_SINGULAR, E_RCCL = 0, -1, -2, -3, -4, -5, -6
 CONV_STATES = ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
                "NO_CORRESPONDENCES")
 K_NN, K_REDUCE, K_XFORM, K_GLUE = 0, 1, 2, 3
@@ -154,6 +160,25 @@ SIGNATURES = {
     "mvr_ring_run": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
                                C.POINTER(C.c_int), _dp, _dp]),
+    "mvr_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "mvr_ctx_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    "mvr_ctx_comm_destroy": (C.c_int, [_vp]),
+    "mvr_ctx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mvr_rccl_library": (C.c_char_p, []),
+    "mvr_ring_segments": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "mvr_ring_run_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
+                                       C.POINTER(C.c_int), _dp, _dp]),
+    "mvr_world_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)]),
+    "mvr_world_destroy": (C.c_int, [_vp]),
+    "mvr_world_size": (C.c_int, [_vp]),
+    "mvr_world_ctx": (_vp, [_vp, C.c_int]),
+    "mvr_world_last_error": (C.c_char_p, [_vp]),
+    "mvr_world_upload": (C.c_int, [_vp, C.c_int, _fp, _sz, _sz]),
+    "mvr_world_ring_run": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
+                                     C.POINTER(C.c_int), _dp, _dp]),
     "mvr_pose_to_mat4": (None, [_dp, _dp]),
     "mvr_lum_incidence": (None, [_dp, _dp]),
     "mvr_refine_axis": (C.c_int, [C.c_int, _dp, C.c_float, _fp, _fp]),
@@ -498,7 +523,7 @@ class Context:
         _chk(_lib.mvr_cloud_transform_batch(self._h, n, d, s, _p(T, C.c_double)), self._h)
 
     def ring_step(self, posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=16, reciprocal=True, fma=False,
-                  steps=None):
+                  steps=None, _entry=None):
         """mvr_ring_step: one outer pass of registrationLUM in one native call (single process).  edges: [(src view,
         tgt view)]; poses: list of (4,4) float64.  Returns (new poses, info) like ring_host_step, plus info["rows"]
         (ne x 32 edge table) and info["timing_ms"] = (enqueue, GPU wait + copy, host solve).  poses may be a list of
@@ -523,11 +548,33 @@ class Context:
         if steps is None:
             _chk(_lib.mvr_ring_step(self._h, *args), self._h)
         else:                     # mvr_ring_run: `steps` passes in one call; outputs of the last one, timing summed
-            _chk(_lib.mvr_ring_run(self._h, int(steps), *args), self._h)
+            _chk((_entry or _lib.mvr_ring_run)(self._h, int(steps), *args), self._h)
         new = np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1))        # (V,4,4): indexable like the list that came in
         info = dict(pair_T=np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1)), pair_n=pn.tolist(),
                     pair_mse=pm.tolist(), lum_pose=lum, lum_iterations=its.value, rows=rows, timing_ms=tuple(tm.tolist()))
         return new, info
+
+    # ---- multi-GPU (mvr_world.cpp): one process per GPU
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank on this context's device (collective: every rank calls it with rank 0's unique id)."""
+        assert len(unique_id) == 128
+        _chk(_lib.mvr_ctx_comm_init(self._h, unique_id, int(rank), int(world)), self._h)
+
+    def comm_destroy(self):
+        _chk(_lib.mvr_ctx_comm_destroy(self._h), self._h)
+
+    def comm_info(self):
+        """(rank, world, ranks RCCL itself reports for the communicator; 0 = no communicator)"""
+        r, w, n = C.c_int(), C.c_int(), C.c_int()
+        _chk(_lib.mvr_ctx_comm_info(self._h, C.byref(r), C.byref(w), C.byref(n)), self._h)
+        return r.value, w.value, n.value
+
+    def ring_run_sharded(self, posed_slots, raw_slots, edges, poses, max_dist, origin, steps=1, lum_iterations=16, reciprocal=True,
+                         fma=False):
+        """mvr_ring_run_sharded: this rank's share of `steps` outer passes + one RCCL all-reduce of the edge table per
+        pass; same arguments and results as ring_step(steps=...) on every rank."""
+        return self.ring_step(posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=lum_iterations,
+                              reciprocal=reciprocal, fma=fma, steps=steps, _entry=_lib.mvr_ring_run_sharded)
 
     def pair_moments2_batch(self, pairs, max_dist, origin, dev_ptr=None, reciprocal=True, fma=False, ranges=None):
         """All scan pairs of one global iteration in one call: one launch per stage for all pairs (culled
@@ -601,3 +648,90 @@ class Context:
         n, ms, w = C.c_uint64(), C.c_double(), C.c_double()
         _chk(_lib.mvr_prof_get(self._h, family, C.byref(n), C.byref(ms), C.byref(w)), self._h)
         return n.value, ms.value, w.value
+
+
+# ------------------------------------------------------------------ multi-GPU
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId (rank 0); hand the 128 bytes to the other ranks by the launcher's means."""
+    buf = C.create_string_buffer(128)
+    _chk(_lib.mvr_comm_unique_id(buf))
+    return buf.raw
+
+
+def rccl_library() -> str:
+    return _lib.mvr_rccl_library().decode()
+
+
+def ring_segments(edge_queries, world, rank):
+    """the sharding of the ring pass: [(edge, first query, count)] of `rank` (mvr_ring_segments)"""
+    ne = len(edge_queries)
+    q = (C.c_size_t * max(ne, 1))(*[int(v) for v in edge_queries])
+    se, sb, sc, n = (C.c_int * max(ne, 1))(), (C.c_size_t * max(ne, 1))(), (C.c_size_t * max(ne, 1))(), C.c_int()
+    _chk(_lib.mvr_ring_segments(ne, q, int(world), int(rank), se, sb, sc, C.byref(n)))
+    return [(se[k], sb[k], sc[k]) for k in range(n.value)]
+
+
+class _BorrowedContext(Context):
+    """a rank's context of a World: owned by the world, never destroyed from here"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def close(self):
+        self._h = None
+
+
+class World:
+    """One process, n GPUs (mvr_world_create: one context per device + ncclCommInitAll)."""
+
+    def __init__(self, n_dev, device_ids=None):
+        h = _vp()
+        ids = (C.c_int * n_dev)(*device_ids) if device_ids is not None else None
+        rc = _lib.mvr_world_create(C.byref(h), int(n_dev), ids)
+        if rc != OK:
+            raise MvrError(rc, "mvr_world_create(%d): %s" % (n_dev, rccl_library()))
+        self._h, self.n = h, n_dev
+
+    def ctx(self, rank) -> Context:
+        return _BorrowedContext(_vp(_lib.mvr_world_ctx(self._h, int(rank))))
+
+    def upload(self, slot, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        rc = _lib.mvr_world_upload(self._h, int(slot), _p(pts, C.c_float), len(pts), 4 * pts.shape[1])
+        if rc != OK:
+            raise MvrError(rc, _lib.mvr_world_last_error(self._h).decode())
+
+    def ring_run(self, posed_slots, raw_slots, edges, poses, max_dist, origin, steps=1, lum_iterations=16, reciprocal=True, fma=False):
+        V, ne = len(posed_slots), len(edges)
+        ps, rs = (C.c_int * V)(*[int(v) for v in posed_slots]), (C.c_int * V)(*[int(v) for v in raw_slots])
+        es, et = (C.c_int * ne)(*[int(e[0]) for e in edges]), (C.c_int * ne)(*[int(e[1]) for e in edges])
+        P = np.ascontiguousarray(np.asarray(poses, np.float64).transpose(0, 2, 1)).reshape(V, 16)
+        o = np.ascontiguousarray(origin, np.float64)
+        lum, rows, tm = np.zeros((V, 6)), np.empty((ne, 32)), np.zeros(3)
+        pT, pn, pm, its = np.empty((ne, 16), np.float32), np.empty(ne), np.empty(ne), C.c_int()
+        rc = _lib.mvr_world_ring_run(self._h, int(steps), V, ps, rs, ne, es, et, float(max_dist), int(reciprocal), int(fma),
+                                     _p(o, C.c_double), int(lum_iterations), _p(P, C.c_double), _p(lum, C.c_double), _p(pT, C.c_float),
+                                     _p(pn, C.c_double), _p(pm, C.c_double), C.byref(its), _p(rows, C.c_double), _p(tm, C.c_double))
+        if rc != OK:
+            raise MvrError(rc, _lib.mvr_world_last_error(self._h).decode())
+        new = np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1))
+        return new, dict(pair_T=np.ascontiguousarray(pT.reshape(ne, 4, 4).transpose(0, 2, 1)), pair_n=pn.tolist(), pair_mse=pm.tolist(),
+                         lum_pose=lum, lum_iterations=its.value, rows=rows, timing_ms=tuple(tm.tolist()))
+
+    def close(self):
+        if self._h:
+            _lib.mvr_world_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

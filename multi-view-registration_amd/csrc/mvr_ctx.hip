@@ -265,6 +265,7 @@ API const char *mvr_strerror(int s)
     case MVR_E_NOCORR: return "not enough correspondences (< 3)";
     case MVR_E_NOMEM: return "out of memory";
     case MVR_E_SINGULAR: return "singular linear system";
+    case MVR_E_RCCL: return "RCCL error or RCCL library not available";
     default: return "unknown status";
   }
 }
@@ -296,6 +297,8 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_NN_MODE")) c->nn_mode = std::atoi(m);   // 0 brute force, 1 culled (default)
   if (const char *m = std::getenv("MVR_CULL_Q")) c->cull_q = std::atoi(m);     // 64-query groups per set: 1, 2 (0 = auto)
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
+  if (const char *m = std::getenv("MVR_CULL_SLICES")) c->cull_slices = std::atoi(m);   // XCD dealing of a pair's query sets: 1, 2, 4, 8 (0 = auto)
+  if (const char *m = std::getenv("MVR_SEED_FORWARD")) c->seed_forward = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_POSED_REFRESH")) c->posed_refresh = std::atoi(m) != 0;
@@ -333,6 +336,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   Ctx *c = CTX(ctx);
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)mvr_ctx_comm_destroy(ctx);         // (a world's communicators are lent, not owned: just dropped)
   for (Ctx *w : c->workers) {
     w->slots[0] = Cloud(); w->slots[1] = Cloud();      // borrowed views: nothing to free
     (void)mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(w));
@@ -346,7 +350,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   c->orders.clear();
   if (c->order_pool) c->order_pool->close();          // orderings that outlive the context free their buffers themselves
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_table) (void)hipHostFree(c->h_table);
@@ -829,7 +833,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -858,6 +862,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     off_s[k + 1] = off_s[k] + s.n; off_t[k + 1] = off_t[k] + t.n;
     off_p[k + 1] = off_p[k] + (size_t)reduce_blocks_for(c, n) * 29;
   }
+  const nnkey_t *keys_before = w->bkeys;
   if (int rc = ensure(w, w->bkeys, w->bkeys_cap, off_s[n_pairs])) return rc;
   if (int rc = ensure(w, w->brkeys, w->brkeys_cap, off_t[n_pairs])) return rc;
   if (int rc = ensure(w, w->bbound, w->bbound_cap, off_t[n_pairs])) return rc;
@@ -870,11 +875,26 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   uint32_t *counts = w->bchunks + off_c[n_pairs];
   const double max2 = max_dist * max_dist;
   const float cap2 = cap_from_max2(max2);
+  // Do the forward keys left in bkeys[] by the previous fused pass on this context belong to the very same searches
+  // (same point sets in the same order -- a posed copy keeps its scan's set id and ordering --, same query ranges,
+  // same layout)?  Then every forward search starts from the distance of its previous match (seed_from_keys): the
+  // passes of a registration differ by a small motion.  The bound is computed from the CURRENT coordinates, so it is
+  // exact whatever happened to the poses in between; results do not depend on it.
+  std::vector<unsigned long long> sig;
+  sig.push_back((unsigned long long)n_pairs); sig.push_back((unsigned long long)(fma != 0));
+  for (int k = 0; k < n_pairs; ++k) {
+    const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
+    const unsigned long long v[6] = {s.set_id, t.set_id, (unsigned long long)s.n, (unsigned long long)t.n, (unsigned long long)qb[k], (unsigned long long)qn[k]};
+    sig.insert(sig.end(), v, v + 6);
+  }
+  const bool seed = c->seed_forward && (phases & 1) && keys_before == w->bkeys && w->fused_sig == sig;
+  if (phases & 1) w->fused_sig = sig;
   std::vector<CullPair> fwd((size_t)n_pairs), rev((size_t)n_pairs);
   for (int k = 0; k < n_pairs; ++k) {
     const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
     fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, w->bkeys + off_s[k]);
-    fwd[k].key_by_pos = 1;       // forward keys live in the source's Hilbert order from here on (coalesced for every consumer below)
+    fwd[k].key_by_pos = 1;       // forward keys live in sorted space from here on: slot = the query's position, low word = the match's position
+    fwd[k].seed_from_keys = seed ? 1u : 0u;
     if (reciprocal && qn[k]) { fwd[k].clear = w->bbound + off_t[k]; fwd[k].clear_n = (uint32_t)t.n; }    // the forward launch presets the start bounds
     // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
     rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, w->brkeys + off_t[k]);
@@ -1305,6 +1325,8 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "nn_mode")) c->nn_mode = value;
   else if (!std::strcmp(key, "cull_q")) c->cull_q = value;
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
+  else if (!std::strcmp(key, "cull_slices")) c->cull_slices = value;
+  else if (!std::strcmp(key, "seed_forward")) c->seed_forward = value != 0;
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
   else if (!std::strcmp(key, "posed_refresh")) c->posed_refresh = value != 0;
   else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }

@@ -74,28 +74,32 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// lowest original index among points [first, first + count) of the sorted
-// target array at distance exactly `d`; the loads are independent (one L2 round trip)
+// lowest original index among points [first, first + count) of the sorted target array at distance exactly `d`,
+// packed with where it sits: (original index << 32) | sorted position (~0: none); the loads are independent (one L2
+// round trip)
+using winner_t = unsigned long long;
+constexpr winner_t kNoWinner = ~0ull;
 template <bool FMA, int COUNT>
-__device__ __forceinline__ uint32_t span_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t first, float d,
+__device__ __forceinline__ winner_t span_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t first, float d,
                                                 float qx, float qy, float qz)
 {
   float4 p[COUNT];
 #pragma unroll
   for (int k = 0; k < COUNT; ++k) p[k] = ts[min(first + (uint32_t)k, nt - 1u)];
-  uint32_t best = kNone;
+  winner_t best = kNoWinner;
 #pragma unroll
   for (int k = 0; k < COUNT; ++k)
-    if (first + (uint32_t)k < nt && dist2<FMA>(p[k], qx, qy, qz) == d) best = min(best, __float_as_uint(p[k].w));
+    if (first + (uint32_t)k < nt && dist2<FMA>(p[k], qx, qy, qz) == d)
+      best = min(best, ((winner_t)__float_as_uint(p[k].w) << 32) | (winner_t)(first + (uint32_t)k));
   return best;
 }
 
 // the rare tie path: a whole sub-tile, 2 points at a time (keeps the register footprint of the hot path)
 template <bool FMA>
-__device__ __forceinline__ uint32_t sub_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t sub, float d, float qx,
+__device__ __forceinline__ winner_t sub_argmin(const float4 *__restrict__ ts, uint32_t nt, uint32_t sub, float d, float qx,
                                             float qy, float qz)
 {
-  uint32_t best = kNone;
+  winner_t best = kNoWinner;
 #pragma unroll 1
   for (int k = 0; k < kSub; k += 2) best = min(best, span_argmin<FMA, 2>(ts, nt, sub * kSub + (uint32_t)k, d, qx, qy, qz));
   return best;
@@ -118,7 +122,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
                const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
                const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, uint32_t key_by_pos,
-               const uint32_t *__restrict__ qbound, unsigned long long *__restrict__ evals)
+               const uint32_t *__restrict__ qbound, uint32_t seed_from_keys, uint32_t set, unsigned long long *__restrict__ evals)
 {
   constexpr int NQ = 4 * Q;      // queries per lane
   constexpr int NB = 64 * Q;     // queries per block
@@ -146,7 +150,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 #endif
 #ifdef MVR_STAMP
   const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
-  if (evals && blockIdx.x == 0 && threadIdx.x == 0) atomicExch(evals + kEvalRegion + 15, st_rt0);
+  if (evals && set == 0 && threadIdx.x == 0) atomicExch(evals + kEvalRegion + 15, st_rt0);
 #endif
   float4 *T = lds[wv];
   // Queries = sorted positions [q_begin, q_begin + q_count) of the query cloud.  With qflags only the positions
@@ -156,7 +160,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   // qlist[p], p < *qcount (compacted matched targets: the form used when the target is much larger than the set of
   // queries, e.g. the merged target of the sequential mode); key slot = p.
   const uint32_t nq = qlist ? min(*qcount, q_count) : q_count;
-  const uint32_t b_begin = blockIdx.x * NB;
+  const uint32_t b_begin = set * NB;
   if (b_begin >= nq) return;                      // block-uniform
 
   // This wave's own tiles (own tile i <-> tile W i + wv) are looked at in ballot BLOCKS of 64; block k lies
@@ -232,12 +236,24 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   }
   // the per-query bounds start at +inf, or at a distance the caller KNOWS a point within (qbound: the reverse
   // search of a matched target starts from the distance of the source point that matched it -- no blind first cells)
+  // ... or at the distance of the point this very query matched LAST time (seed_from_keys: `keys` still holds the
+  // previous result of the same query set against the same target set, low word = the match's sorted position): both
+  // clouds have moved since, but that point is still a point of the target, so its distance NOW is an exact, inclusive
+  // bound -- the search of an ICP step starts where the previous step ended instead of blind.
   for (int i = threadIdx.x; i < NB; i += 64 * W) {
     uint32_t seed = 0x7F800000u;
+    const uint32_t pos = b_begin + (uint32_t)i, at = pos < nq ? pos : b_begin;
     if (qbound) {
-      const uint32_t pos = b_begin + (uint32_t)i, at = pos < nq ? pos : b_begin;
       const uint32_t v = qbound[qlist ? qlist[at] : (q_begin + at)];
       if (v < seed) seed = v;       // (~0 = no bound)
+    }
+    if (seed_from_keys) {
+      const uint32_t prev = (uint32_t)keys[q_begin + at];
+      if (prev < nt) {
+        const float4 tp = ts[prev], qp = qs[q_begin + at];
+        const uint32_t v = __float_as_uint(dist2<FMA>(tp, qp.x, qp.y, qp.z));
+        if (v < seed) seed = v;
+      }
     }
     sbest[i] = seed;
   }
@@ -245,7 +261,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   MVR_MARK(0);
 
   float U = cap2;                 // wave-uniform: no query of this set needs a point farther than U
-  bool U_stale = qbound != nullptr;       // seeded bounds: U is their maximum, derived when first needed
+  bool U_stale = qbound != nullptr || seed_from_keys != 0;       // seeded bounds: U is their maximum, derived when first needed
   uint32_t cells_done = 0, tiles_tested = 0;
 
   auto shared_bound = [&](int j) {
@@ -306,8 +322,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
         else if (m[q] == best[q] && bsub[q] != kNone && m[q] < 3.0e38f) {
           // exact tie between two sub-tiles (visited in any order): keep the one
           // holding the lowest original index.  Rare; only duplicates / symmetric data.
-          const uint32_t o1 = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
-          const uint32_t o2 = sub_argmin<FMA>(ts, nt, sub, best[q], qx[q], qy[q], qz[q]);
+          const winner_t o1 = sub_argmin<FMA>(ts, nt, bsub[q], best[q], qx[q], qy[q], qz[q]);
+          const winner_t o2 = sub_argmin<FMA>(ts, nt, sub, best[q], qx[q], qy[q], qz[q]);
           if (o2 < o1) bsub[q] = sub;
         }
       }
@@ -571,33 +587,60 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   // The waves share out the 4 Q lane columns (16 queries each): wave wv finishes columns wv, wv + W, ...
   // The queries are re-read before the barrier (their latency hides behind the wait for the slowest wave).
   constexpr int NC = 4 * Q / W;                                 // columns per wave
-  float4 fq[NC];
+  // The finishing lane needs its column's query again.  One wave per set (W == 1): column j of a lane IS its own query
+  // j, still in registers (qx, qy, qz) -- only its original index is fetched, and only by the lanes that store a key
+  // under it.  (Re-reading the queries ahead of the barrier, as the W > 1 path does to hide their latency behind the
+  // wait for the slowest wave, made the compiler park 64 bytes per lane in scratch: 150 MB of spill traffic per fused
+  // launch, measured with the WRITE_SIZE counter.)
+  float fqx[NC], fqy[NC], fqz[NC];
+  uint32_t fqw[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    const uint32_t pos = b_begin + (uint32_t)((wv + j * W) * 16 + l16), rpos = pos < nq ? pos : b_begin;
-    fq[j] = qs[qlist ? qlist[rpos] : (q_begin + rpos)];         // this query's coordinates (and its original index)
+    if (W == 1) { fqx[j] = qx[j]; fqy[j] = qy[j]; fqz[j] = qz[j]; fqw[j] = kNone; }
+    else {
+      const uint32_t pos = b_begin + (uint32_t)((wv + j * W) * 16 + l16), rpos = pos < nq ? pos : b_begin;
+      const float4 f = qs[qlist ? qlist[rpos] : (q_begin + rpos)];         // this query's coordinates (and its original index)
+      fqx[j] = f.x; fqy[j] = f.y; fqz[j] = f.z; fqw[j] = __float_as_uint(f.w);
+    }
   }
-  __syncthreads();
-  nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // [4 W][NB]: (d2 bits, sub-tile)
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    part[(wv * 4 + g) * NB + q * 16 + l16] = ((nnkey_t)__float_as_uint(best[q]) << 32) | bsub[q];
-  __syncthreads();
-  MVR_MARK(6);
+  // W == 1: the four partial results of a query sit in the four lane groups of this one wave, same register, lanes 16
+  // apart: two cross-lane steps combine them -- no LDS round trip, no barrier, nothing parked in scratch meanwhile.
+  // W > 1: the waves meet in LDS (over the tile buffers).
+  nnkey_t *part = reinterpret_cast<nnkey_t *>(&lds[0][0]);      // W > 1 only: [4 W][NB]: (d2 bits, sub-tile)
   nnkey_t pm[NC];
-  bool tie[NC];
+  bool tie[NC];      // another partial reached the same distance in a different sub-tile (rare: duplicates / symmetric data)
+  if constexpr (W == 1) {
 #pragma unroll
-  for (int j = 0; j < NC; ++j) {
-    const int i = (wv + j * W) * 16 + l16;
-    nnkey_t pk[4 * W];
-    pm[j] = kKeyInit;
+    for (int j = 0; j < NC; ++j) {
+      const nnkey_t mine = ((nnkey_t)__float_as_uint(best[j]) << 32) | bsub[j];
+      nnkey_t m = min(mine, (nnkey_t)__shfl_xor(mine, 16, 64));
+      m = min(m, (nnkey_t)__shfl_xor(m, 32, 64));
+      pm[j] = m;
+      int other = (uint32_t)(mine >> 32) == (uint32_t)(m >> 32) && (uint32_t)mine != (uint32_t)m && (uint32_t)mine != kNone;
+      other |= __shfl_xor(other, 16, 64);
+      other |= __shfl_xor(other, 32, 64);
+      tie[j] = other != 0;
+    }
+  } else {
+    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4 * W; ++p) { pk[p] = part[p * NB + i]; pm[j] = min(pm[j], pk[p]); }
-    tie[j] = false;      // another partial reached the same distance in a different sub-tile (rare: duplicates / symmetric data)
+    for (int q = 0; q < NQ; ++q)
+      part[(wv * 4 + g) * NB + q * 16 + l16] = ((nnkey_t)__float_as_uint(best[q]) << 32) | bsub[q];
+    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4 * W; ++p)
-      tie[j] |= (uint32_t)(pk[p] >> 32) == (uint32_t)(pm[j] >> 32) && (uint32_t)pk[p] != (uint32_t)pm[j] && (uint32_t)pk[p] != kNone;
+    for (int j = 0; j < NC; ++j) {
+      const int i = (wv + j * W) * 16 + l16;
+      nnkey_t pk[4 * W];
+      pm[j] = kKeyInit;
+#pragma unroll
+      for (int p = 0; p < 4 * W; ++p) { pk[p] = part[p * NB + i]; pm[j] = min(pm[j], pk[p]); }
+      tie[j] = false;
+#pragma unroll
+      for (int p = 0; p < 4 * W; ++p)
+        tie[j] |= (uint32_t)(pk[p] >> 32) == (uint32_t)(pm[j] >> 32) && (uint32_t)pk[p] != (uint32_t)pm[j] && (uint32_t)pk[p] != kNone;
+    }
   }
+  MVR_MARK(6);
   // the index (lowest original index at distance == best): one re-scan of the winning sub-tile, 8 points
   // per lane group (MVR_CULL_CB columns' loads in flight at a time: 2 needs 64 registers and spills; measured equal)
 #ifndef MVR_CULL_CB
@@ -621,43 +664,54 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
       const uint32_t dbits = (uint32_t)(pm[j] >> 32), sub = (uint32_t)pm[j];
       const float d = __uint_as_float(dbits);
       const bool found = sub != kNone && d <= cap2;
-      uint32_t o = kNone;
+      winner_t ow = kNoWinner;           // (original index << 32) | sorted position: the minimum is the lowest ORIGINAL index
       if (found) {
         const uint32_t first = sub * kSub + g * (kSub / 4);
 #pragma unroll
         for (int k = 0; k < kSub / 4; ++k)
-          if (first + (uint32_t)k < nt && dist2<FMA>(cand[jj][k], fq[j].x, fq[j].y, fq[j].z) == d) o = min(o, __float_as_uint(cand[jj][k].w));
-        if (tie[j]) {
+          if (first + (uint32_t)k < nt && dist2<FMA>(cand[jj][k], fqx[j], fqy[j], fqz[j]) == d)
+            ow = min(ow, ((winner_t)__float_as_uint(cand[jj][k].w) << 32) | (winner_t)(first + (uint32_t)k));
+        if (tie[j]) {          // (wave-uniform for W == 1: every lane group of the column sees the same flag)
 #pragma unroll 1
           for (int p = 0; p < 4 * W; ++p) {
-            const nnkey_t k = part[p * NB + i];
+            nnkey_t k;
+            if constexpr (W == 1) k = (nnkey_t)__shfl(((nnkey_t)__float_as_uint(best[j]) << 32) | bsub[j], p * 16 + l16, 64);
+            else k = part[p * NB + i];
             if ((uint32_t)(k >> 32) == dbits && (uint32_t)k != sub && (uint32_t)k != kNone)
-              o = min(o, span_argmin<FMA, kSub / 4>(ts, nt, (uint32_t)k * kSub + g * (kSub / 4), d, fq[j].x, fq[j].y, fq[j].z));
+              ow = min(ow, span_argmin<FMA, kSub / 4>(ts, nt, (uint32_t)k * kSub + g * (kSub / 4), d, fqx[j], fqy[j], fqz[j]));
           }
         }
       }
-      o = min(o, (uint32_t)__shfl_xor((int)o, 16, 64));
-      o = min(o, (uint32_t)__shfl_xor((int)o, 32, 64));
+      ow = min(ow, (winner_t)__shfl_xor(ow, 16, 64));
+      ow = min(ow, (winner_t)__shfl_xor(ow, 32, 64));
       if (g == 0 && pos < nq && (!qflags || qflags[q_begin + pos] != 0)) {
-        // key slot: sorted / list position, or original index (or, on request, the absolute sorted position)
-        const uint32_t ord = (qflags || qlist) ? pos : (key_by_pos ? q_begin + pos : __float_as_uint(fq[j].w));
-        keys[ord] = (found && o != kNone) ? (((nnkey_t)dbits << 32) | o) : kKeyInit;
+        // key slot: sorted / list position, or original index (or, on request, the absolute sorted position).
+        // Low word: the winner's original index -- or, key_by_pos, its SORTED POSITION: the consumers of the fused
+        // pass (start bounds, reciprocal filter, moments) work in sorted space, so no original-index -> position
+        // gather is left between the stages.
+        uint32_t ord = (qflags || qlist) ? pos : q_begin + pos;
+        if (!(qflags || qlist) && !key_by_pos) ord = (W == 1) ? __float_as_uint(qs[q_begin + pos].w) : fqw[j];
+        const uint32_t low = key_by_pos ? (uint32_t)ow : (uint32_t)(ow >> 32);
+        keys[ord] = (found && ow != kNoWinner) ? (((nnkey_t)dbits << 32) | low) : kKeyInit;
       }
     }
+    // one column's candidates at a time: with the loads of all columns hoisted to the top the kernel no longer fits its
+    // 96 registers and parks 32 bytes per lane in scratch (86 MB written per fused launch for 19 MB of keys)
+    __builtin_amdgcn_sched_barrier(0);
   }
   MVR_MARK(7);
   if (evals && lane == 0) {
     const unsigned long long e = (unsigned long long)cells_done * 64ull * nvalid;
     // sharded counters: one 128-byte line per shard, or thousands of waves serialise on one address
-    unsigned long long *a = evals + (size_t)(blockIdx.x & (kEvalShards - 1)) * kEvalStride;
+    unsigned long long *a = evals + (size_t)(set & (kEvalShards - 1)) * kEvalStride;
     unsigned long long *b = a + kEvalRegion;
     atomicAdd(a, e);              // this launch (profiling)
     atomicAdd(b, e);              // running total (mvr_icp_stats.evals)
     atomicMax(b + 1, (unsigned long long)cells_done);     // diagnostics: heaviest wave (cells evaluated)
     atomicMax(b + 2, (unsigned long long)tiles_tested);
 #ifdef MVR_TRACE
-    if (blockIdx.x < kTraceBlocks) {     // block record: start (first wave), end (last wave), cells (max over waves), XCC id
-      unsigned long long *tr = evals + 2 * kEvalRegion + kTraceRec * (size_t)blockIdx.x;
+    if (set < kTraceBlocks) {     // block record: start (first wave), end (last wave), cells (max over waves), XCC id
+      unsigned long long *tr = evals + 2 * kEvalRegion + kTraceRec * (size_t)set;
       if (wv == 0) {
         tr[0] = tr_rt0;
         for (int k = 0; k < 8; ++k) tr[4 + k] = trm[k];
@@ -684,7 +738,7 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
     // histogram of wave end times (5 us bins since block 0 started): shard k, slot 14 = bin k; shard 0 slot 15 = base
     unsigned long long *h = evals + kEvalRegion;
     const unsigned long long base = atomicAdd(h + 15, 0ull);
-    if (base != 0 && blockIdx.x != 0) {
+    if (base != 0 && set != 0) {
       const unsigned long long bin = min((__builtin_amdgcn_s_memrealtime() - base) / 500ull, (unsigned long long)(kEvalShards - 1));
       atomicAdd(h + bin * kEvalStride + 14, 1ull);
     }
@@ -693,29 +747,57 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
   (void)st_entry; (void)st_stage; (void)st_adv; (void)st_proc; (void)st_reval; (void)st_begin; (void)st_loopend;
 }
 
-// One kernel per (queries per set, waves per set), compiled for 5 waves per SIMD (<= 96 VGPRs).  A single
-// launch runs equally fast with 4, 5 or 6 resident waves (it is bound by its tail), but with the scan
-// pairs of a step overlapping on several streams the chip stays full and residency pays (~3 %).
+// One kernel per (queries per set, waves per set), compiled for 4 waves per SIMD (<= 128 VGPRs; it uses 106).
+// Round 1 ran it at 5 (<= 96 VGPRs) with a few registers parked in scratch -- which looked free in the timings and was
+// not in the counters: every wave writes its 24-72 spilled bytes per lane out and reads them back, 60-190 MB of
+// WRITE_SIZE per fused launch for 29 MB of keys and bounds.  At 4 waves nothing spills, the launch moves 151 MB
+// instead of 276-448 (tools/measure_traffic.sh) and the ring step takes the same time (0.883 vs 0.884 ms).
 #ifndef MVR_CULL_WAVES
-#define MVR_CULL_WAVES 5
+#define MVR_CULL_WAVES 4
 #endif
 #ifdef MVR_CULL_WAVES_MAX          // experiments: cap the residency as well
 #define MVR_CULL_WAVES_ATTR MVR_CULL_WAVES, MVR_CULL_WAVES_MAX
 #else
 #define MVR_CULL_WAVES_ATTR MVR_CULL_WAVES
 #endif
-// blockIdx.y = scan pair: the searches of all pairs of a global iteration are ONE launch (the arguments of
-// up to kBatchPairs pairs travel by value), so the chip is filled by the union of their query sets and the
-// tail of one pair's search is covered by the others.
+// ONE launch runs the searches of all scan pairs of a global iteration (the arguments of up to kBatchPairs pairs travel
+// by value): the chip is filled by the union of their query sets and the tail of one pair's search is covered by the
+// others.  Block -> (pair, query set), XCD-aware: blocks b and b + 8 share an XCD (MI355X deals workgroups round-robin
+// over its 8 XCDs; which XCD block 0 gets is not fixed and nothing here depends on it -- speed only), and every XCD has
+// its own 4 MB L2.  With a plain (set, pair) grid every XCD walks through EVERY pair's target: 8 copies of each target
+// (3.6 MB with its boxes) cross the fabric per launch -- 448 MB measured for 12 pairs against ~100 MB of distinct
+// bytes.  Here a pair is cut into `slices` interleaved slices of its query sets (set mod slices; slices = 8 / gcd(pairs,
+// 8), so that pairs * slices fills the 8 XCDs evenly) and slice u of the launch goes to the blocks with b mod 8 ==
+// u mod 8, one slice after the other: an XCD works on one target at a time and a target is read by `slices` XCDs
+// instead of 8.  Interleaved slices keep the XCDs balanced: heavy query sets are neighbours in the Hilbert order.
+struct XcdMap { uint32_t sets[kBatchPairs]; uint32_t n_pairs, slices; };
+__host__ __device__ inline uint32_t slice_len(uint32_t sets, uint32_t slices, uint32_t slice)
+{
+  return sets > slice ? (sets - slice + slices - 1u) / slices : 0u;
+}
+__host__ __device__ inline bool xcd_map_block(const XcdMap &m, uint32_t block, uint32_t *pair, uint32_t *set)
+{
+  uint32_t r = block >> 3;
+  for (uint32_t u = block & 7u; u < m.n_pairs * m.slices; u += 8u) {
+    const uint32_t p = u / m.slices, sl = u % m.slices, len = slice_len(m.sets[p], m.slices, sl);
+    if (r < len) { *pair = p; *set = sl + r * m.slices; return true; }
+    r -= len;
+  }
+  return false;
+}
+
 template <bool FMA, int Q, int W>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? MVR_CULL_WAVES : 3)))
-nn_cull_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
+nn_cull_kernel(CullBatch batch, XcdMap map, unsigned long long *__restrict__ evals)
 {
-  const CullPair &a = batch.p[blockIdx.y];
-  if (a.clear)        // every block of the pair's row (also those past its last query set) clears its stride of the array
-    for (uint32_t i = blockIdx.x * (64u * W) + threadIdx.x; i < a.clear_n; i += gridDim.x * (64u * W)) a.clear[i] = 0xFFFFFFFFu;
+  uint32_t pair = 0, set = 0;
+  if (!xcd_map_block(map, blockIdx.x, &pair, &set)) return;          // block-uniform
+  pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair); set = (uint32_t)__builtin_amdgcn_readfirstlane((int)set);
+  const CullPair &a = batch.p[pair];
+  if (a.clear)        // the blocks of the pair share out the array (each clears its stride)
+    for (uint32_t i = set * (64u * W) + threadIdx.x; i < a.clear_n; i += map.sets[pair] * (64u * W)) a.clear[i] = 0xFFFFFFFFu;
   nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
-                          a.keys, a.key_by_pos, a.qbound, evals);
+                          a.keys, a.key_by_pos, a.qbound, a.seed_from_keys, set, evals);
 }
 
 }  // namespace
@@ -738,14 +820,29 @@ int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2,
     // sets win until there are far more sets than the chip holds at once
     int Q = (qmax <= (size_t)c->n_cu * 8 * 4 * 64) ? 1 : 2;
     if (c->cull_q == 1 || c->cull_q == 2) Q = c->cull_q;      // tuning override
-    const dim3 grid((unsigned)((qmax + 64 * Q - 1) / (64 * Q)), (unsigned)m);   // one block (W cooperating waves) per query set
     // waves sharing one query set: a lone search is bound by its longest chain of cells, two waves per set halve
     // it; a fused batch keeps the chip full whatever the chains are, and one wave per set then does the same work
     // with fewer, better filled passes (measured on the 12-pair ring: 1.52 ms/step with W = 1, 1.73 with 2, 2.27 with 4)
+    XcdMap map;
     size_t sets = 0;
-    for (int k = 0; k < m; ++k) sets += ((size_t)batch.p[k].q_count + 64 * Q - 1) / (64 * Q);
+    for (int k = 0; k < kBatchPairs; ++k) {
+      map.sets[k] = k < m ? (uint32_t)(((size_t)batch.p[k].q_count + 64 * Q - 1) / (64 * Q)) : 0u;
+      sets += map.sets[k];
+    }
     int W = sets >= (size_t)c->n_cu * 40 ? 1 : 2;
     if (c->cull_w == 1 || c->cull_w == 2 || c->cull_w == 4) W = c->cull_w;      // tuning override
+    map.n_pairs = (uint32_t)m;
+    uint32_t g = 8u, pm = (uint32_t)m;
+    while (pm % g) g >>= 1;                                    // gcd(pairs, 8)
+    map.slices = 8u / g;
+    if (c->cull_slices == 1 || c->cull_slices == 2 || c->cull_slices == 4 || c->cull_slices == 8) map.slices = (uint32_t)c->cull_slices;   // tuning override (8: no locality, every XCD visits every pair)
+    uint32_t per_xcd = 0;                                      // the longest of the 8 block lists
+    for (uint32_t v = 0; v < 8u; ++v) {
+      uint32_t tot = 0;
+      for (uint32_t u = v; u < map.n_pairs * map.slices; u += 8u) tot += slice_len(map.sets[u / map.slices], map.slices, u % map.slices);
+      per_xcd = std::max(per_xcd, tot);
+    }
+    const dim3 grid(8u * per_xcd);            // one block (W cooperating waves) per query set, dealt as xcd_map_block says
     // region A (evaluations) is only read back by the profiler: per launch at level 1 (cleared here, copied out
     // after the launch), as a running total at level 2 (cleared when profiling starts, read once at the end)
     const bool per_launch = c->prof && !c->prof_totals;
@@ -755,7 +852,7 @@ int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2,
 #endif
     ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0,
                  per_launch ? upper : 0.0, per_launch ? kEvalShards : 0);
-#define MVR_LAUNCH_CULL(F, QQ, WW) hipLaunchKernelGGL((nn_cull_kernel<F, QQ, WW>), grid, dim3(64 * WW), 0, c->stream, batch, c->evals)
+#define MVR_LAUNCH_CULL(F, QQ, WW) hipLaunchKernelGGL((nn_cull_kernel<F, QQ, WW>), grid, dim3(64 * WW), 0, c->stream, batch, map, c->evals)
 #define MVR_LAUNCH_CULL_W(F, QQ)                                                                  \
   do { if (W == 1) MVR_LAUNCH_CULL(F, QQ, 1); else if (W == 2) MVR_LAUNCH_CULL(F, QQ, 2); else MVR_LAUNCH_CULL(F, QQ, 4); } while (0)
     if (fma) { if (Q == 2) MVR_LAUNCH_CULL_W(true, 2); else MVR_LAUNCH_CULL_W(true, 1); }

@@ -288,13 +288,15 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
   if (j == kNone) return;
   const float d2 = __uint_as_float((uint32_t)(key >> 32));
   if ((double)d2 > b.max2) return;
+  // (by_pos: the forward keys carry the match's sorted position -- no original-index -> position gather here)
+  const uint32_t tpos = a.by_pos ? j : a.tinv[j];
   // the reverse search of that target may start from this distance: the point that matched it is that close
   if (a.bound) {
     // ANY matching source's distance is a valid start bound, so the writers are not ordered: a relaxed store, last
     // one wins (an atomic min per match cost 40 us per ring step and pruned 0.3 % more).  Which one wins only moves
     // the amount of pruning from run to run, never a result.
-    __atomic_store_n(&a.bound[a.tinv[j]], (uint32_t)(key >> 32), __ATOMIC_RELAXED);
-  } else a.flags[a.tinv[j]] = 1;
+    __atomic_store_n(&a.bound[tpos], (uint32_t)(key >> 32), __ATOMIC_RELAXED);
+  } else a.flags[tpos] = 1;
 }
 
 // ---- ordered compaction of the flags of ALL pairs of a batch (blockIdx.y = pair): count per 256-position chunk,

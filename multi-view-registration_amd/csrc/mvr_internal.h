@@ -131,6 +131,9 @@ struct Ctx {
   int nn_mode = 1;                                    // 0: brute force, 1: culled (exact, identical results)
   int cull_q = 0;                                     // culled kernel: queries per lane (0 = auto)
   int cull_w = 0;                                     // culled kernel: waves sharing one query set (1, 2, 4; 0 = by launch size)
+  int cull_slices = 0;                                // culled kernel: interleaved slices a pair's query sets are dealt to the XCDs in (1, 2, 4, 8; 0 = 8 / gcd(pairs, 8))
+  int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
+  std::vector<unsigned long long> fused_sig;          // what the forward keys in bkeys[] belong to (point-set ids, ranges, offsets): the previous fused pass on this context
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
   // workers: contexts with their own stream and work buffers that BORROW clouds of this
   // context (slots 0/1) so that independent scan pairs run concurrently on the GPU
@@ -152,6 +155,9 @@ struct Ctx {
   int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
   int posed_refresh = 1;                              // mvr_cloud_transform_batch brings the posed copies' index up to date from the sources' sorted copies
   int pair_groups = 2;                                // fused pass: groups of pairs on concurrent streams (1: a single stream); measured on the 12-pair ring: 1.27 / 1.22 / 1.28 / 1.39 ms per step with 1 / 2 / 3 / 4
+  // multi-GPU (mvr_world.cpp): an RCCL communicator (ncclComm_t; null = this context is a world of its own)
+  void *comm = nullptr; bool comm_owned = false; int comm_rank = 0, comm_world = 1;
+  double *dist_table = nullptr; size_t dist_table_cap = 0;   // [edges][32]: this rank's rows, all-reduced in place
   // instrumentation
   bool prof = false;
   unsigned prof_mask = ~0u;                           // families that are timed (bit f = family f)
@@ -261,7 +267,8 @@ struct CullPair {
   uint32_t q_begin = 0, q_count = 0, nt = 0, n_tiles = 0;
   const uint32_t *qbound = nullptr;   // optional, by sorted position: bits of a distance (squared) within which the query is KNOWN to have a point -- the search starts from that bound instead of the cap
   uint32_t *clear = nullptr; uint32_t clear_n = 0;   // optional: [clear_n] words this launch sets to ~0 on the side (the pair's start-bound array, before the flag stage: saves a memset launch in the chain of small kernels)
-  uint32_t key_by_pos = 0;       // plain queries only: key slot = sorted position (coalesced stores) instead of the original index
+  uint32_t key_by_pos = 0;       // plain queries only: key slot = the query's sorted position (coalesced stores) instead of its original index, AND the key's low word = the match's sorted position instead of its original index
+  uint32_t seed_from_keys = 0;   // with key_by_pos: keys[] still holds the previous result of the same queries against the same target point set; every search starts from the distance of its previous match
 };
 struct CullBatch { CullPair p[kBatchPairs]; float cap2; };
 CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys);

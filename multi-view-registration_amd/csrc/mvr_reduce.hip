@@ -355,9 +355,9 @@ moments2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, 
 // moments2_kernel (same acceptance, same accumulation order, so the same bits), without the centroid
 // reduction, its final kernel and the match[] round trip that only the two-pass covariance needs.
 // BYPOS (the fused global pass): the forward keys are stored by SORTED position and the points are read from
-// the Hilbert-ordered copies (src = sorted source, tgt = sorted target, w = original index), so only the
-// original-index -> position lookup of the match is a random gather; neighbouring queries have neighbouring
-// matches.  Same points, same acceptance, same order of additions as the walk over the original arrays.
+// the Hilbert-ordered copies (src = sorted source, tgt = sorted target, w = original index); the key's low word is
+// the match's sorted position (the search kernel reports it), so no index lookup is left: neighbouring queries read
+// neighbouring matches.  Same points, same acceptance, same order of additions as the walk over the original arrays.
 template <bool BYPOS>
 __device__ __forceinline__ void accept_moments2_body(const float4 *__restrict__ src, const float4 *__restrict__ tgt,
                                                      const nnkey_t *__restrict__ keys, const nnkey_t *__restrict__ rkeys,
@@ -401,9 +401,9 @@ __device__ __forceinline__ void accept_moments2_body(const float4 *__restrict__ 
       ok[u] = ok[u] && (j[u] != kNone) && !((double)d2[u] > max2);
       if (BYPOS) i[u] = (size_t)__float_as_uint(p4[u].w);
     }
-    if (BYPOS) {
+    if (BYPOS) {            // the fused pass's forward keys carry the match's sorted position itself
 #pragma unroll
-      for (int u = 0; u < kUn; ++u) { tpos[u] = 0; if (ok[u]) tpos[u] = tinv[j[u]]; }
+      for (int u = 0; u < kUn; ++u) tpos[u] = ok[u] ? j[u] : 0u;
     } else {
 #pragma unroll
       for (int u = 0; u < kUn; ++u) tpos[u] = j[u];

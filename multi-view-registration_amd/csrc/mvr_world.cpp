@@ -1,0 +1,346 @@
+// csrc/mvr_world.cpp -- the multi-GPU host of the global (ring / LUM) registration, behind the C-ABI, no torch:
+//
+//   * mvr_ring_run_sharded : ONE RANK's part of the outer passes of Registrator::registrationLUM
+//     (mvr/src/registrator.cpp:625-664).  The V * Ns source queries of all ring pairs (:640-651, the independent,
+//     shardable unit) are dealt to the ranks in contiguous equal ranges (a pair may be split between two ranks: the
+//     sums are additive); every rank holds every scan, so no point ever crosses the fabric.  Per pass: pose the scans
+//     this rank's ranges touch, run its share of the fused searches + sums into a device table [edges][32] f64,
+//     ONE ncclAllReduce(sum) of that table over RCCL/xGMI on the context's stream (3 KB at 12 views: latency-bound),
+//     copy it to the host, and solve (per-pair Umeyama, Lu-Milios, pose update) -- redundantly on every rank, the
+//     all-reduced bits being identical everywhere, so no broadcast is needed.
+//   * one process per GPU (the bench contract): mvr_comm_unique_id on rank 0, the 128 bytes travel by whatever
+//     launcher there is (torch.distributed's store, MPI, a file), mvr_ctx_comm_init = ncclCommInitRank.
+//   * one process, all GPUs: mvr_world_create = one context per device + ncclCommInitAll;
+//     mvr_world_ring_run runs mvr_ring_run_sharded on one host thread per device.
+//
+// RCCL is bound at run time (dlopen): libmvr_hip.so itself does not link it, so the single-GPU path neither loads nor
+// needs it, and a process that already holds an RCCL (PyTorch-ROCm bundles one, built for the HIP runtime it also
+// bundles) shares that copy instead of getting a second one.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "mvr_internal.h"
+
+namespace mvr {
+namespace {
+
+struct Rccl {
+  void *lib = nullptr;
+  std::string path, error;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl &rccl()
+{
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<std::pair<std::string, int> > tries;
+    if (const char *p = std::getenv("MVR_RCCL_LIB")) tries.push_back({p, RTLD_NOW | RTLD_GLOBAL});
+    for (const char *n : {"librccl.so", "librccl.so.1"}) tries.push_back({n, RTLD_NOW | RTLD_NOLOAD});      // a copy the process holds already
+    for (const char *n : {"librccl.so.1", "librccl.so"}) tries.push_back({n, RTLD_NOW | RTLD_GLOBAL});
+    for (auto &t : tries) {
+      r.lib = dlopen(t.first.c_str(), t.second);
+      if (r.lib) { r.path = t.first; break; }
+    }
+    if (!r.lib) { r.error = std::string("RCCL not found (librccl.so): ") + (dlerror() ? dlerror() : ""); return; }
+#define MVR_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
+    MVR_SYM(GetUniqueId, "ncclGetUniqueId"); MVR_SYM(CommInitRank, "ncclCommInitRank"); MVR_SYM(CommInitAll, "ncclCommInitAll");
+    MVR_SYM(CommDestroy, "ncclCommDestroy"); MVR_SYM(CommCount, "ncclCommCount"); MVR_SYM(AllReduce, "ncclAllReduce");
+    MVR_SYM(GetErrorString, "ncclGetErrorString");
+#undef MVR_SYM
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+      r.error = "RCCL library lacks an expected symbol: " + r.path;
+      r.lib = nullptr;
+    }
+  });
+  return r;
+}
+
+int rccl_fail(Ctx *c, const char *what, ncclResult_t e)
+{
+  std::string msg = what;
+  if (rccl().GetErrorString) { msg += ": "; msg += rccl().GetErrorString(e); }
+  return set_error(c, MVR_E_RCCL, msg.c_str());
+}
+
+struct Segment { int edge; size_t q_begin, q_count; };
+
+// the rank's share of the concatenated source queries of all edges: [total rank / world, total (rank + 1) / world)
+std::vector<Segment> split_queries(const std::vector<size_t> &sizes, int world, int rank)
+{
+  unsigned long long total = 0;
+  for (size_t n : sizes) total += n;
+  const unsigned long long lo = total * (unsigned long long)rank / (unsigned long long)world;
+  const unsigned long long hi = total * (unsigned long long)(rank + 1) / (unsigned long long)world;
+  std::vector<Segment> out;
+  unsigned long long base = 0;
+  for (size_t e = 0; e < sizes.size(); ++e) {
+    const unsigned long long a = std::max(lo, base), b = std::min(hi, base + sizes[e]);
+    if (b > a) out.push_back(Segment{(int)e, (size_t)(a - base), (size_t)(b - a)});
+    base += sizes[e];
+  }
+  return out;
+}
+
+}  // namespace
+}  // namespace mvr
+
+using namespace mvr;
+
+#define API __attribute__((visibility("default")))
+#define CTX(p) reinterpret_cast<Ctx *>(p)
+
+struct mvr_world {
+  std::vector<mvr_ctx *> ctx;
+  std::vector<ncclComm_t> comm;        // ncclCommInitAll's communicators (owned here, lent to the contexts)
+  std::string last_error;
+};
+
+extern "C" {
+
+API int mvr_comm_unique_id(char id[MVR_UNIQUE_ID_BYTES])
+{
+  static_assert(MVR_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  if (!id) return MVR_E_ARG;
+  Rccl &r = rccl();
+  if (!r.lib) return MVR_E_RCCL;
+  ncclUniqueId u;
+  if (r.GetUniqueId(&u) != ncclSuccess) return MVR_E_RCCL;
+  std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return MVR_OK;
+}
+
+API const char *mvr_rccl_library(void)
+{
+  Rccl &r = rccl();
+  return r.lib ? r.path.c_str() : r.error.c_str();
+}
+
+API int mvr_ctx_comm_init(mvr_ctx *ctx, const char id[MVR_UNIQUE_ID_BYTES], int rank, int world)
+{
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (c->comm) return set_error(c, MVR_E_ARG, "this context already has a communicator");
+  Rccl &r = rccl();
+  if (!r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t e = r.CommInitRank(&comm, world, u, rank);
+  if (e != ncclSuccess) return rccl_fail(c, "ncclCommInitRank", e);
+  c->comm = comm; c->comm_owned = true; c->comm_rank = rank; c->comm_world = world;
+  return MVR_OK;
+}
+
+API int mvr_ctx_comm_destroy(mvr_ctx *ctx)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (c->comm && c->comm_owned && rccl().lib) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)rccl().CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
+  }
+  c->comm = nullptr; c->comm_owned = false; c->comm_rank = 0; c->comm_world = 1;
+  return MVR_OK;
+}
+
+API int mvr_ctx_comm_info(mvr_ctx *ctx, int *rank, int *world, int *rccl_ranks)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (rank) *rank = c->comm_rank;
+  if (world) *world = c->comm_world;
+  if (rccl_ranks) {
+    *rccl_ranks = 0;          // what RCCL itself says (0: no communicator)
+    if (c->comm && rccl().CommCount) (void)rccl().CommCount(reinterpret_cast<ncclComm_t>(c->comm), rccl_ranks);
+  }
+  return MVR_OK;
+}
+
+API int mvr_ring_segments(int ne, const size_t *edge_queries, int world, int rank, int *seg_edge, size_t *seg_begin, size_t *seg_count, int *n_seg)
+{
+  if (ne < 0 || (ne && !edge_queries) || world < 1 || rank < 0 || rank >= world || !n_seg) return MVR_E_ARG;
+  const std::vector<Segment> s = split_queries(std::vector<size_t>(edge_queries, edge_queries + ne), world, rank);
+  *n_seg = (int)s.size();
+  for (size_t k = 0; k < s.size(); ++k) {
+    if (seg_edge) seg_edge[k] = s[k].edge;
+    if (seg_begin) seg_begin[k] = s[k].q_begin;
+    if (seg_count) seg_count[k] = s[k].q_count;
+  }
+  return MVR_OK;
+}
+
+API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                             const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                             int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
+                             int *lum_iters, double *rows, double *timing_ms)
+{
+  if (!ctx || n_steps < 0 || n_views < 2 || ne < 0 || !posed_slots || !raw_slots || (ne && (!edge_src || !edge_tgt)) || !origin || !poses || !lum_pose)
+    return MVR_E_ARG;
+  for (int e = 0; e < ne; ++e) if (edge_src[e] < 0 || edge_src[e] >= n_views || edge_tgt[e] < 0 || edge_tgt[e] >= n_views) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  Rccl &r = rccl();
+  if (c->comm && !r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
+  // this rank's query ranges (edge e's queries are the points of its SOURCE scan) and the views they touch
+  std::vector<size_t> sizes((size_t)ne);
+  for (int e = 0; e < ne; ++e) {
+    size_t n = 0;
+    if (int rc = mvr_cloud_size(ctx, raw_slots[edge_src[e]], &n)) return rc;
+    sizes[(size_t)e] = n;
+  }
+  const std::vector<Segment> segs = split_queries(sizes, world, rank);
+  std::vector<int> ss, ts, vdst, vsrc, vview;
+  std::vector<size_t> qb, qn;
+  std::vector<char> need((size_t)n_views, 0);
+  for (const Segment &s : segs) {
+    ss.push_back(posed_slots[edge_src[s.edge]]); ts.push_back(posed_slots[edge_tgt[s.edge]]);
+    qb.push_back(s.q_begin); qn.push_back(s.q_count);
+    need[(size_t)edge_src[s.edge]] = need[(size_t)edge_tgt[s.edge]] = 1;
+  }
+  for (int v = 0; v < n_views; ++v) if (need[(size_t)v]) { vdst.push_back(posed_slots[v]); vsrc.push_back(raw_slots[v]); vview.push_back(v); }
+  const size_t table_n = (size_t)std::max(ne, 1) * 32;
+  if (int rc = ensure(c, c->dist_table, c->dist_table_cap, table_n)) return rc;
+  if (c->h_table_cap < table_n) {
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_table) (void)hipHostFree(c->h_table);
+    c->h_table = nullptr; c->h_table_cap = 0;
+    MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), std::max(table_n, (size_t)512) * sizeof(double), hipHostMallocMapped));
+    c->h_table_cap = std::max(table_n, (size_t)512);
+  }
+  using clk = std::chrono::steady_clock;
+  double sum[3] = {0.0, 0.0, 0.0};
+  std::vector<double> T((size_t)vdst.size() * 16), pn((size_t)ne), pm((size_t)ne);
+  for (int step = 0; step < n_steps; ++step) {
+    const auto t0 = clk::now();
+    for (size_t k = 0; k < vview.size(); ++k) std::memcpy(&T[k * 16], poses + 16 * (size_t)vview[k], 16 * sizeof(double));
+    if (!vdst.empty()) { if (int rc = mvr_cloud_transform_batch(ctx, (int)vdst.size(), vdst.data(), vsrc.data(), T.data())) return rc; }
+    MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table, 0, (size_t)ne * 32 * sizeof(double), c->stream));       // rows of other ranks' edges: zero
+    if (!segs.empty()) {
+      // a rank's ranges cover consecutive edges: rows e0 .. of the table, one batched call (one launch per stage)
+      if (int rc = mvr_pair_moments2_batch(ctx, (int)segs.size(), ss.data(), ts.data(), max_dist, reciprocal, fma, qb.data(), qn.data(), origin,
+                                           nullptr, c->dist_table + (size_t)segs[0].edge * 32)) return rc;
+    }
+    if (c->comm && ne) {
+      const ncclResult_t e = r.AllReduce(c->dist_table, c->dist_table, (size_t)ne * 32, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(c->comm), c->stream);
+      if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
+    }
+    if (ne) MVR_HIP_TRY(c, hipMemcpyAsync(c->h_table, c->dist_table, (size_t)ne * 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const auto t1 = clk::now();
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const auto t2 = clk::now();
+    if (rows && ne) std::memcpy(rows, c->h_table, (size_t)ne * 32 * sizeof(double));
+    const int rc = mvr_ring_host_step(n_views, ne, edge_src, edge_tgt, c->h_table, origin, lum_iterations, poses, lum_pose, pair_T,
+                                      pair_n ? pair_n : pn.data(), pair_mse ? pair_mse : pm.data(), lum_iters);
+    const auto t3 = clk::now();
+    sum[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    sum[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+    sum[2] += std::chrono::duration<double, std::milli>(t3 - t2).count();
+    if (rc != MVR_OK) return set_error(c, rc, "LUM solve");
+  }
+  if (timing_ms) for (int j = 0; j < 3; ++j) timing_ms[j] = sum[j];
+  return MVR_OK;
+}
+
+// ------------------------------------------------------------------ one process, all GPUs
+
+API int mvr_world_create(mvr_world **out, int n_dev, const int *device_ids)
+{
+  if (!out || n_dev < 1) return MVR_E_ARG;
+  *out = nullptr;
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return MVR_E_HIP;
+  std::vector<int> devs((size_t)n_dev);
+  for (int k = 0; k < n_dev; ++k) {
+    devs[(size_t)k] = device_ids ? device_ids[k] : k;
+    if (devs[(size_t)k] < 0 || devs[(size_t)k] >= have) return MVR_E_ARG;
+    for (int j = 0; j < k; ++j) if (devs[(size_t)j] == devs[(size_t)k]) return MVR_E_ARG;      // one rank per GPU
+  }
+  Rccl &r = rccl();
+  if (!r.lib) return MVR_E_RCCL;
+  mvr_world *w = new (std::nothrow) mvr_world();
+  if (!w) return MVR_E_NOMEM;
+  w->ctx.assign((size_t)n_dev, nullptr);
+  for (int k = 0; k < n_dev; ++k)
+    if (int rc = mvr_ctx_create(&w->ctx[(size_t)k], devs[(size_t)k])) { mvr_world_destroy(w); return rc; }
+  w->comm.assign((size_t)n_dev, nullptr);
+  if (r.CommInitAll(w->comm.data(), n_dev, devs.data()) != ncclSuccess) { w->comm.clear(); mvr_world_destroy(w); return MVR_E_RCCL; }
+  for (int k = 0; k < n_dev; ++k) {
+    Ctx *c = CTX(w->ctx[(size_t)k]);
+    c->comm = w->comm[(size_t)k]; c->comm_owned = false; c->comm_rank = k; c->comm_world = n_dev;
+  }
+  *out = w;
+  return MVR_OK;
+}
+
+API int mvr_world_destroy(mvr_world *w)
+{
+  if (!w) return MVR_E_ARG;
+  for (mvr_ctx *c : w->ctx) if (c) { (void)mvr_ctx_sync(c); CTX(c)->comm = nullptr; }
+  for (ncclComm_t cm : w->comm) if (cm && rccl().lib) (void)rccl().CommDestroy(cm);
+  for (mvr_ctx *c : w->ctx) if (c) (void)mvr_ctx_destroy(c);
+  delete w;
+  return MVR_OK;
+}
+
+API int mvr_world_size(const mvr_world *w) { return w ? (int)w->ctx.size() : 0; }
+API mvr_ctx *mvr_world_ctx(mvr_world *w, int rank) { return (w && rank >= 0 && rank < (int)w->ctx.size()) ? w->ctx[(size_t)rank] : nullptr; }
+API const char *mvr_world_last_error(const mvr_world *w) { return w ? w->last_error.c_str() : ""; }
+
+// every rank holds every scan: raw scan v goes to slot raw_slots[v] of every context
+API int mvr_world_upload(mvr_world *w, int slot, const float *xyz, size_t n, size_t stride_bytes)
+{
+  if (!w) return MVR_E_ARG;
+  for (mvr_ctx *c : w->ctx)
+    if (int rc = mvr_cloud_upload(c, slot, xyz, n, stride_bytes)) { w->last_error = mvr_last_error(c); return rc; }
+  return MVR_OK;
+}
+
+API int mvr_world_ring_run(mvr_world *w, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
+                           const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
+                           double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters, double *rows,
+                           double *timing_ms)
+{
+  if (!w || w->ctx.empty() || n_views < 2 || !poses || !lum_pose) return MVR_E_ARG;
+  const size_t G = w->ctx.size();
+  // one host thread per device; rank 0 writes the caller's outputs, the others their own copies of the (identical) poses
+  std::vector<int> status(G, MVR_OK);
+  std::vector<std::vector<double> > P(G, std::vector<double>(poses, poses + (size_t)n_views * 16)), L(G, std::vector<double>((size_t)n_views * 6));
+  auto body = [&](size_t g) {
+    const bool lead = g == 0;
+    status[g] = mvr_ring_run_sharded(w->ctx[g], n_steps, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin,
+                                     lum_iterations, lead ? poses : P[g].data(), lead ? lum_pose : L[g].data(), lead ? pair_T : nullptr,
+                                     lead ? pair_n : nullptr, lead ? pair_mse : nullptr, lead ? lum_iters : nullptr, lead ? rows : nullptr,
+                                     lead ? timing_ms : nullptr);
+  };
+  std::vector<std::thread> th;
+  for (size_t g = 1; g < G; ++g) th.emplace_back(body, g);
+  body(0);
+  for (std::thread &t : th) t.join();
+  for (size_t g = 0; g < G; ++g)
+    if (status[g] != MVR_OK) { w->last_error = "rank " + std::to_string(g) + ": " + mvr_last_error(w->ctx[g]); return status[g]; }
+  for (size_t g = 1; g < G; ++g)      // the ranks solved the same table: bit-identical poses, or something is badly wrong
+    if (std::memcmp(P[g].data(), poses, (size_t)n_views * 16 * sizeof(double)) != 0) { w->last_error = "ranks disagree on the poses"; return MVR_E_RCCL; }
+  return MVR_OK;
+}
+
+}  // extern "C"

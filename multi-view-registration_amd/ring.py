@@ -104,19 +104,28 @@ class HipBackend:
         return self.ctx.ring_step(list(range(self.V)), [self.V + v for v in range(self.V)], edges, poses, max_dist, origin,
                                   lum_iterations=lum_iterations, reciprocal=True, fma=self.fma, steps=steps)
 
+    def sharded_run(self, edges, poses, max_dist, origin, lum_iterations, steps):
+        """this rank's share of `steps` passes with the all-reduce done natively (RCCL on the context's stream,
+        mvr_ring_run_sharded): needs ctx.comm_init() on every rank first"""
+        return self.ctx.ring_run_sharded(list(range(self.V)), [self.V + v for v in range(self.V)], edges, poses, max_dist, origin,
+                                         steps=steps, lum_iterations=lum_iterations, reciprocal=True, fma=self.fma)
+
     def close(self):
         self.ctx.close()
 
 
 class RingLUM:
     def __init__(self, backend, n_views, sizes, max_dist, origin, rank=0, world=1, all_reduce=None,
-                 lum_iterations=16, fused=True):
+                 lum_iterations=16, fused=True, native_comm=False):
         self.b, self.V = backend, n_views
         self.edges = ring_edges(n_views)
         self.max_dist, self.origin = float(max_dist), np.asarray(origin, np.float64)
         self.rank, self.world, self.all_reduce = rank, world, all_reduce
-        if world > 1 and all_reduce is None:
-            raise ValueError("world > 1 needs an all_reduce callable")
+        # native_comm: the backend's context carries an RCCL communicator (Context.comm_init) and the whole sharded loop,
+        # all-reduce included, is native (mvr_ring_run_sharded); otherwise the all-reduce is a callable (torch.distributed)
+        self.native_comm = bool(native_comm)
+        if world > 1 and all_reduce is None and not self.native_comm:
+            raise ValueError("world > 1 needs an all_reduce callable or native_comm=True")
         self.lum_iterations = lum_iterations
         self.fused = fused            # world == 1: use the backend's one-call step when it has one
         # edge e's queries are the points of its SOURCE view
@@ -134,6 +143,10 @@ class RingLUM:
         (mvr_ring_run); otherwise step by step.  self.last describes the last pass, its ms_* fields are per-pass means."""
         if steps <= 0:
             return poses
+        if self.native_comm:
+            new, info = self.b.sharded_run(self.edges, poses, self.max_dist, self.origin, self.lum_iterations, steps)
+            self._set_last(info, steps)
+            return new
         if not self._native():
             acc = [0.0, 0.0, 0.0]
             for _ in range(steps):
@@ -157,6 +170,8 @@ class RingLUM:
         """poses: list of V (4,4) float64 column-vector poses -> new list."""
         import time
         b = self.b
+        if self.native_comm:
+            return self.run(poses, 1)
         if self._native():
             # single process: posing, searches, reductions, copy of the table and the host solve in ONE native call
             new, info = b.fused_step(self.edges, poses, self.max_dist, self.origin, self.lum_iterations)

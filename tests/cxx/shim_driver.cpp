@@ -6,11 +6,15 @@
 // usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
 //   mode: seq | lum | auto | err | api          the reference's loops on the PCL-named shim (reference_replay.hpp)
 //         seqdev | lumdev | errdev | register      the product's device-resident drivers (mvr/registrator.hpp)
+//         world                                    the single-process multi-GPU host (mvr_world_*), here with one GPU
 //         denoise
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
+
+#include <unistd.h>
 
 #define MVR_ALIAS_PCL
 #include "reference_replay.hpp"
@@ -93,6 +97,40 @@ int main(int argc, char **argv)
       std::printf("\"merged\":%zu,\"reloaded\":%zu,\"ok\":%d,\"sizes\":[", n, back.size(), (int)ok);
       for (int v = 0; v < V; ++v) std::printf("%zu%s", model.views[v].size(), v + 1 < V ? "," : "");
       std::printf("],");
+    } else if (mode == "world") {
+      // the native multi-GPU host, one process: mvr_world_create(1) (ncclCommInitAll against the SYSTEM RCCL: no torch in
+      // this process) + mvr_world_ring_run == registrationLUMDevice on a plain context
+      mvr_world *w = nullptr;
+      std::fflush(stdout);                       // RCCL prints a version banner on fd 1: keep it out of the JSON
+      const int saved_stdout = dup(1);
+      dup2(2, 1);
+      const int rc = mvr_world_create(&w, 1, nullptr);
+      if (rc != MVR_OK) { std::fprintf(stderr, "mvr_world_create: %s (%s)\n", mvr_strerror(rc), mvr_rccl_library()); return 1; }
+      std::vector<int> raw_s((size_t)V), posed_s((size_t)V), es((size_t)V), et((size_t)V);
+      std::vector<double> poses((size_t)V * 16), lum((size_t)V * 6), pn((size_t)V), pm((size_t)V);
+      for (int v = 0; v < V; ++v) {
+        ScanCloud &pc = model.views[v];
+        pc.initRotation(reg);
+        raw_s[v] = V + v; posed_s[v] = v; es[v] = v; et[v] = (v + 1) % V;
+        if (mvr_world_upload(w, V + v, pc.points.points[0].data, pc.size(), 16) != MVR_OK) return 1;
+        std::memcpy(&poses[(size_t)v * 16], pc.getMatrix().asColumnMajorColumnVector(), 16 * sizeof(double));
+      }
+      const PCLPoint &p0 = model.views[0].points.points[0];
+      const double origin[3] = {p0.x, p0.y, p0.z};
+      int iters = 0;
+      const int rr = mvr_world_ring_run(w, repeat, V, posed_s.data(), raw_s.data(), V, es.data(), et.data(), max_d, 1, 0, origin, 16, poses.data(),
+                                        lum.data(), nullptr, pn.data(), pm.data(), &iters, nullptr, nullptr);
+      if (rr != MVR_OK) { std::fprintf(stderr, "mvr_world_ring_run: %s (%s)\n", mvr_strerror(rr), mvr_world_last_error(w)); return 1; }
+      int rank = -1, world = -1, rccl = -1;
+      mvr_ctx_comm_info(mvr_world_ctx(w, 0), &rank, &world, &rccl);
+      std::fflush(stdout);
+      dup2(saved_stdout, 1);
+      close(saved_stdout);
+      std::printf("\"rccl\":\"%s\",\"comm\":[%d,%d,%d],\"lum_ncorr\":[", mvr_rccl_library(), rank, world, rccl);
+      for (int e = 0; e < V; ++e) std::printf("%d%s", (int)pn[e], e + 1 < V ? "," : "");
+      std::printf("],");
+      for (int v = 0; v < V; ++v) { RowMatrixd m; std::memcpy(&m(0, 0), &poses[(size_t)v * 16], 16 * sizeof(double)); model.views[v].setMatrix(m); }
+      mvr_world_destroy(w);
     } else if (mode == "lumdev") {
       reg.registrationLUMDevice(16 * repeat, max_d, 0);
       std::printf("\"lum_ncorr\":[");

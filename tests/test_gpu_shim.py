@@ -40,8 +40,10 @@ def nn_mode_env(request):
 
 
 def run(exe, mode, V, N, max_d, repeat, config, *extra):
+    env = dict(os.environ)
+    env.pop("MVR_RCCL_LIB", None)        # (the Python package points it at torch's copy; a C++ process uses the system's)
     r = subprocess.run([exe, mode, str(V), str(N), str(max_d), str(repeat), str(config)] + [str(e) for e in extra], stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ))
+                       stderr=subprocess.PIPE, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr
     return json.loads(r.stdout), r.stderr
 
@@ -225,3 +227,14 @@ def test_registration_writes_the_merged_cloud(driver, mvr, orc, tmp_path):
         assert np.all(rgb == ((v << 16) | ((2 * v) << 8) | (255 - v)))
         off += len(exp)
     assert len(open(os.path.join(tmp_path, "points.asc")).read().strip().split("\n")) == out["merged"]
+
+
+def test_world_host_from_cxx_without_torch(driver, mvr, orc):
+    """mvr_world_create / mvr_world_ring_run from a plain C++ process (system HIP + system RCCL, no torch anywhere):
+    a world of one reproduces registrationLUMDevice exactly, and RCCL really carried the table (1 rank reported)."""
+    V, N, max_d = 12, 3000, 8.0
+    out, _ = run(driver, "world", V, N, max_d, 2, 3)
+    ref, _ = run(driver, "lumdev", V, N, max_d, 2, 3)
+    assert out["comm"] == [0, 1, 1] and "rccl" in out["rccl"]
+    assert out["lum_ncorr"] == ref["lum_ncorr"]
+    assert out["poses"] == ref["poses"]                      # printed with %.17g: bit-identical

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""tools/traffic_json.py <dir with FETCH_SIZE/ and WRITE_SIZE/ rocprofv3 --pmc outputs of tools/step_probe.py>
+-> the JSON kept as profiles/nn_cull_traffic.json: per-launch HBM-side bytes of the fused culled search (forward and
+reverse launches of the timed steps, warm-up dispatches dropped), with the gfx950 correction of the guide (FETCH_SIZE
+counts 128-byte requests as 64: doubled; WRITE_SIZE as is), the algorithmic bytes next to it and the hash of the
+kernel source measured."""
+import csv, glob, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = sys.argv[1]
+V, N, STEPS, WARM = 12, 200000, 10, 2
+
+
+def per_dispatch(counter):
+    rows = {}
+    for f in glob.glob(os.path.join(d, counter, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "nn_cull" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                rows[int(r["Dispatch_Id"])] = rows.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    vals = [rows[k] for k in sorted(rows)]
+    return vals[2 * max(WARM, 1):]            # forward + reverse per step; the warm-up steps come first
+
+
+fetch, write = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
+assert len(fetch) == 2 * STEPS and len(write) == 2 * STEPS, (len(fetch), len(write))
+kb = lambda v: sum(v) / len(v)
+ff, fr, wf, wr = kb(fetch[0::2]), kb(fetch[1::2]), kb(write[0::2]), kb(write[1::2])
+fwd, rev = 2 * ff * 1024 + wf * 1024, 2 * fr * 1024 + wr * 1024
+probe = json.loads([l for l in open(os.path.join(d, "FETCH_SIZE.log")) if l.startswith("{")][-1])
+m = probe["n_corr"] / V                      # accepted pairs per scan pair ~ distinct matched targets
+# distinct bytes a launch has to touch, 16-byte points: forward = queries + target (points, 1/64 cell boxes of 32 B, ...) +
+# keys written + start bounds preset; reverse = matched targets (gathered 16 B) + source cloud + bounds + keys
+alg_fwd = V * (16 * N + 16 * N * (1 + 2 / 64.0) + 8 * N + 4 * N)
+alg_rev = V * (16 * m + 4 * m + 4 * m + 16 * N * (1 + 2 / 64.0) + 8 * m)
+src = os.path.join(ROOT, "multi-view-registration_amd", "csrc", "mvr_cull.hip")
+out = {
+    "kernel": "nn_cull_kernel<false,1,1> (exact culled NN, fused launch over the %d scan pairs of a ring step)" % V,
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/step_probe.py %d %d %d %d, MVR_PAIR_GROUPS=1 "
+              "(tools/measure_traffic.sh); mean over the %d timed steps" % (V, N, STEPS, WARM, STEPS),
+    "fetch_size_kb_forward": ff, "fetch_size_kb_reverse": fr, "write_size_kb_forward": wf, "write_size_kb_reverse": wr,
+    "correction": "gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled; WRITE_SIZE as is",
+    "hbm_bytes_forward": fwd, "hbm_bytes_reverse": rev, "hbm_bytes_per_launch": 0.5 * (fwd + rev),
+    "algorithmic_bytes_forward": alg_fwd, "algorithmic_bytes_reverse": alg_rev, "algorithmic_bytes_per_launch": 0.5 * (alg_fwd + alg_rev),
+    "ratio_to_algorithmic": 0.5 * (fwd + rev) / (0.5 * (alg_fwd + alg_rev)),
+    "kernel_source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(),
+    "probe": probe,
+}
+print(json.dumps(out, indent=1))
