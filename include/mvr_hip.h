@@ -322,6 +322,12 @@ int  mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *pos
                           const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                           int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
                           int *lum_iters, double *rows, double *timing_ms);
+/* one rank's half of ONE pass, for launchers that reduce the table themselves (MPI, a test): pose what `rank` of `world`
+ * needs and return ITS rows of the edge table (zero rows for edges it does not touch; rows of a split edge are partial
+ * sums) on the host.  The sum over the ranks' tables, fed to mvr_ring_host_step, is the pass. */
+int  mvr_ring_rows_sharded(mvr_ctx *ctx, int rank, int world, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                           const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                           const double *poses, double *rows);
 /* (b) ONE process, all GPUs: n_dev contexts (device_ids NULL: 0 .. n_dev-1) + ncclCommInitAll;
  *     mvr_world_ring_run drives one host thread per device through mvr_ring_run_sharded and checks that every rank
  *     arrived at bit-identical poses.  mvr_world_upload puts a cloud into the same slot of every rank. */

@@ -170,6 +170,8 @@ SIGNATURES = {
     "mvr_ring_run_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                        C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
                                        C.POINTER(C.c_int), _dp, _dp]),
+    "mvr_ring_rows_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mvr_world_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)]),
     "mvr_world_destroy": (C.c_int, [_vp]),
     "mvr_world_size": (C.c_int, [_vp]),
@@ -575,6 +577,17 @@ class Context:
         pass; same arguments and results as ring_step(steps=...) on every rank."""
         return self.ring_step(posed_slots, raw_slots, edges, poses, max_dist, origin, lum_iterations=lum_iterations,
                               reciprocal=reciprocal, fma=fma, steps=steps, _entry=_lib.mvr_ring_run_sharded)
+
+    def ring_rows_sharded(self, rank, world, posed_slots, raw_slots, edges, poses, max_dist, origin, reciprocal=True, fma=False):
+        """mvr_ring_rows_sharded: the rows of the edge table that `rank` of `world` contributes to one pass (host, (ne, 32))"""
+        V, ne = len(posed_slots), len(edges)
+        ps, rs = (C.c_int * V)(*[int(v) for v in posed_slots]), (C.c_int * V)(*[int(v) for v in raw_slots])
+        es, et = (C.c_int * ne)(*[int(e[0]) for e in edges]), (C.c_int * ne)(*[int(e[1]) for e in edges])
+        P = np.ascontiguousarray(np.asarray(poses, np.float64).transpose(0, 2, 1)).reshape(V, 16)
+        o, rows = np.ascontiguousarray(origin, np.float64), np.zeros((ne, 32))
+        _chk(_lib.mvr_ring_rows_sharded(self._h, int(rank), int(world), V, ps, rs, ne, es, et, float(max_dist), int(reciprocal), int(fma),
+                                        _p(o, C.c_double), _p(P, C.c_double), _p(rows, C.c_double)), self._h)
+        return rows
 
     def pair_moments2_batch(self, pairs, max_dist, origin, dev_ptr=None, reciprocal=True, fma=False, ranges=None):
         """All scan pairs of one global iteration in one call: one launch per stage for all pairs (culled

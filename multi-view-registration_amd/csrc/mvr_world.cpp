@@ -188,36 +188,52 @@ API int mvr_ring_segments(int ne, const size_t *edge_queries, int world, int ran
   return MVR_OK;
 }
 
-API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
-                             const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
-                             int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
-                             int *lum_iters, double *rows, double *timing_ms)
+namespace {
+// what one rank does in every pass: which scans to pose, which (pair, query range) to search
+struct RankPlan {
+  std::vector<Segment> segs;
+  std::vector<int> ss, ts, vdst, vsrc, vview;
+  std::vector<size_t> qb, qn;
+};
+
+int make_rank_plan(mvr_ctx *ctx, int rank, int world, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
+                   const int *edge_tgt, RankPlan *p)
 {
-  if (!ctx || n_steps < 0 || n_views < 2 || ne < 0 || !posed_slots || !raw_slots || (ne && (!edge_src || !edge_tgt)) || !origin || !poses || !lum_pose)
-    return MVR_E_ARG;
-  for (int e = 0; e < ne; ++e) if (edge_src[e] < 0 || edge_src[e] >= n_views || edge_tgt[e] < 0 || edge_tgt[e] >= n_views) return MVR_E_ARG;
-  Ctx *c = CTX(ctx);
-  MVR_HIP_TRY(c, hipSetDevice(c->device));
-  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
-  Rccl &r = rccl();
-  if (c->comm && !r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
-  // this rank's query ranges (edge e's queries are the points of its SOURCE scan) and the views they touch
   std::vector<size_t> sizes((size_t)ne);
-  for (int e = 0; e < ne; ++e) {
+  for (int e = 0; e < ne; ++e) {             // edge e's queries are the points of its SOURCE scan
     size_t n = 0;
     if (int rc = mvr_cloud_size(ctx, raw_slots[edge_src[e]], &n)) return rc;
     sizes[(size_t)e] = n;
   }
-  const std::vector<Segment> segs = split_queries(sizes, world, rank);
-  std::vector<int> ss, ts, vdst, vsrc, vview;
-  std::vector<size_t> qb, qn;
+  p->segs = split_queries(sizes, world, rank);
   std::vector<char> need((size_t)n_views, 0);
-  for (const Segment &s : segs) {
-    ss.push_back(posed_slots[edge_src[s.edge]]); ts.push_back(posed_slots[edge_tgt[s.edge]]);
-    qb.push_back(s.q_begin); qn.push_back(s.q_count);
+  for (const Segment &s : p->segs) {
+    p->ss.push_back(posed_slots[edge_src[s.edge]]); p->ts.push_back(posed_slots[edge_tgt[s.edge]]);
+    p->qb.push_back(s.q_begin); p->qn.push_back(s.q_count);
     need[(size_t)edge_src[s.edge]] = need[(size_t)edge_tgt[s.edge]] = 1;
   }
-  for (int v = 0; v < n_views; ++v) if (need[(size_t)v]) { vdst.push_back(posed_slots[v]); vsrc.push_back(raw_slots[v]); vview.push_back(v); }
+  for (int v = 0; v < n_views; ++v) if (need[(size_t)v]) { p->vdst.push_back(posed_slots[v]); p->vsrc.push_back(raw_slots[v]); p->vview.push_back(v); }
+  return MVR_OK;
+}
+
+// pose the rank's scans and put its rows of the edge table (zero elsewhere) into c->dist_table, asynchronously
+int enqueue_rank_rows(mvr_ctx *ctx, const RankPlan &p, int ne, double max_dist, int reciprocal, int fma, const double origin[3], const double *poses)
+{
+  Ctx *c = CTX(ctx);
+  std::vector<double> T(p.vdst.size() * 16);
+  for (size_t k = 0; k < p.vview.size(); ++k) std::memcpy(&T[k * 16], poses + 16 * (size_t)p.vview[k], 16 * sizeof(double));
+  if (!p.vdst.empty()) { if (int rc = mvr_cloud_transform_batch(ctx, (int)p.vdst.size(), p.vdst.data(), p.vsrc.data(), T.data())) return rc; }
+  MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table, 0, (size_t)std::max(ne, 1) * 32 * sizeof(double), c->stream));       // rows of other ranks' edges: zero
+  if (!p.segs.empty()) {
+    // a rank's ranges cover consecutive edges: rows e0 .. of the table, one batched call (one launch per stage)
+    if (int rc = mvr_pair_moments2_batch(ctx, (int)p.segs.size(), p.ss.data(), p.ts.data(), max_dist, reciprocal, fma, p.qb.data(), p.qn.data(), origin,
+                                         nullptr, c->dist_table + (size_t)p.segs[0].edge * 32)) return rc;
+  }
+  return MVR_OK;
+}
+
+int ensure_tables(Ctx *c, int ne)
+{
   const size_t table_n = (size_t)std::max(ne, 1) * 32;
   if (int rc = ensure(c, c->dist_table, c->dist_table_cap, table_n)) return rc;
   if (c->h_table_cap < table_n) {
@@ -227,19 +243,56 @@ API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *
     MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), std::max(table_n, (size_t)512) * sizeof(double), hipHostMallocMapped));
     c->h_table_cap = std::max(table_n, (size_t)512);
   }
+  return MVR_OK;
+}
+
+bool ring_args_ok(int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src, const int *edge_tgt)
+{
+  if (n_views < 2 || ne < 0 || !posed_slots || !raw_slots || (ne && (!edge_src || !edge_tgt))) return false;
+  for (int e = 0; e < ne; ++e) if (edge_src[e] < 0 || edge_src[e] >= n_views || edge_tgt[e] < 0 || edge_tgt[e] >= n_views) return false;
+  return true;
+}
+}  // namespace
+
+API int mvr_ring_rows_sharded(mvr_ctx *ctx, int rank, int world, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                              const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                              const double *poses, double *rows)
+{
+  if (!ctx || world < 1 || rank < 0 || rank >= world || !ring_args_ok(n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt) || !origin || !poses || !rows)
+    return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  RankPlan plan;
+  if (int rc = make_rank_plan(ctx, rank, world, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, &plan)) return rc;
+  if (int rc = ensure_tables(c, ne)) return rc;
+  if (int rc = enqueue_rank_rows(ctx, plan, ne, max_dist, reciprocal, fma, origin, poses)) return rc;
+  if (ne) MVR_HIP_TRY(c, hipMemcpyAsync(c->h_table, c->dist_table, (size_t)ne * 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (ne) std::memcpy(rows, c->h_table, (size_t)ne * 32 * sizeof(double));
+  return MVR_OK;
+}
+
+API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
+                             const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
+                             int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
+                             int *lum_iters, double *rows, double *timing_ms)
+{
+  if (!ctx || n_steps < 0 || !ring_args_ok(n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt) || !origin || !poses || !lum_pose)
+    return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  Rccl &r = rccl();
+  if (c->comm && !r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
+  RankPlan plan;
+  if (int rc = make_rank_plan(ctx, rank, world, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, &plan)) return rc;
+  if (int rc = ensure_tables(c, ne)) return rc;
   using clk = std::chrono::steady_clock;
   double sum[3] = {0.0, 0.0, 0.0};
-  std::vector<double> T((size_t)vdst.size() * 16), pn((size_t)ne), pm((size_t)ne);
+  std::vector<double> pn((size_t)ne), pm((size_t)ne);
   for (int step = 0; step < n_steps; ++step) {
     const auto t0 = clk::now();
-    for (size_t k = 0; k < vview.size(); ++k) std::memcpy(&T[k * 16], poses + 16 * (size_t)vview[k], 16 * sizeof(double));
-    if (!vdst.empty()) { if (int rc = mvr_cloud_transform_batch(ctx, (int)vdst.size(), vdst.data(), vsrc.data(), T.data())) return rc; }
-    MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table, 0, (size_t)ne * 32 * sizeof(double), c->stream));       // rows of other ranks' edges: zero
-    if (!segs.empty()) {
-      // a rank's ranges cover consecutive edges: rows e0 .. of the table, one batched call (one launch per stage)
-      if (int rc = mvr_pair_moments2_batch(ctx, (int)segs.size(), ss.data(), ts.data(), max_dist, reciprocal, fma, qb.data(), qn.data(), origin,
-                                           nullptr, c->dist_table + (size_t)segs[0].edge * 32)) return rc;
-    }
+    if (int rc = enqueue_rank_rows(ctx, plan, ne, max_dist, reciprocal, fma, origin, poses)) return rc;
     if (c->comm && ne) {
       const ncclResult_t e = r.AllReduce(c->dist_table, c->dist_table, (size_t)ne * 32, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(c->comm), c->stream);
       if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);

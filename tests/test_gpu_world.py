@@ -89,3 +89,30 @@ def test_ring_lum_native_comm_wrapper(mvr, scene):
         assert np.array_equal(np.asarray(new), ref) and r.last["n_corr"] == sum(rinfo["pair_n"])
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_rows_of_all_ranks_sum_to_the_pass(mvr, scene, world):
+    """What N ranks would all-reduce, computed rank by rank on the one GPU here (mvr_ring_rows_sharded -- the very code
+    mvr_ring_run_sharded runs before its ncclAllReduce): the tables add up to the unsharded pass (counts exactly, sums
+    to rounding), only the rows of a rank's own edges are non-zero, and the host step fed with the sum lands on the
+    poses of the single-context step."""
+    scans, poses0, origin = scene
+    V = len(scans)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    posed, raw = list(range(V)), [V + v for v in range(V)]
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v])
+        ref, rinfo = ctx.ring_step(posed, raw, edges, poses0, 8.0, origin)
+        total = np.zeros((V, 32))
+        for rank in range(world):
+            rows = ctx.ring_rows_sharded(rank, world, posed, raw, edges, poses0, 8.0, origin)
+            mine = {e for e, _, _ in mvr.ring_segments([len(scans[s]) for s, _ in edges], world, rank)}
+            assert all((rows[e, 0] > 0) == (e in mine) or rows[e, 0] == 0 for e in range(V))
+            assert all(np.all(rows[e] == 0) for e in range(V) if e not in mine)
+            total += rows
+        assert np.array_equal(total[:, 0], rinfo["rows"][:, 0])
+        assert np.allclose(total[:, 4:], rinfo["rows"][:, 4:], rtol=1e-12, atol=1e-7)
+        rc, new, info = mvr.ring_host_step(V, edges, total, origin, poses0)
+        assert rc == 0 and np.abs(np.asarray(new) - ref).max() < 1e-9
