@@ -176,6 +176,32 @@ int solve6(const double A[36], const double b[6], double x[6])
   return MVR_OK;
 }
 
+// x = A^-1 b for a SYMMETRIC POSITIVE DEFINITE 6 x 6 (the normal matrix MM of LUM::computeEdge): Cholesky without
+// pivot search -- a third of the dependent divisions and none of the row swaps of solve6, which the LUM loop
+// called 12 times per iteration (0.2 of its 0.5 us per edge).  Falls back to solve6 when a pivot is not safely
+// positive (degenerate correspondences: the caller's NaN / singular handling stays as it was).
+int solve6_spd(const double A[36], const double b[6], double x[6])
+{
+  double L[6][6], y[6];
+  double amax = 0.0;
+  for (int k = 0; k < 6; ++k) amax = std::max(amax, std::fabs(A[7 * k]));
+  for (int j = 0; j < 6; ++j) {
+    double d = A[7 * j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    if (!(d > 1e-13 * amax)) return solve6(A, b, x);
+    const double ljj = std::sqrt(d), inv = 1.0 / ljj;
+    L[j][j] = ljj;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[6 * i + j];
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
+  }
+  for (int i = 0; i < 6; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
+  for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k]; x[i] = v / L[i][i]; }
+  return MVR_OK;
+}
+
 // Extension (K10): pcl::registration::TransformationEstimationPointToPlaneLLS --
 // x = (A^T A)^-1 A^T b with x = (alpha, beta, gamma, tx, ty, tz), then
 // constructTransformationMatrix: R = Rz(gamma) Ry(beta) Rx(alpha), t.
@@ -413,7 +439,7 @@ static int lum_edge_from_moments_T(const mvr_pair_moments2_t *m2, const double T
   MZ[4] = Sxd(0, 1) - Sxd(1, 0);   // sum (x dy - y dx)
   MZ[5] = Sxd(2, 0) - Sxd(0, 2);   // sum (z dx - x dz)
   double D[6] = {0, 0, 0, 0, 0, 0};
-  if (solve6(MM, MZ, D) != MVR_OK) { *ss = NAN; return MVR_OK; }      // D = MM^-1 MZ
+  if (solve6_spd(MM, MZ, D) != MVR_OK) { *ss = NAN; return MVR_OK; }      // D = MM^-1 MZ
   // residual e = diff - Dt - C av, C = [[0,-D4,D5],[D4,0,-D3],[-D5,D3,0]]; in
   // the shifted frame e = diff - (Dt + C o) - C av'
   M3 Cm = zero3();
@@ -460,6 +486,25 @@ static void lum_incidence(const double pose[6], double out[36])
 }
 
 API void mvr_lum_incidence(const double pose[6], double H[36]) { lum_incidence(pose, H); }
+
+// x = H(pose)^-1 b without forming H: rows 3..5 of H only couple the three rotational unknowns
+//   x3 + sy x5 = b3,   sx x4 + cx cy x5 = b4,   cx x4 - sx cy x5 = b5      (determinant of the 2 x 2: -cy)
+// and rows 0..2 are the identity plus the top-right block times those three.  (Eleven general 6 x 6 eliminations
+// per LUM iteration were a fifth of its time.)  false: cos(pitch) = 0, H is singular.
+static bool solve_incidence(const double pose[6], const double b[6], double x[6])
+{
+  const double cx = std::cos(pose[3]), sx = std::sin(pose[3]), cy = std::cos(pose[4]), sy = std::sin(pose[4]);
+  if (std::fabs(cy) < 1e-300) return false;
+  // [sx, cx cy; cx, -sx cy] (x4, x5)^T = (b4, b5)^T
+  const double det = -sx * sx * cy - cx * cx * cy;      // = -cy
+  x[4] = (-sx * cy * b[4] - cx * cy * b[5]) / det;
+  x[5] = (sx * b[5] - cx * b[4]) / det;
+  x[3] = b[3] - sy * x[5];
+  x[0] = b[0] - ((pose[1] * sx - pose[2] * cx) * x[4] + (pose[1] * cx * cy + pose[2] * sx * cy) * x[5]);
+  x[1] = b[1] - (pose[2] * x[3] + (-pose[0] * sx) * x[4] + (-pose[0] * cx * cy + pose[2] * sy) * x[5]);
+  x[2] = b[2] - ((-pose[1]) * x[3] + (pose[0] * cx) * x[4] + (-pose[0] * sx * cy - pose[1] * sy) * x[5]);
+  return true;
+}
 
 // LUM::compute (App. A.6) on per-edge moments.
 API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_pair_moments2_t *m2,
@@ -518,9 +563,8 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     if (solve_spd(dim, G.data(), B.data(), row_end.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
     double sum = 0.0;
     for (int vi = 1; vi < n; ++vi) {
-      double inc[36], sol[6], dp[6], nrm = 0.0;
-      lum_incidence(poses + 6 * vi, inc);
-      if (solve6(inc, &B[6 * (vi - 1)], sol) != MVR_OK) continue;       // incidence^-1 * X_vi
+      double sol[6], dp[6], nrm = 0.0;
+      if (!solve_incidence(poses + 6 * vi, &B[6 * (vi - 1)], sol)) continue;       // incidence^-1 * X_vi
       for (int r = 0; r < 6; ++r) { dp[r] = -sol[r]; nrm += sol[r] * sol[r]; }
       sum += std::sqrt(nrm);
       for (int r = 0; r < 6; ++r) poses[6 * vi + r] += dp[r];

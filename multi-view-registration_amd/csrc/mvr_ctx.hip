@@ -566,7 +566,9 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
   if (add) {
     ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)add);
     MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-    new_point_set(c, d);                      // a different point set: its order is rebuilt on next use
+    // a different point set.  Its ordering: the old one extended by the appended scan's own (the points that were
+    // there did not move: registrator.cpp:576 only ever appends), or -- when that is not possible -- rebuilt on next use
+    if (!(dst != src && d.segs.empty() && extend_point_set(c, d, d.n, s))) new_point_set(c, d);
     // normals survive only if both parts carry them
     const bool keep = s.has_normals && (d.has_normals || d.n == 0);
     if (keep) {
@@ -597,7 +599,7 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   if (int rc = launch_transform_f64(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
   if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
-  c->slots[dst].coords_valid = false;
+  c->slots[dst].stale_coords();
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
     if (int rc = launch_rotate_normals_f64(c, c->slots[src].nrm, c->slots[dst].nrm, n, T)) return rc;
@@ -641,7 +643,7 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     if (!in[k]) continue;
     c->slots[dst[k]].n = n[k];
     if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
-    c->slots[dst[k]].coords_valid = false;
+    c->slots[dst[k]].stale_coords();
     c->slots[dst[k]].has_normals = false;
   }
   // Culled search: the posed copies are about to be searched -- bring their index up to date here, from the
@@ -685,7 +687,7 @@ API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16
   if (int rc = launch_transform_f32(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
   if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
-  c->slots[dst].coords_valid = false;
+  c->slots[dst].stale_coords();
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
     if (int rc = launch_rotate_normals_f32(c, c->slots[src].nrm, c->slots[dst].nrm, n, T)) return rc;
@@ -1240,7 +1242,7 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     }
     cur_mse = h[7];
     if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
-    cur.coords_valid = false;
+    cur.stale_coords();
     mvr_mat4f_mul(tr, fin, fin);
     ++iters;
     state = MVR_CONV_NOT; converged = 0;
@@ -1260,7 +1262,7 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
     c->slots[os].n = ns;
     if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
-    c->slots[os].coords_valid = false;
+    c->slots[os].stale_coords();
     if (c->slots[ss].has_normals && ns) {      // ICP::transformCloud rotates the source normals too
       if (int rc = ensure(c, c->slots[os].nrm, c->slots[os].nrm_cap, ns)) return rc;
       if (int rc = launch_rotate_normals_f32(c, c->slots[ss].nrm, c->slots[os].nrm, ns, fin)) return rc;

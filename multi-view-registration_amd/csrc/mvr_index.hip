@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
   float4 *__restrict__ sorted = rb.sorted[cloud], *__restrict__ tlo = rb.tlo[cloud], *__restrict__ thi = rb.thi[cloud],
          *__restrict__ cbox = rb.cbox[cloud];
   const int lane = threadIdx.x & 63;
-  const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t tile = (size_t)rb.tile_begin[cloud] + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const size_t base = tile * kCullTile;
   if (base >= n) return;
   float tl[3] = {3.0e38f, 3.0e38f, 3.0e38f}, th[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -227,8 +227,9 @@ __global__ void __launch_bounds__(64) super_box_kernel(RefreshBatch rb)
   float4 *__restrict__ sbox = rb.sbox[cloud];
   const size_t n_tiles = ((size_t)rb.n[cloud] + kCullTile - 1) / kCullTile;
   const int lane = threadIdx.x;
-  if ((size_t)blockIdx.x * 64 >= n_tiles) return;
-  const size_t t = (size_t)blockIdx.x * 64 + lane;
+  const size_t sb = (size_t)(rb.tile_begin[cloud] / 64u) + blockIdx.x;       // (a partial refresh starts at the super box of its first tile)
+  if (sb * 64 >= n_tiles) return;
+  const size_t t = sb * 64 + lane;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   if (t < n_tiles) {
     const float4 a = tlo[t], b = thi[t];
@@ -241,9 +242,19 @@ __global__ void __launch_bounds__(64) super_box_kernel(RefreshBatch rb)
       hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
     }
   if (lane == 0) {
-    sbox[2 * (size_t)blockIdx.x] = make_float4(lo[0], lo[1], lo[2], 0.f);
-    sbox[2 * (size_t)blockIdx.x + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    sbox[2 * sb] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    sbox[2 * sb + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
   }
+}
+
+// dst's ordering grows by an appended cloud's own: perm / inv entries old_n .. old_n + n_s - 1
+__global__ void append_order_kernel(uint32_t *__restrict__ perm, uint32_t *__restrict__ inv, const uint32_t *__restrict__ sperm,
+                                    const uint32_t *__restrict__ sinv, size_t n_s, uint32_t old_n)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_s) return;
+  perm[old_n + k] = old_n + sperm[k];
+  inv[old_n + k] = old_n + sinv[k];
 }
 
 // ------------------------------------------------------ reciprocal glue (sorted space)
@@ -387,7 +398,7 @@ void new_point_set(Ctx *c, Cloud &cl)
 {
   cl.set_id = c->next_set_id++;
   cl.order.reset();
-  cl.coords_valid = false;
+  cl.stale_coords();
 }
 
 void inherit_point_set(Cloud &dst, const Cloud &src)
@@ -399,7 +410,28 @@ void inherit_point_set(Cloud &dst, const Cloud &src)
   dst.set_id = src.set_id;
   if (src.order) dst.order = src.order;
   else if (!same) dst.order.reset();
+  dst.stale_coords();
+}
+
+bool extend_point_set(Ctx *c, Cloud &dst, size_t old_n, const Cloud &src)
+{
+  const size_t add = src.n, n = old_n + add;
+  if (c->nn_mode == 0 || old_n == 0 || add == 0 || n > 0xFFFFFFF0ull) return false;
+  if (!dst.order || dst.order->n != old_n || !src.order || src.order->n != add || dst.order == src.order) return false;
+  if (dst.order.use_count() != 1) return false;                          // another cloud shares dst's ordering: it must not change under it
+  if (dst.order->perm_bytes < n * sizeof(uint32_t) || dst.order->inv_bytes < n * sizeof(uint32_t)) return false;
+  hipLaunchKernelGGL(append_order_kernel, dim3((unsigned)((add + 255) / 256)), dim3(256), 0, c->stream, dst.order->perm, dst.order->inv,
+                     src.order->perm, src.order->inv, add, (uint32_t)old_n);
+  if (hipGetLastError() != hipSuccess) return false;
+  dst.order->n = n;
+  c->orders.erase(dst.set_id);
+  dst.set_id = c->next_set_id++;                                         // a different point set, with an ordering already
+  c->orders[dst.set_id] = dst.order;
+  // the sorted copy and the boxes of the points that were there stay valid (they did not move): only the tail is refreshed
+  const bool head_ok = dst.coords_valid && dst.sorted != nullptr;
   dst.coords_valid = false;
+  dst.fresh_tiles = head_ok ? old_n / kCullTile : 0;
+  return true;
 }
 
 // ordering (once per point set) and buffers; *stale = the sorted copy / boxes must be refreshed
@@ -416,7 +448,7 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
       cl.order = it->second.lock();
       if (cl.order && cl.order->n != n) cl.order.reset();
     }
-    cl.coords_valid = false;
+    cl.stale_coords();
   }
   if (!cl.order) {
     // sort once per point set: bbox -> 30-bit Morton codes -> radix sort -> perm / inv
@@ -467,13 +499,16 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
     c->orders[cl.set_id] = ord;
     // every resident copy of this point set shares the new ordering
     for (Cloud &o : c->slots) if (&o != &cl && o.set_id == cl.set_id && o.n == n && !o.order) o.order = ord;
-    cl.coords_valid = false;
+    cl.stale_coords();
   }
   if (!cl.coords_valid) {
     // buffers follow the cloud's CAPACITY (a target reserved for all its scans is never re-allocated as it grows)
     const size_t room = std::max(n, cl.cap), room_tiles = (room + kCullTile - 1) / kCullTile;
+    const float4 *sorted_before = cl.sorted;
     if (int rc = ensure(c, cl.sorted, cl.sorted_cap, cl.sorted_cap >= n ? n : room)) return rc;
+    if (cl.sorted != sorted_before) cl.fresh_tiles = 0;          // a new buffer holds nothing
     if (cl.tiles_cap < tiles) {
+      cl.fresh_tiles = 0;
       (void)hipStreamSynchronize(c->stream);
       if (cl.tlo) (void)hipFree(cl.tlo);
       if (cl.thi) (void)hipFree(cl.thi);
@@ -509,14 +544,18 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
       rb.pts[k] = cl ? cl->pts : nullptr; rb.perm[k] = cl ? cl->order->perm : nullptr; rb.n[k] = cl ? cl->n : 0;
       rb.sorted[k] = cl ? cl->sorted : nullptr; rb.tlo[k] = cl ? cl->tlo : nullptr; rb.thi[k] = cl ? cl->thi : nullptr;
       rb.cbox[k] = cl ? cl->cbox : nullptr; rb.sbox[k] = cl ? cl->sbox : nullptr;
-      if (cl) { tmax = std::max(tmax, (cl->n + kCullTile - 1) / kCullTile); work += 36.0 * (double)cl->n; }
+      // a cloud that only grew at its end (fresh_tiles) refreshes from the tile of its first new point on; posed
+      // copies (from) are always refreshed whole
+      const size_t t0 = (cl && !rb.from[k]) ? std::min(cl->fresh_tiles, (cl->n + kCullTile - 1) / kCullTile) : 0;
+      rb.tile_begin[k] = (unsigned)t0;
+      if (cl) { tmax = std::max(tmax, (cl->n + kCullTile - 1) / kCullTile - t0); work += 36.0 * (double)(cl->n - t0 * kCullTile); }
     }
     if (tmax == 0) continue;
     ProfScope ps(c, MVR_K_GLUE, work);
     hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tmax + 3) / 4), (unsigned)m), dim3(256), 0, c->stream, rb);
-    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64), (unsigned)m), dim3(64), 0, c->stream, rb);
+    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64 + 1), (unsigned)m), dim3(64), 0, c->stream, rb);     // (+1: a partial range may straddle one more super box)
     MVR_HIP_TRY(c, hipGetLastError());
-    for (int k = 0; k < m; ++k) clouds[base + k]->coords_valid = true;
+    for (int k = 0; k < m; ++k) { clouds[base + k]->coords_valid = true; clouds[base + k]->fresh_tiles = 0; }
   }
   return MVR_OK;
 }

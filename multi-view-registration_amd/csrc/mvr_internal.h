@@ -63,6 +63,8 @@ struct Cloud {
   float4 *cbox = nullptr;              // [tiles][4 cells][lo, hi]: AABBs of the 64-point cells of every tile
   float4 *sbox = nullptr;              // [ceil(tiles / 64)][lo, hi]: AABBs of 64 consecutive tiles
   bool coords_valid = false;           // sorted[] / tlo / thi / cbox match pts[]
+  size_t fresh_tiles = 0;              // with !coords_valid: that many LEADING tiles of sorted[] / boxes are still current (a cloud that only grew at its end: mvr_cloud_append with an extended ordering); any other change of the coordinates resets it
+  void stale_coords() { coords_valid = false; fresh_tiles = 0; }
   // optional unit normals {nx,ny,nz,0} (point-to-plane extension, K10)
   float4 *nrm = nullptr; size_t nrm_cap = 0;
   bool has_normals = false;
@@ -234,6 +236,7 @@ struct RefreshBatch {
   // optional, with `from`: the source's points in original order and where their posed copies go (the transform itself,
   // done by the same launch)
   const float4 *xsrc[kBatchClouds]; float4 *xdst[kBatchClouds];
+  unsigned tile_begin[kBatchClouds];       // refresh tiles from this one on (a cloud that grew at its end keeps its leading tiles)
 };
 // index of posed copies, straight from the sources' sorted copies (culled mode; called by mvr_cloud_transform_batch).
 // with_pts: also write dst->pts = T * src->pts.  handled[k] (optional) = cloud k was refreshed by this call.
@@ -254,6 +257,10 @@ int launch_nn(Ctx *c, const float4 *q, size_t q_begin, size_t q_count, const uin
 int ensure_index(Ctx *c, Cloud &cl);
 void new_point_set(Ctx *c, Cloud &cl);                 // after upload / append / clear
 void inherit_point_set(Cloud &dst, const Cloud &src);  // after copy / transform
+// dst has just grown from old_n points by the points of `src` (appended at its end): keep dst's ordering and extend it by
+// src's own, shifted -- the merged target of the sequential mode then never sorts its 2M points again.  false: not
+// applicable (no ordering on either side, a shared ordering, no room): the caller falls back to new_point_set.
+bool extend_point_set(Ctx *c, Cloud &dst, size_t old_n, const Cloud &src);
 // culled exact NN.  Queries: sorted positions [q_begin, q_begin+q_count) of the query cloud; key ordinal = ORIGINAL
 // index of the query, or -- with qflags (one byte per sorted position, only flagged positions are searched) -- the
 // sorted position.  cap2: distances above it are not needed (+inf = unbounded).  The batch form runs the searches
