@@ -867,7 +867,9 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   const nnkey_t *keys_before = w->bkeys;
   if (int rc = ensure(w, w->bkeys, w->bkeys_cap, off_s[n_pairs])) return rc;
   if (int rc = ensure(w, w->brkeys, w->brkeys_cap, off_t[n_pairs])) return rc;
+  const uint32_t *bound_before = w->bbound;
   if (int rc = ensure(w, w->bbound, w->bbound_cap, off_t[n_pairs])) return rc;
+  if (w->bbound != bound_before) w->bbound_clean = false;
   if (int rc = ensure(w, w->bpartials, w->bpartials_cap, off_p[n_pairs])) return rc;
   if (int rc = ensure(w, w->blist, w->blist_cap, off_t[n_pairs])) return rc;
   if (int rc = ensure(w, w->bslot, w->bslot_cap, off_t[n_pairs])) return rc;
@@ -897,13 +899,17 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, w->bkeys + off_s[k]);
     fwd[k].key_by_pos = 1;       // forward keys live in sorted space from here on: slot = the query's position, low word = the match's position
     fwd[k].seed_from_keys = seed ? 1u : 0u;
-    if (reciprocal && qn[k]) { fwd[k].clear = w->bbound + off_t[k]; fwd[k].clear_n = (uint32_t)t.n; }    // the forward launch presets the start bounds
+    if (reciprocal && qn[k] && c->fused_mark) fwd[k].mark = w->bbound + off_t[k];      // the forward launch records where the reverse searches start
     // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
     rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, w->brkeys + off_t[k]);
     rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
     rev[k].qbound = w->bbound + off_t[k];      // a matched target has a source point at the forward distance: its search starts there
   }
-  if (phases & 1) { if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc; }
+  if (phases & 1) {
+    if (reciprocal && !w->bbound_clean) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, w->bbound_cap * sizeof(uint32_t), w->stream));
+    if (reciprocal) w->bbound_clean = false;        // dirty until this pass's moments launch has put it back
+    if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+  }
   if (!(phases & 2)) return MVR_OK;
   const bool recip = reciprocal != 0;
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
@@ -925,12 +931,13 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       g.q_begin = qb[k]; g.q_count = qn[k]; g.blocks = reduce_blocks_for(c, qn[k]);
     }
     if (recip) {
-      if (int rc = launch_flag_matched_batch(w, gb, m)) return rc;
+      if (!c->fused_mark) { if (int rc = launch_flag_matched_batch(w, gb, m)) return rc; }      // (else: marked by the forward launch itself)
       if (int rc = launch_compact_flags_batch(w, gb, m)) return rc;
       if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc;
     }
     if (int rc = launch_accept_moments2_batch(w, gb, m)) return rc;
   }
+  if (recip) w->bbound_clean = true;
   return MVR_OK;
 }
 
@@ -1329,6 +1336,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
   else if (!std::strcmp(key, "cull_slices")) c->cull_slices = value;
   else if (!std::strcmp(key, "seed_forward")) c->seed_forward = value != 0;
+  else if (!std::strcmp(key, "fused_mark")) c->fused_mark = value != 0;
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
   else if (!std::strcmp(key, "posed_refresh")) c->posed_refresh = value != 0;
   else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }

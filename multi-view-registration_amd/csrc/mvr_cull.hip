@@ -122,7 +122,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
                const uint32_t *__restrict__ qlist, const uint32_t *__restrict__ qcount, const float4 *__restrict__ ts, uint32_t nt,
                const float4 *__restrict__ tlo, const float4 *__restrict__ thi, const float4 *__restrict__ cbox,
                const float4 *__restrict__ sbox, uint32_t n_tiles, float cap2, nnkey_t *__restrict__ keys, uint32_t key_by_pos,
-               const uint32_t *__restrict__ qbound, uint32_t seed_from_keys, uint32_t set, unsigned long long *__restrict__ evals)
+               const uint32_t *__restrict__ qbound, uint32_t seed_from_keys, uint32_t *__restrict__ mark, uint32_t set,
+               unsigned long long *__restrict__ evals)
 {
   constexpr int NQ = 4 * Q;      // queries per lane
   constexpr int NB = 64 * Q;     // queries per block
@@ -693,6 +694,8 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
         if (!(qflags || qlist) && !key_by_pos) ord = (W == 1) ? __float_as_uint(qs[q_begin + pos].w) : fqw[j];
         const uint32_t low = key_by_pos ? (uint32_t)ow : (uint32_t)(ow >> 32);
         keys[ord] = (found && ow != kNoWinner) ? (((nnkey_t)dbits << 32) | low) : kKeyInit;
+        // the matched target's reverse search may start from this distance (the fused pass: `low` is its position)
+        if (mark && found && ow != kNoWinner) __atomic_store_n(&mark[low], dbits, __ATOMIC_RELAXED);
       }
     }
     // one column's candidates at a time: with the loads of all columns hoisted to the top the kernel no longer fits its
@@ -794,10 +797,8 @@ nn_cull_kernel(CullBatch batch, XcdMap map, unsigned long long *__restrict__ eva
   if (!xcd_map_block(map, blockIdx.x, &pair, &set)) return;          // block-uniform
   pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)pair); set = (uint32_t)__builtin_amdgcn_readfirstlane((int)set);
   const CullPair &a = batch.p[pair];
-  if (a.clear)        // the blocks of the pair share out the array (each clears its stride)
-    for (uint32_t i = set * (64u * W) + threadIdx.x; i < a.clear_n; i += map.sets[pair] * (64u * W)) a.clear[i] = 0xFFFFFFFFu;
   nn_cull_body<FMA, Q, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
-                          a.keys, a.key_by_pos, a.qbound, a.seed_from_keys, set, evals);
+                          a.keys, a.key_by_pos, a.qbound, a.seed_from_keys, a.key_by_pos ? a.mark : nullptr, set, evals);
 }
 
 }  // namespace

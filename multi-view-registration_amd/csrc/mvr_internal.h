@@ -135,6 +135,7 @@ struct Ctx {
   int cull_w = 0;                                     // culled kernel: waves sharing one query set (1, 2, 4; 0 = by launch size)
   int cull_slices = 0;                                // culled kernel: interleaved slices a pair's query sets are dealt to the XCDs in (1, 2, 4, 8; 0 = 8 / gcd(pairs, 8))
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
+  int fused_mark = 1;                                 // fused pass: the forward launch itself records the matched targets' start bounds (0: a separate launch re-reads the keys)
   std::vector<unsigned long long> fused_sig;          // what the forward keys in bkeys[] belong to (point-set ids, ranges, offsets): the previous fused pass on this context
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
   // workers: contexts with their own stream and work buffers that BORROW clouds of this
@@ -149,6 +150,7 @@ struct Ctx {
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint32_t *bbound = nullptr; size_t bbound_cap = 0;     // [targets of all pairs] bits of the forward d2 of a source that matched the target (~0: not matched)
+  bool bbound_clean = false;                             // bbound[] is all ~0 (the moments launch of a pass restores what its forward launch marked)
   uint32_t *blist = nullptr; size_t blist_cap = 0;
   uint32_t *bslot = nullptr; size_t bslot_cap = 0;
   uint32_t *bchunks = nullptr; size_t bchunks_cap = 0;      // per-chunk counts / offsets, then one count per pair
@@ -273,7 +275,7 @@ struct CullPair {
   nnkey_t *keys = nullptr;
   uint32_t q_begin = 0, q_count = 0, nt = 0, n_tiles = 0;
   const uint32_t *qbound = nullptr;   // optional, by sorted position: bits of a distance (squared) within which the query is KNOWN to have a point -- the search starts from that bound instead of the cap
-  uint32_t *clear = nullptr; uint32_t clear_n = 0;   // optional: [clear_n] words this launch sets to ~0 on the side (the pair's start-bound array, before the flag stage: saves a memset launch in the chain of small kernels)
+  uint32_t *mark = nullptr;      // optional, with key_by_pos: [nt] start bounds of the reverse searches, by the target's sorted position (all ~0 on entry).  A query that finds a match within the cap stores the bits of its d2 at its match's position -- what a separate "flag the matched targets" launch did by re-reading all the keys.  Any matching source's distance is a valid bound: relaxed stores, last one wins.
   uint32_t key_by_pos = 0;       // plain queries only: key slot = the query's sorted position (coalesced stores) instead of its original index, AND the key's low word = the match's sorted position instead of its original index
   uint32_t seed_from_keys = 0;   // with key_by_pos: keys[] still holds the previous result of the same queries against the same target point set; every search starts from the distance of its previous match
 };

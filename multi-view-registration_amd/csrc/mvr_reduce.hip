@@ -469,6 +469,11 @@ __global__ void __launch_bounds__(kRT) accept_moments2_batch_kernel(GlueBatch b)
 {
   const GluePair &a = b.p[blockIdx.y];
   if ((int)blockIdx.x >= a.blocks) return;
+  // the start bounds the forward launch marked have been consumed by the reverse launch: back to "no target matched",
+  // ready for the next pass's forward launch (nothing in this kernel reads them)
+  if (a.bound && b.reciprocal)
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.nt; i += (unsigned long long)a.blocks * blockDim.x)
+      a.bound[i] = 0xFFFFFFFFu;
   const Vec3d o{b.origin[0], b.origin[1], b.origin[2]};
   if (a.by_pos)
     accept_moments2_body<true>(a.qs, a.ts, a.keys, a.rkeys, a.slot, nullptr, a.tinv, (size_t)a.q_begin, (size_t)a.q_count, b.max2, b.reciprocal, o,

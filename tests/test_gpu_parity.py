@@ -47,6 +47,45 @@ def test_cloud_roundtrip_and_append(gpu):
     assert np.array_equal(gpu.download(4), a)
 
 
+def test_grown_target_searches_like_a_fresh_upload(gpu, orc, mvr):
+    """A target that grows by mvr_cloud_append keeps its ordering and extends it by the appended cloud's own (no re-sort
+    of the merged cloud: the sequential mode's growing target, registrator.cpp:576).  Whatever the ordering, searches
+    are exact: the grown target answers like the same points uploaded at once -- ragged sizes (tile seams inside 256-point
+    tiles), several appends, an append after the ordering was shared by a copy (falls back to a rebuild), a self-append."""
+    rng = np.random.default_rng(106)
+    parts = [rand_cloud(rng, n, scale=25) for n in (3000, 1777, 256, 5001, 33)]
+    q = rand_cloud(rng, 4000, scale=25)
+    gpu.upload(0, parts[0]); gpu.reserve(0, 40000); gpu.upload(5, q)
+    whole = parts[0]
+    for k, p in enumerate(parts[1:]):
+        i0, d0 = gpu.nn(5, 0)                       # the target is indexed (and searched) before it grows again
+        oi, od = orc.nn(q, whole, kdtree=True)
+        assert np.array_equal(i0, oi) and np.array_equal(bits(d0), bits(od))
+        gpu.upload(1, p)
+        gpu.nn(1, 0)                                # the appended cloud has an ordering of its own (as an aligned scan has)
+        if k == 2:
+            gpu.copy(7, 0)                          # a copy now shares the target's ordering: the next append must not touch it
+            gpu.nn(5, 7)
+        gpu.append(0, 1)
+        whole = np.concatenate([whole, p])
+        if k == 2:
+            i7, d7 = gpu.nn(5, 7)                   # the copy still answers for the OLD point set
+            o7, od7 = orc.nn(q, whole[:len(whole) - len(p)], kdtree=True)
+            assert np.array_equal(i7, o7) and np.array_equal(bits(d7), bits(od7))
+    gi, gd = gpu.nn(5, 0)
+    oi, od = orc.nn(q, whole, kdtree=True)
+    assert gpu.size(0) == len(whole) and np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
+    gpu.upload(2, whole)
+    fi, fd = gpu.nn(5, 2)
+    assert np.array_equal(gi, fi) and np.array_equal(bits(gd), bits(fd))
+    qq, mm, dd = gpu.correspondences(5, 0, 6.0)
+    c = orc.correspondences(q, whole, 6.0, kdtree=True)
+    assert np.array_equal(qq, c["query"]) and np.array_equal(mm, c["match"]) and np.array_equal(bits(dd), bits(c["dist2"]))
+    gpu.append(0, 0)                                # self-append: the ordering is rebuilt
+    si, sd = gpu.nn(5, 0)
+    assert np.array_equal(si, oi) and np.array_equal(bits(sd), bits(od))      # duplicates sit at higher indices: the lowest index wins
+
+
 def test_transforms_bit_exact(gpu, orc):
     rng = np.random.default_rng(101)
     pts = rand_cloud(rng, 5000)
