@@ -127,8 +127,30 @@ void cloud_free(Cloud &cl)
   if (cl.cbox) (void)hipFree(cl.cbox);
   if (cl.sbox) (void)hipFree(cl.sbox);
   if (cl.nrm) (void)hipFree(cl.nrm);
-  cl.order.reset();
+  if (cl.gsorted) (void)hipFree(cl.gsorted);
+  cl.order.reset(); cl.grid.reset();
   cl = Cloud();
+}
+
+// dst = T * src was just computed by the f64 transform kernel: remember the pose when src holds its set's canonical
+// coordinates and T is a rigid motion (what the grid search needs to walk the set's pose-invariant grid)
+void note_pose(Cloud &dst, const Cloud &src, bool src_canonical, const double T[16])
+{
+  dst.canonical = false; dst.pose_known = false;
+  if (!src_canonical || &dst == &src) return;
+  if (T[3] != 0.0 || T[7] != 0.0 || T[11] != 0.0 || T[15] != 1.0) return;
+  // rigid to within FLOAT rounding: the poses of a registration are products with PCL-style float 4x4s
+  // (lum.getTransformation is an Eigen::Affine3f), orthonormal to ~1e-7 only.  The search maps its queries with the true
+  // inverse of the 3x3 (make_grid_pair), so what is left of the non-rigidity is a relative distortion of distances of
+  // that size, inside the search ball's relative margin (1e-5).
+  for (int a = 0; a < 3; ++a)
+    for (int b = a; b < 3; ++b) {
+      const double d = T[4 * a] * T[4 * b] + T[4 * a + 1] * T[4 * b + 1] + T[4 * a + 2] * T[4 * b + 2];
+      if (std::fabs(d - (a == b ? 1.0 : 0.0)) > 2e-6) return;
+    }
+  dst.pose_known = true;
+  std::memcpy(dst.pose, T, 16 * sizeof(double));
+  dst.grid = src.grid;
 }
 
 float cap_from_max2(double max2)
@@ -299,6 +321,7 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
   if (const char *m = std::getenv("MVR_CULL_SLICES")) c->cull_slices = std::atoi(m);   // XCD dealing of a pair's query sets: 1, 2, 4, 8 (0 = auto)
   if (const char *m = std::getenv("MVR_SEED_FORWARD")) c->seed_forward = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_RING_SEARCH")) c->ring_search = std::atoi(m);   // fused pass: 1 = grid search for bounded queries, 0 = culled kernel only
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_POSED_REFRESH")) c->posed_refresh = std::atoi(m) != 0;
@@ -347,10 +370,10 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (auto &s : c->slots) cloud_free(s);
-  c->orders.clear();
+  c->orders.clear(); c->grids.clear();
   if (c->order_pool) c->order_pool->close();          // orderings that outlive the context free their buffers themselves
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_table) (void)hipHostFree(c->h_table);
@@ -415,6 +438,7 @@ API int mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, siz
     MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   cl.n = n;
+  cl.canonical = true;            // these are the point set's canonical coordinates (the grid search's frame of reference)
   return MVR_OK;
 }
 
@@ -538,6 +562,7 @@ API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
   }
   d.n = s.n;
   inherit_point_set(d, s);
+  d.canonical = s.canonical; d.pose_known = s.pose_known; std::memcpy(d.pose, s.pose, sizeof d.pose); d.grid = s.grid;
   d.segs = s.segs;
   d.has_normals = false;
   if (s.has_normals && s.n) {
@@ -598,8 +623,11 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
   if (int rc = launch_transform_f64(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
+  const bool src_canon = c->slots[src].canonical;
   if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
+  else { c->slots[dst].canonical = false; c->slots[dst].pose_known = false; c->slots[dst].grid.reset(); }      // moved in place: no longer the upload coordinates
   c->slots[dst].stale_coords();
+  note_pose(c->slots[dst], c->slots[src], src_canon && dst != src, T);
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
     if (int rc = launch_rotate_normals_f64(c, c->slots[src].nrm, c->slots[dst].nrm, n, T)) return rc;
@@ -642,8 +670,11 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
   for (int k = 0; k < count; ++k) {
     if (!in[k]) continue;
     c->slots[dst[k]].n = n[k];
+    const bool src_canon = c->slots[src[k]].canonical;
     if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
+    else { c->slots[dst[k]].canonical = false; c->slots[dst[k]].pose_known = false; c->slots[dst[k]].grid.reset(); }
     c->slots[dst[k]].stale_coords();
+    note_pose(c->slots[dst[k]], c->slots[src[k]], src_canon && dst[k] != src[k], T + (size_t)k * 16);
     c->slots[dst[k]].has_normals = false;
   }
   // Culled search: the posed copies are about to be searched -- bring their index up to date here, from the
@@ -687,6 +718,7 @@ API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16
   if (int rc = launch_transform_f32(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
   if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
+  else { c->slots[dst].canonical = false; c->slots[dst].pose_known = false; c->slots[dst].grid.reset(); }
   c->slots[dst].stale_coords();
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
@@ -835,7 +867,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_wide = c->grid_wide; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -905,10 +937,54 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
     rev[k].qbound = w->bbound + off_t[k];      // a matched target has a source point at the forward distance: its search starts there
   }
+  // Which kernel: bounded queries (a forward search seeded by its previous match, every reverse search) walk the uniform
+  // grid, one thread per query, a few dozen evaluations each (mvr_grid.hip); queries without a bound -- the first pass --
+  // take the culled kernel.  Both are exact; the choice never shows in a result.
+  bool grid_ok = c->ring_search != 0 && cap2 < FLT_MAX;
+  for (int k = 0; k < n_pairs && grid_ok; ++k) {
+    const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
+    if (qn[k] == 0) continue;
+    grid_ok = s.grid && t.grid && s.gcoords_valid && t.gcoords_valid && s.grid->n == s.n && t.grid->n == t.n &&
+              s.order && t.order && s.grid->built_for == s.order.get() && t.grid->built_for == t.order.get();
+  }
+  std::vector<GridPair> gfwd, grev;
+  if (grid_ok) {
+    if (int rc = ensure(w, w->bheavy, w->bheavy_cap, off_s[n_pairs] + off_t[n_pairs])) return rc;      // forward flags by source position, then reverse flags by list position
+    if (int rc = ensure(w, w->bwide, w->bwide_cap, off_s[n_pairs] + off_t[n_pairs])) return rc;        // the lists of wide bounded queries, same layout
+    if (!w->bwide_count) {                                                                              // their counters: zero now, put back to zero by every pass's moments launch
+      MVR_HIP_TRY(w, hipMalloc(&w->bwide_count, 2 * kWideCounters * sizeof(uint32_t)));
+      MVR_HIP_TRY(w, hipMemsetAsync(w->bwide_count, 0, 2 * kWideCounters * sizeof(uint32_t), w->stream));
+    }
+    if (n_pairs > kWideCounters) grid_ok = false;
+  }
+  if (grid_ok) {
+    gfwd.resize((size_t)n_pairs); grev.resize((size_t)n_pairs);
+    for (int k = 0; k < n_pairs; ++k) {
+      const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
+      if (qn[k] == 0) { gfwd[k] = GridPair(); grev[k] = GridPair(); continue; }
+      gfwd[k] = make_grid_pair(s, qb[k], qn[k], t, w->bkeys + off_s[k]);
+      gfwd[k].key_by_pos = 1; gfwd[k].seed_from_keys = 1; gfwd[k].mark = fwd[k].mark;
+      gfwd[k].heavy = w->bheavy + off_s[k];      // wide balls are left to the culled kernel: same keys, same marks
+      grev[k] = make_grid_pair(t, 0, std::min(qn[k], t.n), s, w->brkeys + off_t[k]);
+      grev[k].qlist = rev[k].qlist; grev[k].qcount = rev[k].qcount; grev[k].qbound = rev[k].qbound;
+      grev[k].heavy = w->bheavy + off_s[n_pairs] + off_t[k];
+      if (c->grid_wide) {
+        grev[k].heavy = nullptr;                 // every reverse query has a bound: the wide ones all take the wave-per-query launch
+        gfwd[k].wide_list = w->bwide + off_s[k]; gfwd[k].wide_count = w->bwide_count + k;
+        grev[k].wide_list = w->bwide + off_s[n_pairs] + off_t[k]; grev[k].wide_count = w->bwide_count + kWideCounters + k;
+      }
+    }
+  }
   if (phases & 1) {
     if (reciprocal && !w->bbound_clean) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, w->bbound_cap * sizeof(uint32_t), w->stream));
     if (reciprocal) w->bbound_clean = false;        // dirty until this pass's moments launch has put it back
-    if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+    if (grid_ok && seed) {
+      if (int rc = launch_nn_grid_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc;
+      if (c->grid_wide) { if (int rc = launch_nn_grid_wide_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc; }
+      // ... and the queries it flagged, in place (blocks without a flagged query leave at once)
+      for (int k = 0; k < n_pairs; ++k) fwd[k].qflags = qn[k] ? w->bheavy + off_s[k] : nullptr;
+      if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+    } else if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
   }
   if (!(phases & 2)) return MVR_OK;
   const bool recip = reciprocal != 0;
@@ -929,11 +1005,18 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       g.nt = qn[k] ? t.n : 0;
       g.partials = w->bpartials + off_p[k]; g.out = table + (size_t)k * 32;
       g.q_begin = qb[k]; g.q_count = qn[k]; g.blocks = reduce_blocks_for(c, qn[k]);
+      if (grid_ok && c->grid_wide) { g.zero_a = w->bwide_count + k; g.zero_b = w->bwide_count + kWideCounters + k; }
     }
     if (recip) {
       if (!c->fused_mark) { if (int rc = launch_flag_matched_batch(w, gb, m)) return rc; }      // (else: marked by the forward launch itself)
       if (int rc = launch_compact_flags_batch(w, gb, m)) return rc;
-      if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc;
+      if (grid_ok) {
+        if (int rc = launch_nn_grid_batch(w, grev.data() + base, m, cap2, fma != 0)) return rc;
+        if (c->grid_wide) { if (int rc = launch_nn_grid_wide_batch(w, grev.data() + base, m, cap2, fma != 0)) return rc; }
+        else
+        for (int j = 0; j < m; ++j) rev[base + j].qflags = qn[base + j] ? w->bheavy + off_s[n_pairs] + off_t[base + j] : nullptr;     // the wide ones, by list position
+        if (!c->grid_wide) { if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc; }
+      } else if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc;
     }
     if (int rc = launch_accept_moments2_batch(w, gb, m)) return rc;
   }
@@ -961,6 +1044,18 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     std::vector<Cloud *> used;
     for (int k = 0; k < n_pairs; ++k) { used.push_back(&c->slots[src[k]]); used.push_back(&c->slots[dst[k]]); }
     if (int rc = ensure_index_batch(c, used.data(), (int)used.size())) return rc;      // one refresh launch for all views
+    if (c->pair_fused && c->ring_search && max_dist * max_dist < (double)FLT_MAX) {
+      // the grid search's side: every posed copy finds its set's grid (built once, from the cloud that holds the set's
+      // canonical coordinates) and refreshes its coordinates in grid order -- one launch for all views
+      std::sort(used.begin(), used.end());
+      used.erase(std::unique(used.begin(), used.end()), used.end());
+      for (Cloud *cl : used) {
+        if (cl->grid || !cl->pose_known || cl->n == 0) continue;
+        for (Cloud &o : c->slots)
+          if (o.set_id == cl->set_id && o.canonical && o.n == cl->n) { if (ensure_grid(c, o)) cl->grid = o.grid; break; }
+      }
+      if (int rc = refresh_grid_coords_batch(c, used.data(), (int)used.size())) return rc;
+    }
   }
   if (c->nn_mode != 0 && c->pair_fused) {
     // Optionally in G groups of pairs, group 0 on the caller's stream and the others on worker streams: a group's
@@ -1337,6 +1432,9 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_slices")) c->cull_slices = value;
   else if (!std::strcmp(key, "seed_forward")) c->seed_forward = value != 0;
   else if (!std::strcmp(key, "fused_mark")) c->fused_mark = value != 0;
+  else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
+  else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
+  else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
   else if (!std::strcmp(key, "posed_refresh")) c->posed_refresh = value != 0;
   else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }

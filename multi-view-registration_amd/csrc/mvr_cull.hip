@@ -690,12 +690,12 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
         // Low word: the winner's original index -- or, key_by_pos, its SORTED POSITION: the consumers of the fused
         // pass (start bounds, reciprocal filter, moments) work in sorted space, so no original-index -> position
         // gather is left between the stages.
-        uint32_t ord = (qflags || qlist) ? pos : q_begin + pos;
+        uint32_t ord = (qlist || (qflags && !key_by_pos)) ? pos : q_begin + pos;      // (flagged queries of a fused pass keep their absolute slots)
         if (!(qflags || qlist) && !key_by_pos) ord = (W == 1) ? __float_as_uint(qs[q_begin + pos].w) : fqw[j];
         const uint32_t low = key_by_pos ? (uint32_t)ow : (uint32_t)(ow >> 32);
         keys[ord] = (found && ow != kNoWinner) ? (((nnkey_t)dbits << 32) | low) : kKeyInit;
         // the matched target's reverse search may start from this distance (the fused pass: `low` is its position)
-        if (mark && found && ow != kNoWinner) __atomic_store_n(&mark[low], dbits, __ATOMIC_RELAXED);
+        if (mark && found && ow != kNoWinner) __hip_atomic_store(&mark[low], dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     // one column's candidates at a time: with the loads of all columns hoisted to the top the kernel no longer fits its
@@ -773,22 +773,6 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 // 8), so that pairs * slices fills the 8 XCDs evenly) and slice u of the launch goes to the blocks with b mod 8 ==
 // u mod 8, one slice after the other: an XCD works on one target at a time and a target is read by `slices` XCDs
 // instead of 8.  Interleaved slices keep the XCDs balanced: heavy query sets are neighbours in the Hilbert order.
-struct XcdMap { uint32_t sets[kBatchPairs]; uint32_t n_pairs, slices; };
-__host__ __device__ inline uint32_t slice_len(uint32_t sets, uint32_t slices, uint32_t slice)
-{
-  return sets > slice ? (sets - slice + slices - 1u) / slices : 0u;
-}
-__host__ __device__ inline bool xcd_map_block(const XcdMap &m, uint32_t block, uint32_t *pair, uint32_t *set)
-{
-  uint32_t r = block >> 3;
-  for (uint32_t u = block & 7u; u < m.n_pairs * m.slices; u += 8u) {
-    const uint32_t p = u / m.slices, sl = u % m.slices, len = slice_len(m.sets[p], m.slices, sl);
-    if (r < len) { *pair = p; *set = sl + r * m.slices; return true; }
-    r -= len;
-  }
-  return false;
-}
-
 template <bool FMA, int Q, int W>
 __global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? MVR_CULL_WAVES : 3)))
 nn_cull_kernel(CullBatch batch, XcdMap map, unsigned long long *__restrict__ evals)
@@ -833,17 +817,9 @@ int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2,
     int W = sets >= (size_t)c->n_cu * 40 ? 1 : 2;
     if (c->cull_w == 1 || c->cull_w == 2 || c->cull_w == 4) W = c->cull_w;      // tuning override
     map.n_pairs = (uint32_t)m;
-    uint32_t g = 8u, pm = (uint32_t)m;
-    while (pm % g) g >>= 1;                                    // gcd(pairs, 8)
-    map.slices = 8u / g;
-    if (c->cull_slices == 1 || c->cull_slices == 2 || c->cull_slices == 4 || c->cull_slices == 8) map.slices = (uint32_t)c->cull_slices;   // tuning override (8: no locality, every XCD visits every pair)
-    uint32_t per_xcd = 0;                                      // the longest of the 8 block lists
-    for (uint32_t v = 0; v < 8u; ++v) {
-      uint32_t tot = 0;
-      for (uint32_t u = v; u < map.n_pairs * map.slices; u += 8u) tot += slice_len(map.sets[u / map.slices], map.slices, u % map.slices);
-      per_xcd = std::max(per_xcd, tot);
-    }
-    const dim3 grid(8u * per_xcd);            // one block (W cooperating waves) per query set, dealt as xcd_map_block says
+    unsigned grid_blocks = 0;
+    xcd_map_plan(map, c->cull_slices, &grid_blocks);          // slices = 8 / gcd(pairs, 8) unless forced (8: no locality, every XCD visits every pair)
+    const dim3 grid(grid_blocks);            // one block (W cooperating waves) per query set, dealt as xcd_map_block says
     // region A (evaluations) is only read back by the profiler: per launch at level 1 (cleared here, copied out
     // after the launch), as a running total at level 2 (cleared when profiling starts, read once at the end)
     const bool per_launch = c->prof && !c->prof_totals;

@@ -1,0 +1,541 @@
+// csrc/mvr_grid.hip -- exact 1-NN for queries that come with a BOUND, one thread per query (gfx950).
+//
+// The culled kernel of mvr_cull.hip answers 64 queries at a time against 64-point cells: ~450 distance evaluations
+// per query however tight the query's bound is -- its granularity is the cell.  In an ICP run almost every search
+// after the first pass comes with a bound a fraction of a millimetre wide: the forward search of a pass starts from
+// the distance of its previous match (the clouds move by little between passes), the reverse search of a matched
+// target from its forward distance.  For those the right tool is what the reference gets from its kd-tree
+// (tree_->nearestKSearch inside icp.align, registrator.cpp:569, and determineReciprocalCorrespondences, :502/:649):
+// look at the handful of points inside the ball and nothing else.
+//
+// Structure: a UNIFORM GRID over every point set in its canonical (upload) coordinates -- pose-invariant like the
+// Hilbert ordering, built once per scan (cell ids -> radix sort -> dense cell-start array: O(1) lookup, no hashing) and
+// shared by all posed copies; plus a one-byte-per-cell distance map ("how many cells to the nearest occupied one").
+// Per pass a posed copy only refreshes its coordinates in grid order (one streaming launch for all views).
+// Search: the query is mapped into the target's canonical frame (inverse pose), the cells overlapped by the ball of its
+// bound (plus a margin far above every rounding involved) are walked row by row -- a row of cells along x is ONE
+// contiguous range of the grid-ordered array -- and every candidate is evaluated in the POSED frame with the float
+// formula of all the other search kernels: same d2 bits, lowest ORIGINAL index on ties, so the result is bit-identical
+// to the brute-force and the culled kernels.  A query without any bound (no previous match) first reads the distance
+// map: two thirds of a turntable scan has no counterpart in its neighbour and leaves after one byte.  A query whose ball
+// is WIDE (no bound but close to the target, or a seed that moved far: the first passes) is not walked by one thread --
+// a wave is as slow as its slowest lane and those queries come in clusters -- but flagged for the culled kernel, which
+// then runs over the flagged positions in place (its blocks without a flagged query leave at once).
+// Compiled with -ffp-contract=off.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mvr_internal.h"
+
+namespace mvr {
+
+CellGrid::~CellGrid()
+{
+  for (void *p : {(void *)start, (void *)gperm, (void *)graw, (void *)g2h, (void *)dt}) if (p) (void)hipFree(p);
+}
+
+namespace {
+
+struct GridGeom { float lo[3]; float inv_h; int dim[3]; };
+
+__device__ __forceinline__ int cell_of(float x, float lo, float inv_h, int dim)
+{
+  // monotone in x (float subtract, multiply and floor are monotone): a point inside [a, b] gets a cell inside
+  // [cell_of(a), cell_of(b)] -- what the search's cell range relies on.  Clamped: points ON the upper face.
+  const float f = floorf((x - lo) * inv_h);
+  return (int)fminf(fmaxf(f, 0.f), (float)(dim - 1));
+}
+
+__global__ void cell_id_kernel(const float4 *__restrict__ p, size_t n, GridGeom g, uint32_t *__restrict__ cid, uint32_t *__restrict__ idx)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = p[i];
+  const int x = cell_of(v.x, g.lo[0], g.inv_h, g.dim[0]), y = cell_of(v.y, g.lo[1], g.inv_h, g.dim[1]), z = cell_of(v.z, g.lo[2], g.inv_h, g.dim[2]);
+  cid[i] = (uint32_t)((z * g.dim[1] + y) * g.dim[0] + x);
+  idx[i] = (uint32_t)i;
+}
+
+// distance map, by dilation: dt = 0 on occupied cells; step k marks with k every unmarked cell that has a cell marked
+// < k among its 26 neighbours (Chebyshev distance k).  One launch per step, reading the previous step's array.
+__global__ void dt_init_kernel(const uint32_t *__restrict__ start, size_t cells, uint8_t *__restrict__ dt)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cells) dt[c] = start[c + 1] > start[c] ? 0 : 255;
+}
+__global__ void dt_step_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int nx, int ny, int nz, int step)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= (size_t)nx * ny * nz) return;
+  uint8_t v = in[c];
+  if (v == 255) {
+    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((size_t)nx * ny));
+    bool near = false;
+    for (int dz = -1; dz <= 1 && !near; ++dz)
+      for (int dy = -1; dy <= 1 && !near; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int X = x + dx, Y = y + dy, Z = z + dz;
+          if (X < 0 || Y < 0 || Z < 0 || X >= nx || Y >= ny || Z >= nz) continue;
+          if (in[((size_t)Z * ny + Y) * nx + X] != 255) { near = true; break; }
+        }
+    if (near) v = (uint8_t)step;
+  }
+  out[c] = v;
+}
+
+// start[c] = first grid position whose cell id is >= c (lower bound in the sorted ids); start[cells] = n
+__global__ void cell_start_kernel(const uint32_t *__restrict__ sorted_cid, size_t n, size_t cells, uint32_t *__restrict__ start)
+{
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > cells) return;
+  size_t lo = 0, hi = n;
+  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (sorted_cid[mid] < (uint32_t)c) lo = mid + 1; else hi = mid; }
+  start[c] = (uint32_t)lo;
+}
+
+__global__ void grid_gather_kernel(const float4 *__restrict__ p, const uint32_t *__restrict__ gperm, size_t n, float4 *__restrict__ graw)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t o = gperm[k];
+  float4 v = p[o];
+  v.w = __uint_as_float(o);
+  graw[k] = v;
+}
+
+__global__ void g2h_kernel(const uint32_t *__restrict__ gperm, const uint32_t *__restrict__ inv, size_t n, uint32_t *__restrict__ g2h)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) g2h[k] = inv[gperm[k]];
+}
+
+// posed coordinates in grid order: the SAME function of the same inputs as the posed points themselves
+// (pose_point_f64 of the canonical point), so gsorted[k].xyz == pts[gperm[k]].xyz bit for bit
+struct GridPoseBatch { const float4 *graw[kBatchClouds]; float4 *out[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; };
+__global__ void grid_pose_kernel(GridPoseBatch b)
+{
+  const int cl = blockIdx.y;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= b.n[cl]) return;
+  const float4 p = b.graw[cl][k];
+  float4 v = pose_point_f64(b.T[cl], p);
+  v.w = p.w;
+  b.out[cl][k] = v;
+}
+
+template <bool FMA>
+__device__ __forceinline__ float gdist2(const float4 t, float qx, float qy, float qz)
+{
+  const float dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+  if (FMA) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+constexpr int kGridThreads = 256;
+
+template <bool FMA>
+__global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, XcdMap map, unsigned long long *__restrict__ evals)
+{
+  uint32_t pair = 0, set = 0;
+  if (!xcd_map_block(map, blockIdx.x, &pair, &set)) return;
+  const GridPair &a = batch.p[pair];
+  const float cap2 = batch.cap2;
+  const uint32_t nq = a.qlist ? min(*a.qcount, a.q_count) : a.q_count;
+  const uint32_t pos = set * kGridThreads + threadIdx.x;
+  unsigned long long n_eval = 0;
+  bool went_wide = false;
+  if (pos < nq) {
+    const uint32_t qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;            // position in the query cloud's Hilbert order
+    const float4 q = a.qs[qpos];
+    // the bound: the cap, or a distance within which a point is KNOWN to exist (inclusive)
+    float bound = cap2;
+    bool seeded = false;
+    if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) { bound = __uint_as_float(v); seeded = true; } }
+    if (a.seed_from_keys) {
+      const uint32_t prev = (uint32_t)a.keys[qpos];
+      if (prev < a.nt) { const float d = gdist2<FMA>(a.ts[prev], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }
+    }
+    // the ball in the target's canonical frame.  The mapping itself is done in double; what the margin has to cover is
+    // that both clouds' posed coordinates are FLOAT roundings of the exact motion (half an ulp per coordinate and cloud:
+    // 1e-4 mm at |p| ~ 1e3 mm) and the float cell arithmetic below -- scaled with the coordinates' magnitude
+    const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+    const double qx = q.x, qy = q.y, qz = q.z;
+    const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
+    const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
+    const float rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+    const int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+    const int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+    const int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+    bool worth = true;
+    if (!seeded) {
+      // nothing known: is any target point near at all?  The query's own cell (clamped into the grid) is dt cells from the
+      // nearest occupied one, so every target point is at least (dt - 1) cell edges away along some axis -- plus
+      // however far the query itself lies outside the grid
+      const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
+      const uint32_t d = a.dt[((size_t)cz * a.dim[1] + cy) * a.dim[0] + cx];
+      const float least = (d == 255u ? (float)kGridDtMax : (float)d - 1.f) * a.h;
+      worth = !(least > rad);
+    }
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    // wide balls are not walked here: without a bound they come in clusters (the rim of the overlap) and go to the culled
+    // kernel, which answers 64 neighbouring queries at once; with a bound they are scattered and get a wave each
+    const bool wide = worth && nrows > batch.light_rows;
+    const bool to_cull = wide && a.heavy != nullptr && (!seeded || a.wide_list == nullptr);
+    const bool to_wave = wide && !to_cull && a.wide_list != nullptr;
+    if (a.heavy) a.heavy[a.qlist ? pos : qpos] = to_cull ? 1 : 0;
+    went_wide = to_wave;
+    if (!to_cull && !to_wave) {
+      float bd = bound;                 // candidates beyond the bound cannot be the answer; at the bound they can (inclusive)
+      uint32_t bi = kNone, bk = 0;
+      if (worth) {
+        // rows of cells (x-runs: ONE contiguous range of the grid-ordered array each); the next row's range is requested
+        // while this row's points are evaluated, the points two at a time
+        uint32_t row = (uint32_t)((z0 * a.dim[1] + y0) * a.dim[0]);
+        uint32_t s = a.start[row + (uint32_t)x0], e = a.start[row + (uint32_t)x1 + 1u];
+        for (int it = 0; it < nrows; ++it) {
+          uint32_t s2 = 0, e2 = 0;
+          if (it + 1 < nrows) {
+            const int y = y0 + (it + 1) % ny, z = z0 + (it + 1) / ny;
+            row = (uint32_t)((z * a.dim[1] + y) * a.dim[0]);
+            s2 = a.start[row + (uint32_t)x0]; e2 = a.start[row + (uint32_t)x1 + 1u];
+          }
+          n_eval += e - s;
+          uint32_t k = s;
+          for (; k + 1 < e; k += 2) {
+            const float4 t0 = a.gts[k], t1 = a.gts[k + 1];
+            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
+            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w);
+            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k + 1; }
+          }
+          if (k < e) {
+            const float4 t0 = a.gts[k];
+            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z);
+            const uint32_t o0 = __float_as_uint(t0.w);
+            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+          }
+          s = s2; e = e2;
+        }
+      }
+      const bool found = bi != kNone && bd <= cap2;
+      const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
+      uint32_t low = bi;
+      if (found && (a.key_by_pos || a.mark)) {
+        const uint32_t hp = a.g2h[bk];              // the match's position in its set's Hilbert order
+        if (a.key_by_pos) low = hp;
+        if (a.mark) __hip_atomic_store(&a.mark[hp], __float_as_uint(bd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      a.keys[ord] = found ? (((nnkey_t)__float_as_uint(bd) << 32) | low) : kKeyInit;
+    }
+  }
+  {   // the wave's wide queries: one counter bump per wave, ordinals in lane order
+    const unsigned long long m = __ballot(went_wide);
+    if (m) {
+      const int lane = threadIdx.x & 63;
+      uint32_t base = 0;
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(a.wide_count, (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+      if (went_wide) a.wide_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
+    }
+  }
+  if (evals) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o, 64);
+    if ((threadIdx.x & 63) == 0 && n_eval) {
+      unsigned long long *s = evals + (size_t)((set * 4u + (threadIdx.x >> 6)) & (kEvalShards - 1)) * kEvalStride;
+      atomicAdd(s, n_eval);
+      atomicAdd(s + kEvalRegion, n_eval);
+    }
+  }
+}
+
+// ---- the wide bounded queries: ONE WAVE per query.  The rows of cells its ball overlaps are dealt to the lanes (one
+// contiguous range of the grid-ordered array each), their lengths prefix-summed, and the candidates -- a few hundred
+// for a 4 mm ball -- shared out evenly: lane l takes candidates l, l + 64, ...  (a thread walking them alone would hold
+// its whole wave up: a wave is as slow as its slowest lane).
+constexpr int kWideWaves = 4;      // waves per block
+template <bool FMA>
+__global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+{
+  const GridPair &a = batch.p[blockIdx.y];
+  if (!a.wide_count) return;
+  __shared__ uint32_t row_s[kWideWaves][64], row_off[kWideWaves][65];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t n_wide = *a.wide_count, stride = gridDim.x * kWideWaves;
+  const float cap2 = batch.cap2;
+  unsigned long long n_eval = 0;
+  for (uint32_t i = blockIdx.x * kWideWaves + wv; i < n_wide; i += stride) {
+    const uint32_t pos = a.wide_list[i];
+    const uint32_t qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;
+    const float4 q = a.qs[qpos];
+    float bound = cap2;
+    if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) bound = __uint_as_float(v); }
+    if (a.seed_from_keys) {
+      const uint32_t prev = (uint32_t)a.keys[qpos];
+      if (prev < a.nt) { const float d = gdist2<FMA>(a.ts[prev], q.x, q.y, q.z); if (d <= bound) bound = d; }
+    }
+    const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+    const double qx = q.x, qy = q.y, qz = q.z;
+    const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
+    const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
+    const float rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+    const int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+    const int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+    const int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    nnkey_t best = ((nnkey_t)__float_as_uint(bound) << 32) | kNone;        // (d2 bits, original index): the minimum is the answer, ties to the lowest index
+    uint32_t bk = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+      const int r = r0 + lane;
+      uint32_t s = 0, len = 0;
+      if (r < nrows) {
+        const uint32_t row = (uint32_t)(((z0 + r / ny) * a.dim[1] + (y0 + r % ny)) * a.dim[0]);
+        s = a.start[row + (uint32_t)x0];
+        len = a.start[row + (uint32_t)x1 + 1u] - s;
+      }
+      uint32_t inc = len;                       // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= o) inc += v; }
+      const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+      row_s[wv][lane] = s; row_off[wv][lane] = inc - len;
+      if (lane == 63) row_off[wv][64] = total;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t j = lane; j < total; j += 64) {
+        int lo = 0, hi = 63;                    // the row whose range holds candidate j: last row with off <= j
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (row_off[wv][mid] <= j) lo = mid; else hi = mid - 1; }
+        const uint32_t k = row_s[wv][lo] + (j - row_off[wv][lo]);
+        const float4 t = a.gts[k];
+        const nnkey_t key = ((nnkey_t)__float_as_uint(gdist2<FMA>(t, q.x, q.y, q.z)) << 32) | __float_as_uint(t.w);
+        if (key < best) { best = key; bk = k; }
+      }
+      n_eval += total;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // the wave's answer: the smallest (d2, index); the lane that holds it knows where it sits
+    nnkey_t m = best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const nnkey_t v = (nnkey_t)__shfl_xor((unsigned long long)m, o, 64); m = v < m ? v : m; }
+    const unsigned long long who = __ballot(best == m && (uint32_t)best != kNone);
+    const bool found = (uint32_t)m != kNone && __uint_as_float((uint32_t)(m >> 32)) <= cap2;
+    if (found && who) {
+      const int src = __ffsll((long long)who) - 1;
+      const uint32_t wk = (uint32_t)__shfl((int)bk, src, 64);
+      if (lane == 0) {
+        const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
+        uint32_t low = (uint32_t)m;
+        if (a.key_by_pos || a.mark) {
+          const uint32_t hp = a.g2h[wk];
+          if (a.key_by_pos) low = hp;
+          if (a.mark) __hip_atomic_store(&a.mark[hp], (uint32_t)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a.keys[ord] = (m & 0xFFFFFFFF00000000ull) | low;
+      }
+    } else if (lane == 0) {
+      const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
+      a.keys[ord] = kKeyInit;
+    }
+  }
+  if (evals && lane == 0 && n_eval) {
+    unsigned long long *s = evals + (size_t)((blockIdx.x * kWideWaves + wv) & (kEvalShards - 1)) * kEvalStride;
+    atomicAdd(s, n_eval);
+    atomicAdd(s + kEvalRegion, n_eval);
+  }
+}
+
+}  // namespace
+
+// ---- build: once per point set, from a cloud that holds the set's canonical coordinates
+bool ensure_grid(Ctx *c, Cloud &canon)
+{
+  const size_t n = canon.n;
+  if (!canon.canonical || n == 0 || n > 0xFFFFFFF0ull) return false;
+  if (canon.grid && canon.grid->n == n) return true;
+  canon.grid.reset();
+  auto it = c->grids.find(canon.set_id);
+  if (it != c->grids.end()) { canon.grid = it->second.lock(); if (canon.grid && canon.grid->n == n) return true; canon.grid.reset(); }
+  // bounding box (one small round trip, once per scan): the cell edge and the grid's dimensions come from it
+  float hb[6];
+  if (cloud_bbox(c, canon.pts, n, hb) != MVR_OK) return false;
+  auto g = std::make_shared<CellGrid>();
+  g->n = n;
+  double ext[3];
+  for (int k = 0; k < 3; ++k) { g->lo[k] = hb[k]; ext[k] = std::max(1e-6, (double)hb[3 + k] - (double)hb[k]); }
+  // ~10 points per cell on a SURFACE of about the bounding box's face area (a scan is a sheet, not a volume); never more
+  // than 192 cells per axis / 6 M cells (24 MB of cell starts)
+  const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+  double h = std::sqrt(10.0 * area / (double)n);
+  h = std::max(h, std::max(ext[0], std::max(ext[1], ext[2])) / 192.0);
+  for (;;) {
+    double cells = 1.0;
+    for (int k = 0; k < 3; ++k) { g->dim[k] = (int)std::floor(ext[k] / h) + 1; cells *= g->dim[k]; }
+    if (cells <= 6.0e6) break;
+    h *= 1.25;
+  }
+  g->h = (float)h; g->inv_h = (float)(1.0 / h);
+  const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
+  uint32_t *cid_a = nullptr, *cid_b = nullptr, *idx_a = nullptr;
+  uint8_t *dt_tmp = nullptr;
+  bool ok = hipMalloc(&g->start, (cells + 1) * 4) == hipSuccess && hipMalloc(&g->gperm, n * 4) == hipSuccess &&
+            hipMalloc(&g->graw, n * sizeof(float4)) == hipSuccess && hipMalloc(&g->g2h, n * 4) == hipSuccess &&
+            hipMalloc(&g->dt, cells) == hipSuccess && hipMalloc(&dt_tmp, cells) == hipSuccess && hipMalloc(&cid_a, n * 4) == hipSuccess &&
+            hipMalloc(&cid_b, n * 4) == hipSuccess && hipMalloc(&idx_a, n * 4) == hipSuccess;
+  if (ok) {
+    GridGeom gg;
+    for (int k = 0; k < 3; ++k) { gg.lo[k] = g->lo[k]; gg.dim[k] = g->dim[k]; }
+    gg.inv_h = g->inv_h;
+    const unsigned nb = (unsigned)((n + 255) / 256), cb = (unsigned)((cells + 255) / 256);
+    hipLaunchKernelGGL(cell_id_kernel, dim3(nb), dim3(256), 0, c->stream, canon.pts, n, gg, cid_a, idx_a);
+    int bits = 1;
+    while (((size_t)1 << bits) < cells) ++bits;
+    size_t bytes = 0;
+    ok = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, cid_a, cid_b, idx_a, g->gperm, (int)n, 0, bits, c->stream) == hipSuccess;
+    void *tmp = nullptr;
+    if (ok) ok = hipMalloc(&tmp, bytes + 256) == hipSuccess;
+    if (ok) ok = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, cid_a, cid_b, idx_a, g->gperm, (int)n, 0, bits, c->stream) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(cell_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, cid_b, n, cells, g->start);
+      hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, c->stream, canon.pts, g->gperm, n, g->graw);
+      // distance map: kGridDtMax dilation steps, ping-pong (an even count: the result ends in g->dt)
+      static_assert(kGridDtMax % 2 == 0, "ping-pong ends in dt");
+      hipLaunchKernelGGL(dt_init_kernel, dim3(cb), dim3(256), 0, c->stream, g->start, cells, g->dt);
+      for (int step = 1; step <= kGridDtMax; ++step) {
+        uint8_t *in = (step & 1) ? g->dt : dt_tmp, *out = (step & 1) ? dt_tmp : g->dt;
+        hipLaunchKernelGGL(dt_step_kernel, dim3(cb), dim3(256), 0, c->stream, in, out, g->dim[0], g->dim[1], g->dim[2], step);
+      }
+      ok = hipGetLastError() == hipSuccess;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (tmp) (void)hipFree(tmp);
+  }
+  if (dt_tmp) (void)hipFree(dt_tmp);
+  for (uint32_t *p : {cid_a, cid_b, idx_a}) if (p) (void)hipFree(p);
+  if (!ok) return false;
+  canon.grid = g;
+  for (auto i2 = c->grids.begin(); i2 != c->grids.end();) i2 = i2->second.expired() ? c->grids.erase(i2) : std::next(i2);
+  c->grids[canon.set_id] = g;
+  return true;
+}
+
+// posed copies: coordinates in grid order (and the grid-position -> Hilbert-position map, once per ordering)
+int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
+{
+  for (int base = 0; base < count; base += kBatchClouds) {
+    GridPoseBatch b;
+    const int m = std::min(kBatchClouds, count - base);
+    size_t nmax = 0;
+    int used = 0;
+    for (int k = 0; k < m; ++k) {
+      Cloud *cl = posed[base + k];
+      if (!cl || !cl->grid || !cl->pose_known || cl->gcoords_valid || cl->n == 0 || cl->grid->n != cl->n) continue;
+      if (int rc = ensure(c, cl->gsorted, cl->gsorted_cap, cl->n)) return rc;
+      if (cl->order && cl->grid->built_for != cl->order.get()) {
+        hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h);
+        cl->grid->built_for = cl->order.get();
+      }
+      b.graw[used] = cl->grid->graw; b.out[used] = cl->gsorted; b.n[used] = cl->n;
+      std::memcpy(b.T[used].m, cl->pose, sizeof b.T[used].m);
+      nmax = std::max(nmax, cl->n);
+      cl->gcoords_valid = true;
+      ++used;
+    }
+    if (!used) continue;
+    for (int k = used; k < kBatchClouds; ++k) { b.graw[k] = nullptr; b.out[k] = nullptr; b.n[k] = 0; }
+    ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)nmax * used);
+    hipLaunchKernelGGL(grid_pose_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)used), dim3(256), 0, c->stream, b);
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
+}
+
+GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cloud &t, nnkey_t *keys)
+{
+  GridPair p;
+  const CellGrid &g = *t.grid;
+  p.qs = q.sorted; p.q_begin = (uint32_t)q_begin; p.q_count = (uint32_t)q_count;
+  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h;
+  for (int k = 0; k < 3; ++k) { p.lo[k] = g.lo[k]; p.dim[k] = g.dim[k]; }
+  p.inv_h = g.inv_h; p.h = g.h;
+  // inverse of the pose's affine map x -> A x + t (column-major 4 x 4, column-vector; A is a rotation up to float rounding:
+  // the true inverse of the 3 x 3 by cofactors, in double): r = A^-1 p - A^-1 t
+  const double *T = t.pose;
+  const double A[3][3] = {{T[0], T[4], T[8]}, {T[1], T[5], T[9]}, {T[2], T[6], T[10]}};
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  const double id = 1.0 / det;
+  const double I[3][3] = {{(A[1][1] * A[2][2] - A[1][2] * A[2][1]) * id, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id},
+                          {(A[1][2] * A[2][0] - A[1][0] * A[2][2]) * id, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id},
+                          {(A[1][0] * A[2][1] - A[1][1] * A[2][0]) * id, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id}};
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) p.minv[4 * r + k] = I[r][k];
+    p.minv[4 * r + 3] = -(I[r][0] * T[12] + I[r][1] * T[13] + I[r][2] * T[14]);
+  }
+  p.nt = (uint32_t)t.n;
+  p.keys = keys;
+  return p;
+}
+
+int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma)
+{
+  for (int base = 0; base < n_pairs; base += kGridBatchPairs) {
+    GridBatch batch;
+    XcdMap map;
+    const int m = std::min(kGridBatchPairs, n_pairs - base);
+    size_t total = 0;
+    for (int k = 0; k < kBatchPairs; ++k) map.sets[k] = 0;
+    for (int k = 0; k < kGridBatchPairs; ++k) {
+      batch.p[k] = k < m ? pairs[base + k] : GridPair{};
+      if (k < m && batch.p[k].nt == 0) batch.p[k].q_count = 0;
+      map.sets[k] = k < m ? (uint32_t)(((size_t)batch.p[k].q_count + kGridThreads - 1) / kGridThreads) : 0u;
+      total += map.sets[k];
+    }
+    batch.cap2 = cap2;
+    batch.light_rows = c->grid_light_rows;
+    if (total == 0) continue;
+    map.n_pairs = (uint32_t)m;
+    unsigned grid_blocks = 0;
+    xcd_map_plan(map, c->cull_slices, &grid_blocks);
+    const bool per_launch = c->prof && !c->prof_totals;
+    if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    if (fma) hipLaunchKernelGGL((nn_grid_kernel<true>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals);
+    else hipLaunchKernelGGL((nn_grid_kernel<false>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals);
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
+}
+
+int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma)
+{
+  for (int base = 0; base < n_pairs; base += kGridBatchPairs) {
+    GridBatch batch;
+    const int m = std::min(kGridBatchPairs, n_pairs - base);
+    bool any = false;
+    for (int k = 0; k < kGridBatchPairs; ++k) {
+      batch.p[k] = k < m ? pairs[base + k] : GridPair{};
+      if (k >= m || batch.p[k].nt == 0 || batch.p[k].q_count == 0 || !batch.p[k].wide_list) batch.p[k].wide_count = nullptr;
+      any = any || batch.p[k].wide_count != nullptr;
+    }
+    if (!any) continue;
+    batch.cap2 = cap2;
+    batch.light_rows = c->grid_light_rows;
+    // how many are on the lists is only known on the device: a fixed number of waves per pair strides over its list
+    // (every wave's loop ends at the count: the grid always drains)
+    const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * 8 / (std::max(1, m) * kWideWaves));
+    const bool per_launch = c->prof && !c->prof_totals;
+    if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    if (fma) hipLaunchKernelGGL((nn_grid_wide_kernel<true>), dim3(blocks_x, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals);
+    else hipLaunchKernelGGL((nn_grid_wide_kernel<false>), dim3(blocks_x, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals);
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
+}
+
+}  // namespace mvr

@@ -285,7 +285,7 @@ __global__ void seed_bounds_kernel(const nnkey_t *__restrict__ keys, const uint3
   const uint32_t j = (uint32_t)key;
   if (j == kNone) return;
   if ((double)__uint_as_float((uint32_t)(key >> 32)) > max2) return;
-  __atomic_store_n(&bound[tinv[j]], (uint32_t)(key >> 32), __ATOMIC_RELAXED);      // any match's distance will do (see flag_matched_batch_kernel)
+  __hip_atomic_store(&bound[tinv[j]], (uint32_t)(key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // any match's distance will do (see flag_matched_batch_kernel)
 }
 
 __global__ void flag_matched_batch_kernel(GlueBatch b)
@@ -306,7 +306,7 @@ __global__ void flag_matched_batch_kernel(GlueBatch b)
     // ANY matching source's distance is a valid start bound, so the writers are not ordered: a relaxed store, last
     // one wins (an atomic min per match cost 40 us per ring step and pruned 0.3 % more).  Which one wins only moves
     // the amount of pruning from run to run, never a result.
-    __atomic_store_n(&a.bound[tpos], (uint32_t)(key >> 32), __ATOMIC_RELAXED);
+    __hip_atomic_store(&a.bound[tpos], (uint32_t)(key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else a.flags[tpos] = 1;
 }
 
@@ -398,6 +398,7 @@ void new_point_set(Ctx *c, Cloud &cl)
 {
   cl.set_id = c->next_set_id++;
   cl.order.reset();
+  cl.grid.reset(); cl.canonical = true; cl.pose_known = false;        // its points, as they are now, DEFINE the new set: canonical coordinates
   cl.stale_coords();
 }
 
@@ -410,7 +411,21 @@ void inherit_point_set(Cloud &dst, const Cloud &src)
   dst.set_id = src.set_id;
   if (src.order) dst.order = src.order;
   else if (!same) dst.order.reset();
+  dst.grid.reset(); dst.canonical = false; dst.pose_known = false;      // (the callers that know the pose say so afterwards)
   dst.stale_coords();
+}
+
+int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6])
+{
+  if (n == 0) return MVR_E_ARG;
+  if (int rc = ensure(c, c->partials, c->partials_cap, (size_t)1024 * 32)) return rc;
+  const int bb = (int)std::min<size_t>(256, (n + 255) / 256);
+  float *part = reinterpret_cast<float *>(c->partials);
+  hipLaunchKernelGGL(bbox_partial_kernel, dim3(bb), dim3(256), 0, c->stream, pts, n, part);
+  hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, c->stream, part, bb, c->bbox);
+  MVR_HIP_TRY(c, hipMemcpyAsync(out, c->bbox, 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MVR_OK;
 }
 
 bool extend_point_set(Ctx *c, Cloud &dst, size_t old_n, const Cloud &src)

@@ -40,6 +40,25 @@ struct Order {
   ~Order();
 };
 
+// Uniform grid over a point SET in its CANONICAL coordinates (the coordinates it was uploaded with): like the ordering
+// it belongs to the set, is built once per scan and shared by every posed copy -- a rigid motion moves the points, not
+// their cells.  A search in a posed copy maps the query into the canonical frame (inverse of the copy's pose), walks the
+// cells its search ball overlaps, and evaluates the candidates in the POSED frame (same float arithmetic as every other
+// search kernel: bit-identical distances).  See mvr_grid.hip.
+struct CellGrid {
+  size_t n = 0;
+  float lo[3] = {0, 0, 0};
+  float h = 1.f, inv_h = 1.f;            // cell edge
+  int dim[3] = {1, 1, 1};                // cells per axis; cell id = (z * dim[1] + y) * dim[0] + x
+  uint32_t *start = nullptr;             // [cells + 1] first grid position of every cell (points sorted by cell id)
+  uint32_t *gperm = nullptr;             // [n] grid position -> original index
+  float4 *graw = nullptr;                // [n] canonical coordinates in grid order, w = bits(original index)
+  uint32_t *g2h = nullptr;               // [n] grid position -> position in the set's Hilbert ordering (what the fused pass's keys carry)
+  uint8_t *dt = nullptr;                 // [cells] Chebyshev distance, in cells, to the nearest occupied cell (0 = occupied, 255 = farther than kGridDtMax): "is there any point near here at all" in ONE byte
+  const Order *built_for = nullptr;      // the ordering g2h refers to
+  ~CellGrid();
+};
+
 // A cloud is an array of float4 {x,y,z,1}: the same 16-byte record as
 // pcl::PointXYZ (mvr/include/types.h:14), so a host upload is one memcpy and
 // every lane moves one point with a single 16-byte access (dwordx4).
@@ -64,11 +83,18 @@ struct Cloud {
   float4 *sbox = nullptr;              // [ceil(tiles / 64)][lo, hi]: AABBs of 64 consecutive tiles
   bool coords_valid = false;           // sorted[] / tlo / thi / cbox match pts[]
   size_t fresh_tiles = 0;              // with !coords_valid: that many LEADING tiles of sorted[] / boxes are still current (a cloud that only grew at its end: mvr_cloud_append with an extended ordering); any other change of the coordinates resets it
-  void stale_coords() { coords_valid = false; fresh_tiles = 0; }
+  void stale_coords() { coords_valid = false; fresh_tiles = 0; gcoords_valid = false; }
   // optional unit normals {nx,ny,nz,0} (point-to-plane extension, K10)
   float4 *nrm = nullptr; size_t nrm_cap = 0;
   bool has_normals = false;
   std::vector<Seg> segs;               // global numbering of a shard (target sharding over ranks)
+  // pose bookkeeping for the grid search: `canonical` = these ARE the set's upload coordinates; otherwise, when
+  // pose_known, pts = pose * (canonical coordinates of the set) exactly as mvr_cloud_transform computes it
+  bool canonical = false, pose_known = false;
+  double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::shared_ptr<CellGrid> grid;          // the set's grid (shared)
+  float4 *gsorted = nullptr; size_t gsorted_cap = 0;      // posed coordinates in grid order, w = bits(original index)
+  bool gcoords_valid = false;          // gsorted matches pts
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;      // "no neighbour" index
@@ -110,6 +136,9 @@ struct Ctx {
   Cloud slots[MVR_MAX_SLOTS + 2];          // +2 internal scratch clouds
   uint64_t next_set_id = 1;
   std::map<uint64_t, std::weak_ptr<Order> > orders;   // set_id -> ordering (shared between posed copies)
+  std::map<uint64_t, std::weak_ptr<CellGrid> > grids;     // set_id -> uniform grid (shared between posed copies)
+  int grid_light_rows = 4;                            // grid search (default = kGridLightRows): rows of cells a thread walks itself before handing the query to the culled kernel
+  int ring_search = 1;                                // fused pass: 1 = seeded searches walk the uniform grid (thread per query), 0 = always the culled kernel
   std::shared_ptr<OrderPool> order_pool = std::make_shared<OrderPool>();
   // per-pair work buffers (grown on demand)
   nnkey_t *keys = nullptr;   size_t keys_cap = 0;     // [Ns] forward NN keys (by original source index)
@@ -149,6 +178,10 @@ struct Ctx {
   // workspace of the fused batch (culled mode): forward keys of all pairs, reverse keys + flags, per-pair partial rows
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
+  uint32_t *bwide = nullptr; size_t bwide_cap = 0;       // [sources + targets of all pairs] grid search: ordinals of the wide bounded queries
+  int grid_wide = 1;                                     // 1: wide BOUNDED queries of the grid search get a wave each (0: flagged for the culled kernel like the unbounded ones)
+  uint32_t *bwide_count = nullptr;                       // [2 * kBatchPairs ...] their counts (zeroed by the pass's moments launch)
+  uint8_t *bheavy = nullptr; size_t bheavy_cap = 0;      // [sources of all pairs] grid search: queries left to the culled kernel (wide balls)
   uint32_t *bbound = nullptr; size_t bbound_cap = 0;     // [targets of all pairs] bits of the forward d2 of a source that matched the target (~0: not matched)
   bool bbound_clean = false;                             // bbound[] is all ~0 (the moments launch of a pass restores what its forward launch marked)
   uint32_t *blist = nullptr; size_t blist_cap = 0;
@@ -281,7 +314,74 @@ struct CullPair {
 };
 struct CullBatch { CullPair p[kBatchPairs]; float cap2; };
 CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys);
+// block -> (pair, query set) of a fused launch, XCD-aware (see mvr_cull.hip: nn_cull_kernel)
+struct XcdMap { uint32_t sets[kBatchPairs]; uint32_t n_pairs, slices; };
+__host__ __device__ inline uint32_t slice_len(uint32_t sets, uint32_t slices, uint32_t slice)
+{
+  return sets > slice ? (sets - slice + slices - 1u) / slices : 0u;
+}
+__host__ __device__ inline bool xcd_map_block(const XcdMap &m, uint32_t block, uint32_t *pair, uint32_t *set)
+{
+  uint32_t r = block >> 3;
+  for (uint32_t u = block & 7u; u < m.n_pairs * m.slices; u += 8u) {
+    const uint32_t p = u / m.slices, sl = u % m.slices, len = slice_len(m.sets[p], m.slices, sl);
+    if (r < len) { *pair = p; *set = sl + r * m.slices; return true; }
+    r -= len;
+  }
+  return false;
+}
+
+inline void xcd_map_plan(XcdMap &map, int forced_slices, unsigned *grid_blocks)
+{
+  uint32_t g = 8u;
+  while (map.n_pairs % g) g >>= 1;                            // gcd(pairs, 8)
+  map.slices = 8u / g;
+  if (forced_slices == 1 || forced_slices == 2 || forced_slices == 4 || forced_slices == 8) map.slices = (uint32_t)forced_slices;
+  uint32_t per_xcd = 0;                                       // the longest of the 8 block lists
+  for (uint32_t v = 0; v < 8u; ++v) {
+    uint32_t tot = 0;
+    for (uint32_t u = v; u < map.n_pairs * map.slices; u += 8u) tot += slice_len(map.sets[u / map.slices], map.slices, u % map.slices);
+    per_xcd = per_xcd > tot ? per_xcd : tot;
+  }
+  *grid_blocks = 8u * per_xcd;
+}
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);
+// ---- grid search (mvr_grid.hip): exact 1-NN of seeded / bounded queries, one thread per query
+struct GridPair {
+  const float4 *qs = nullptr;                 // queries: a Hilbert-ordered posed cloud (w = original index)
+  const uint32_t *qlist = nullptr, *qcount = nullptr;     // optional: compacted query positions + their device count (key slot = list position)
+  uint32_t q_begin = 0, q_count = 0;
+  const float4 *gts = nullptr;                // target: posed coordinates in GRID order (w = original index)
+  const float4 *ts = nullptr;                 // target in Hilbert order (only to price the seed: the previous match's position)
+  const uint32_t *start = nullptr, *g2h = nullptr;
+  const uint8_t *dt = nullptr;
+  float lo[3] = {0, 0, 0}, inv_h = 1.f, h = 1.f;
+  int dim[3] = {1, 1, 1};
+  uint8_t *heavy = nullptr;                   // optional, by query position (by LIST position with qlist): a query whose ball spans more than `light_rows` rows of cells is NOT answered here but flagged (1, else 0) for the culled kernel, which is built for wide searches
+  double minv[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};     // posed frame -> canonical frame of the target: r = minv (3 x 4, row-major) * (p, 1)
+  uint32_t nt = 0;
+  nnkey_t *keys = nullptr;
+  const uint32_t *qbound = nullptr;           // optional start bounds by query position (bits of a d2; ~0 = none)
+  uint32_t *mark = nullptr;                   // optional: start bounds of the reverse searches, by the match's Hilbert position
+  uint32_t key_by_pos = 0, seed_from_keys = 0;
+  // a BOUNDED query whose ball is wide (scattered among the others: a match that moved far, a long correspondence) is
+  // neither walked by its own thread (the wave would wait for it) nor flagged for the culled kernel (one such query
+  // per 64 would wake every block): its ordinal is appended here and a second launch gives each of them a whole wave
+  uint32_t *wide_list = nullptr, *wide_count = nullptr;
+};
+constexpr int kGridBatchPairs = 12;
+constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
+constexpr int kGridDtMax = 12;        // dilation steps of the distance map
+constexpr int kGridLightRows = 4;     // default number of rows of cells (x-runs) a thread walks by itself (2 x 2: a ball up to half a cell edge in radius); wider balls go to the culled kernel
+struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; };
+int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
+int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the queries the first launch put on the wide lists
+// the set's grid (built from `canon`, a cloud holding the set's canonical coordinates) and the posed copy's grid-ordered
+// coordinates; false = not available (the caller uses the culled kernel)
+int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo xyz, hi xyz} on the host (synchronises the stream)
+bool ensure_grid(Ctx *c, Cloud &canon);
+int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
+GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cloud &t, nnkey_t *keys);
 int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
                    bool fma, nnkey_t *keys);
 // one scan pair of a batched global pass (mvr_pair_moments2_batch, culled mode): everything the glue and the
@@ -299,6 +399,7 @@ struct GluePair {
   double *partials = nullptr, *out = nullptr;             // [blocks][29] scratch, 32 doubles result
   unsigned long long q_begin = 0, q_count = 0;
   int blocks = 0, by_pos = 0;
+  uint32_t *zero_a = nullptr, *zero_b = nullptr;          // optional: two device words the moments launch resets to 0 (the grid search's wide-list counters of this pair)
 };
 struct GlueBatch { GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal; };
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);

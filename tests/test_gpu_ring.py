@@ -123,6 +123,40 @@ def test_batched_pairs_equal_single_calls(gpu, mvr, streams):
         gpu.tune(pair_streams=6, pair_fused=1, pair_groups=2)
 
 
+def test_grid_search_equals_culled_search_over_passes(mvr, orc):
+    """The fused pass answers its BOUNDED queries (forward searches seeded by the previous pass's matches, all reverse
+    searches) with the thread-per-query grid search (mvr_grid.hip) and the rest with the culled kernel: same edge
+    tables, same poses, bit for bit, as with the culled kernel alone -- over several passes from the prior (so that
+    unseeded, freshly seeded and well seeded passes all occur), at 12 views x 20k points and 36 x 3k, and the table of
+    the last pass equals the oracle's correspondences."""
+    for V, N, max_d in ((12, 20000, 4.0), (36, 3000, 8.0)):
+        sp = mvr.synth_params(V, 3)
+        scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+        piv, ax = mvr.synth_prior(sp)
+        poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+        origin = np.array(sp.pivot)
+        edges = [(i, (i + 1) % V) for i in range(V)]
+        runs = []
+        for mode in (0, 1):
+            with mvr.Context(0) as ctx:
+                ctx.tune(ring_search=mode)
+                for v in range(V):
+                    ctx.upload(V + v, scans[v])
+                poses, log = [p.copy() for p in poses0], []
+                for _ in range(5):
+                    poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin)
+                    log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+                runs.append(log)
+                if mode == 1:
+                    last_in = np.frombuffer(log[-2][0]).reshape(V, 4, 4)          # poses that went INTO the last pass
+                    clouds = [orc.transform_f64(last_in[v], scans[v]) for v in range(V)]
+                    for e in (0, V // 2, V - 1):
+                        cc = orc.correspondences(clouds[edges[e][0]], clouds[edges[e][1]], max_d, kdtree=True)
+                        assert int(info["rows"][e, 0]) == len(cc)
+                        assert abs(info["rows"][e, 31] - float(cc["dist2"].astype(np.float64).sum())) < 1e-9 * max(1.0, info["rows"][e, 31])
+        assert runs[0] == runs[1], (V, N)
+
+
 def test_transform_batch_equals_single_transforms(gpu, mvr):
     """mvr_cloud_transform_batch poses many clouds in one launch, bit for bit like mvr_cloud_transform."""
     g = load_golden("ring_12x2048.npz")
