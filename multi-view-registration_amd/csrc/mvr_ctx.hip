@@ -373,7 +373,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   c->orders.clear(); c->grids.clear();
   if (c->order_pool) c->order_pool->close();          // orderings that outlive the context free their buffers themselves
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_table) (void)hipHostFree(c->h_table);
@@ -867,7 +867,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_wide = c->grid_wide; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_cluster = c->grid_cluster; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -952,9 +952,10 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     if (int rc = ensure(w, w->bheavy, w->bheavy_cap, off_s[n_pairs] + off_t[n_pairs])) return rc;      // forward flags by source position, then reverse flags by list position
     if (int rc = ensure(w, w->bwide, w->bwide_cap, off_s[n_pairs] + off_t[n_pairs])) return rc;        // the lists of wide bounded queries, same layout
     if (!w->bwide_count) {                                                                              // their counters: zero now, put back to zero by every pass's moments launch
-      MVR_HIP_TRY(w, hipMalloc(&w->bwide_count, 2 * kWideCounters * sizeof(uint32_t)));
-      MVR_HIP_TRY(w, hipMemsetAsync(w->bwide_count, 0, 2 * kWideCounters * sizeof(uint32_t), w->stream));
+      MVR_HIP_TRY(w, hipMalloc(&w->bwide_count, 3 * kWideCounters * sizeof(uint32_t)));
+      MVR_HIP_TRY(w, hipMemsetAsync(w->bwide_count, 0, 3 * kWideCounters * sizeof(uint32_t), w->stream));
     }
+    if (int rc = ensure(w, w->bcull_sets, w->bcull_sets_cap, off_s[n_pairs] / 64 + (size_t)n_pairs)) return rc;      // the forward sets that hold a flagged query
     if (n_pairs > kWideCounters) grid_ok = false;
   }
   if (grid_ok) {
@@ -968,6 +969,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       grev[k] = make_grid_pair(t, 0, std::min(qn[k], t.n), s, w->brkeys + off_t[k]);
       grev[k].qlist = rev[k].qlist; grev[k].qcount = rev[k].qcount; grev[k].qbound = rev[k].qbound;
       grev[k].heavy = w->bheavy + off_s[n_pairs] + off_t[k];
+      if (c->cull_list && c->grid_lanes == 1) { gfwd[k].cull_sets = w->bcull_sets + off_s[k] / 64 + (size_t)k; gfwd[k].cull_count = w->bwide_count + 2 * kWideCounters + k; }
       if (c->grid_wide) {
         grev[k].heavy = nullptr;                 // every reverse query has a bound: the wide ones all take the wave-per-query launch
         gfwd[k].wide_list = w->bwide + off_s[k]; gfwd[k].wide_count = w->bwide_count + k;
@@ -980,10 +982,26 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     if (reciprocal) w->bbound_clean = false;        // dirty until this pass's moments launch has put it back
     if (grid_ok && seed) {
       if (int rc = launch_nn_grid_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc;
+      if (c->grid_debug) {          // diagnostics (tune key grid_debug): how many queries left the thread-per-query walk, per pass
+        std::vector<uint32_t> cnt((size_t)kWideCounters); std::vector<uint8_t> hv(off_s[n_pairs]);
+        MVR_HIP_TRY(w, hipStreamSynchronize(w->stream));
+        MVR_HIP_TRY(w, hipMemcpy(cnt.data(), w->bwide_count, kWideCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        MVR_HIP_TRY(w, hipMemcpy(hv.data(), w->bheavy, hv.size(), hipMemcpyDeviceToHost));
+        size_t wide = 0, cull = 0, sets = 0;
+        for (int k = 0; k < n_pairs; ++k) {
+          wide += cnt[k];
+          for (size_t i = 0; i < qn[k]; i += 64) { size_t f = 0; for (size_t j = i; j < std::min(qn[k], i + 64); ++j) f += hv[off_s[k] + j]; cull += f; sets += f != 0; }
+        }
+        std::fprintf(stderr, "[grid] forward: %zu queries, %zu to a wave each, %zu to the culled kernel in %zu sets\n", off_s[n_pairs], wide, cull, sets);
+      }
       if (c->grid_wide) { if (int rc = launch_nn_grid_wide_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc; }
       // ... and the queries it flagged, in place (blocks without a flagged query leave at once)
-      for (int k = 0; k < n_pairs; ++k) fwd[k].qflags = qn[k] ? w->bheavy + off_s[k] : nullptr;
-      if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+      for (int k = 0; k < n_pairs; ++k) {
+        fwd[k].qflags = qn[k] ? w->bheavy + off_s[k] : nullptr;
+        fwd[k].setlist = gfwd[k].cull_sets; fwd[k].setcount = gfwd[k].cull_count;
+      }
+      if (c->cull_list && c->grid_lanes == 1) { if (int rc = launch_nn_cull_list_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc; }
+      else if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
     } else if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
   }
   if (!(phases & 2)) return MVR_OK;
@@ -1005,13 +1023,22 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       g.nt = qn[k] ? t.n : 0;
       g.partials = w->bpartials + off_p[k]; g.out = table + (size_t)k * 32;
       g.q_begin = qb[k]; g.q_count = qn[k]; g.blocks = reduce_blocks_for(c, qn[k]);
-      if (grid_ok && c->grid_wide) { g.zero_a = w->bwide_count + k; g.zero_b = w->bwide_count + kWideCounters + k; }
+      if (grid_ok) { g.zero_a = w->bwide_count + k; g.zero_b = w->bwide_count + kWideCounters + k; g.zero_c = w->bwide_count + 2 * kWideCounters + k; }
     }
     if (recip) {
       if (!c->fused_mark) { if (int rc = launch_flag_matched_batch(w, gb, m)) return rc; }      // (else: marked by the forward launch itself)
       if (int rc = launch_compact_flags_batch(w, gb, m)) return rc;
       if (grid_ok) {
         if (int rc = launch_nn_grid_batch(w, grev.data() + base, m, cap2, fma != 0)) return rc;
+        if (c->grid_debug && c->grid_wide) {
+          std::vector<uint32_t> cnt((size_t)2 * kWideCounters), qc((size_t)n_pairs);
+          MVR_HIP_TRY(w, hipStreamSynchronize(w->stream));
+          MVR_HIP_TRY(w, hipMemcpy(cnt.data(), w->bwide_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+          MVR_HIP_TRY(w, hipMemcpy(qc.data(), counts, qc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+          size_t wide = 0, all = 0;
+          for (int j = 0; j < m; ++j) { wide += cnt[kWideCounters + base + j]; all += qc[base + j]; }
+          std::fprintf(stderr, "[grid] reverse: %zu queries, %zu to a wave each\n", all, wide);
+        }
         if (c->grid_wide) { if (int rc = launch_nn_grid_wide_batch(w, grev.data() + base, m, cap2, fma != 0)) return rc; }
         else
         for (int j = 0; j < m; ++j) rev[base + j].qflags = qn[base + j] ? w->bheavy + off_s[n_pairs] + off_t[base + j] : nullptr;     // the wide ones, by list position
@@ -1435,6 +1462,13 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
   else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;
+  else if (!std::strcmp(key, "grid_debug")) c->grid_debug = value != 0;
+  else if (!std::strcmp(key, "cull_list")) c->cull_list = value != 0;
+  else if (!std::strcmp(key, "cull_list_w")) { if (value != 1 && value != 2 && value != 4) return MVR_E_ARG; c->cull_list_w = value; }
+  else if (!std::strcmp(key, "grid_cluster")) { if (value < 1) return MVR_E_ARG; c->grid_cluster = value; }
+  else if (!std::strcmp(key, "grid_wide_waves")) { if (value < 1 || value > 64) return MVR_E_ARG; c->grid_wide_waves = value; }
+  else if (!std::strcmp(key, "grid_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->grid_lanes = value; }
+  else if (!std::strcmp(key, "grid_cell_points")) { if (value < 1) return MVR_E_ARG; c->grid_cell_points = value; }
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
   else if (!std::strcmp(key, "posed_refresh")) c->posed_refresh = value != 0;
   else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }

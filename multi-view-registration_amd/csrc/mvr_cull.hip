@@ -785,7 +785,52 @@ nn_cull_kernel(CullBatch batch, XcdMap map, unsigned long long *__restrict__ eva
                           a.keys, a.key_by_pos, a.qbound, a.seed_from_keys, a.key_by_pos ? a.mark : nullptr, set, evals);
 }
 
+// The same search for the query sets on a LIST (flagged queries are few and clustered: a block per set of the whole
+// range would start tens of thousands of blocks that leave at once).  How many sets are listed is only known on the
+// device: a fixed number of blocks per pair strides over its list, W waves per set (few sets: latency counts).
+template <bool FMA, int W>
+__global__ void __launch_bounds__(64 * W)
+nn_cull_list_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
+{
+  const CullPair &a = batch.p[blockIdx.y];
+  if (!a.setcount) return;
+  const uint32_t n = *a.setcount;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t set = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.setlist[i]);
+    nn_cull_body<FMA, 1, W>(a.qs, a.q_begin, a.q_count, a.qflags, a.qlist, a.qcount, a.ts, a.nt, a.tlo, a.thi, a.cbox, a.sbox, a.n_tiles, batch.cap2,
+                            a.keys, a.key_by_pos, a.qbound, a.seed_from_keys, a.key_by_pos ? a.mark : nullptr, set, evals);
+    __syncthreads();           // the next set reuses the block's LDS
+  }
+}
+
 }  // namespace
+
+int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma)
+{
+  for (int base = 0; base < n_pairs; base += kBatchPairs) {
+    CullBatch batch;
+    const int m = std::min(kBatchPairs, n_pairs - base);
+    bool any = false;
+    for (int k = 0; k < kBatchPairs; ++k) {
+      batch.p[k] = k < m ? pairs[base + k] : CullPair{};
+      if (k >= m || batch.p[k].nt == 0 || batch.p[k].q_count == 0 || !batch.p[k].setlist || !batch.p[k].qflags) batch.p[k].setcount = nullptr;
+      any = any || batch.p[k].setcount != nullptr;
+    }
+    batch.cap2 = cap2;
+    if (!any) continue;
+    const int W = (c->cull_list_w == 1 || c->cull_list_w == 4) ? c->cull_list_w : 2;
+    const dim3 grid((unsigned)std::max(1, c->n_cu * 8 / std::max(1, m)), (unsigned)m);
+    const bool per_launch = c->prof && !c->prof_totals;
+    if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+#define MVR_LAUNCH_LIST(F, WW) hipLaunchKernelGGL((nn_cull_list_kernel<F, WW>), grid, dim3(64 * WW), 0, c->stream, batch, c->evals)
+    if (fma) { if (W == 1) MVR_LAUNCH_LIST(true, 1); else if (W == 2) MVR_LAUNCH_LIST(true, 2); else MVR_LAUNCH_LIST(true, 4); }
+    else     { if (W == 1) MVR_LAUNCH_LIST(false, 1); else if (W == 2) MVR_LAUNCH_LIST(false, 2); else MVR_LAUNCH_LIST(false, 4); }
+#undef MVR_LAUNCH_LIST
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
+}
 
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma)
 {

@@ -140,17 +140,23 @@ __device__ __forceinline__ float gdist2(const float4 t, float qx, float qy, floa
 
 constexpr int kGridThreads = 256;
 
-template <bool FMA>
+// G lanes share a query: lane `sub` of the group walks rows sub, sub + G, ... of the ball's rows of cells, the group's
+// answers meet in log2(G) shuffles.  (One lane per query leaves a wave waiting for its widest ball -- rows times points
+// of dependent round trips; dealing the rows to G lanes cuts that chain G-fold and the spread between lanes with it.
+// The query, its seed and its cell range are loaded by all G lanes from the same addresses: one request.)
+template <bool FMA, int G>
 __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, XcdMap map, unsigned long long *__restrict__ evals)
 {
+  constexpr uint32_t kPerBlock = kGridThreads / G;
   uint32_t pair = 0, set = 0;
   if (!xcd_map_block(map, blockIdx.x, &pair, &set)) return;
   const GridPair &a = batch.p[pair];
   const float cap2 = batch.cap2;
   const uint32_t nq = a.qlist ? min(*a.qcount, a.q_count) : a.q_count;
-  const uint32_t pos = set * kGridThreads + threadIdx.x;
+  const uint32_t sub = threadIdx.x % G;
+  const uint32_t pos = set * kPerBlock + threadIdx.x / G;
   unsigned long long n_eval = 0;
-  bool went_wide = false;
+  bool went_wide = false, went_cull = false;
   if (pos < nq) {
     const uint32_t qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;            // position in the query cloud's Hilbert order
     const float4 q = a.qs[qpos];
@@ -187,53 +193,69 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     // wide balls are not walked here: without a bound they come in clusters (the rim of the overlap) and go to the culled
     // kernel, which answers 64 neighbouring queries at once; with a bound they are scattered and get a wave each
     const bool wide = worth && nrows > batch.light_rows;
-    const bool to_cull = wide && a.heavy != nullptr && (!seeded || a.wide_list == nullptr);
+    bool to_cull = wide && a.heavy != nullptr && (!seeded || a.wide_list == nullptr);
+    if (G == 1 && a.heavy != nullptr && a.wide_list != nullptr) {
+      // ... unless the wave is full of them (a stretch of rim whose matches lie far: the same 64 queries are one set of the culled kernel)
+      if (__popcll(__ballot(wide)) >= batch.cluster) to_cull = wide;
+    }
     const bool to_wave = wide && !to_cull && a.wide_list != nullptr;
-    if (a.heavy) a.heavy[a.qlist ? pos : qpos] = to_cull ? 1 : 0;
-    went_wide = to_wave;
+    if (a.heavy && sub == 0) a.heavy[a.qlist ? pos : qpos] = to_cull ? 1 : 0;
+    went_wide = to_wave && sub == 0;
+    went_cull = to_cull;
     if (!to_cull && !to_wave) {
       float bd = bound;                 // candidates beyond the bound cannot be the answer; at the bound they can (inclusive)
       uint32_t bi = kNone, bk = 0;
-      if (worth) {
-        // rows of cells (x-runs: ONE contiguous range of the grid-ordered array each); the next row's range is requested
-        // while this row's points are evaluated, the points two at a time
-        uint32_t row = (uint32_t)((z0 * a.dim[1] + y0) * a.dim[0]);
+      if (worth && (int)sub < nrows) {
+        // rows of cells (x-runs: ONE contiguous range of the grid-ordered array each); this lane's next row's range is
+        // requested while this row's points are evaluated, the points four at a time (a short row repeats its last
+        // point: re-evaluating a point changes nothing)
+        uint32_t row = (uint32_t)(((z0 + (int)sub / ny) * a.dim[1] + (y0 + (int)sub % ny)) * a.dim[0]);
         uint32_t s = a.start[row + (uint32_t)x0], e = a.start[row + (uint32_t)x1 + 1u];
-        for (int it = 0; it < nrows; ++it) {
+        for (int it = (int)sub; it < nrows; it += G) {
           uint32_t s2 = 0, e2 = 0;
-          if (it + 1 < nrows) {
-            const int y = y0 + (it + 1) % ny, z = z0 + (it + 1) / ny;
+          if (it + G < nrows) {
+            const int y = y0 + (it + G) % ny, z = z0 + (it + G) / ny;
             row = (uint32_t)((z * a.dim[1] + y) * a.dim[0]);
             s2 = a.start[row + (uint32_t)x0]; e2 = a.start[row + (uint32_t)x1 + 1u];
           }
           n_eval += e - s;
-          uint32_t k = s;
-          for (; k + 1 < e; k += 2) {
-            const float4 t0 = a.gts[k], t1 = a.gts[k + 1];
+          for (uint32_t k = s; k < e; k += 4) {
+            const uint32_t last = e - 1u;
+            const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
+            const float4 t0 = a.gts[k], t1 = a.gts[k1], t2 = a.gts[k2], t3 = a.gts[k3];
             const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
-            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w);
+            const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
+            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
             if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
-            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k + 1; }
-          }
-          if (k < e) {
-            const float4 t0 = a.gts[k];
-            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z);
-            const uint32_t o0 = __float_as_uint(t0.w);
-            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
+            if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; bk = k2; }
+            if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; bk = k3; }
           }
           s = s2; e = e2;
         }
       }
-      const bool found = bi != kNone && bd <= cap2;
-      const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
-      uint32_t low = bi;
-      if (found && (a.key_by_pos || a.mark)) {
-        const uint32_t hp = a.g2h[bk];              // the match's position in its set's Hilbert order
-        if (a.key_by_pos) low = hp;
-        if (a.mark) __hip_atomic_store(&a.mark[hp], __float_as_uint(bd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the group's answer: the smallest (d2, index) of its lanes
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) {
+        const float od = __shfl_xor(bd, o, 64);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o, 64), ok = (uint32_t)__shfl_xor((int)bk, o, 64);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; bk = ok; }
       }
-      a.keys[ord] = found ? (((nnkey_t)__float_as_uint(bd) << 32) | low) : kKeyInit;
+      if (sub == 0) {
+        const bool found = bi != kNone && bd <= cap2;
+        const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
+        uint32_t low = bi;
+        if (found && (a.key_by_pos || a.mark)) {
+          const uint32_t hp = a.g2h[bk];              // the match's position in its set's Hilbert order
+          if (a.key_by_pos) low = hp;
+          if (a.mark) __hip_atomic_store(&a.mark[hp], __float_as_uint(bd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a.keys[ord] = found ? (((nnkey_t)__float_as_uint(bd) << 32) | low) : kKeyInit;
+      }
     }
+  }
+  if (G == 1 && a.cull_sets) {   // a wave = one 64-query set of the culled kernel: listed if any of its queries was flagged
+    if (__ballot(went_cull) != 0ull && (threadIdx.x & 63) == 0) a.cull_sets[atomicAdd(a.cull_count, 1u)] = (set * kPerBlock + threadIdx.x) >> 6;
   }
   {   // the wave's wide queries: one counter bump per wave, ordinals in lane order
     const unsigned long long m = __ballot(went_wide);
@@ -367,15 +389,16 @@ bool ensure_grid(Ctx *c, Cloud &canon)
   g->n = n;
   double ext[3];
   for (int k = 0; k < 3; ++k) { g->lo[k] = hb[k]; ext[k] = std::max(1e-6, (double)hb[3 + k] - (double)hb[k]); }
-  // ~10 points per cell on a SURFACE of about the bounding box's face area (a scan is a sheet, not a volume); never more
-  // than 192 cells per axis / 6 M cells (24 MB of cell starts)
+  // ~grid_cell_points points per cell on a SURFACE of about the bounding box's face area (a scan is a sheet, not a
+  // volume); never more than 512 cells per axis / 32 M cells (128 MB of cell starts, of which only the cells near the
+  // surface are ever read)
   const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
-  double h = std::sqrt(10.0 * area / (double)n);
-  h = std::max(h, std::max(ext[0], std::max(ext[1], ext[2])) / 192.0);
+  double h = std::sqrt((double)std::max(1, c->grid_cell_points) * area / (double)n);
+  h = std::max(h, std::max(ext[0], std::max(ext[1], ext[2])) / 512.0);
   for (;;) {
     double cells = 1.0;
     for (int k = 0; k < 3; ++k) { g->dim[k] = (int)std::floor(ext[k] / h) + 1; cells *= g->dim[k]; }
-    if (cells <= 6.0e6) break;
+    if (cells <= 32.0e6) break;
     h *= 1.25;
   }
   g->h = (float)h; g->inv_h = (float)(1.0 / h);
@@ -487,16 +510,19 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     GridBatch batch;
     XcdMap map;
     const int m = std::min(kGridBatchPairs, n_pairs - base);
+    const int lanes = (c->grid_lanes == 1 || c->grid_lanes == 2 || c->grid_lanes == 8) ? c->grid_lanes : 4;
+    const size_t per_block = (size_t)(kGridThreads / lanes);
     size_t total = 0;
     for (int k = 0; k < kBatchPairs; ++k) map.sets[k] = 0;
     for (int k = 0; k < kGridBatchPairs; ++k) {
       batch.p[k] = k < m ? pairs[base + k] : GridPair{};
       if (k < m && batch.p[k].nt == 0) batch.p[k].q_count = 0;
-      map.sets[k] = k < m ? (uint32_t)(((size_t)batch.p[k].q_count + kGridThreads - 1) / kGridThreads) : 0u;
+      map.sets[k] = k < m ? (uint32_t)(((size_t)batch.p[k].q_count + per_block - 1) / per_block) : 0u;
       total += map.sets[k];
     }
     batch.cap2 = cap2;
     batch.light_rows = c->grid_light_rows;
+    batch.cluster = c->grid_cluster;
     if (total == 0) continue;
     map.n_pairs = (uint32_t)m;
     unsigned grid_blocks = 0;
@@ -504,8 +530,14 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
     ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
-    if (fma) hipLaunchKernelGGL((nn_grid_kernel<true>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals);
-    else hipLaunchKernelGGL((nn_grid_kernel<false>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals);
+#define MVR_GRID_LAUNCH(F, GG) hipLaunchKernelGGL((nn_grid_kernel<F, GG>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals)
+    switch (lanes) {
+      case 1: if (fma) MVR_GRID_LAUNCH(true, 1); else MVR_GRID_LAUNCH(false, 1); break;
+      case 2: if (fma) MVR_GRID_LAUNCH(true, 2); else MVR_GRID_LAUNCH(false, 2); break;
+      case 8: if (fma) MVR_GRID_LAUNCH(true, 8); else MVR_GRID_LAUNCH(false, 8); break;
+      default: if (fma) MVR_GRID_LAUNCH(true, 4); else MVR_GRID_LAUNCH(false, 4); break;
+    }
+#undef MVR_GRID_LAUNCH
     MVR_HIP_TRY(c, hipGetLastError());
   }
   return MVR_OK;
@@ -527,7 +559,7 @@ int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     batch.light_rows = c->grid_light_rows;
     // how many are on the lists is only known on the device: a fixed number of waves per pair strides over its list
     // (every wave's loop ends at the count: the grid always drains)
-    const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * 8 / (std::max(1, m) * kWideWaves));
+    const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * c->grid_wide_waves / (std::max(1, m) * kWideWaves));
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
     ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);

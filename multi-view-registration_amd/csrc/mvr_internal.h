@@ -179,6 +179,14 @@ struct Ctx {
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint32_t *bwide = nullptr; size_t bwide_cap = 0;       // [sources + targets of all pairs] grid search: ordinals of the wide bounded queries
+  int grid_cell_points = 10;                             // points per occupied cell the grid's cell edge aims at (grids built from then on)
+  int grid_lanes = 4;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
+  int grid_cluster = 16;                                 // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
+  int grid_wide_waves = 32;                              // waves per CU of the wave-per-query launch
+  int cull_list = 1;                                     // 1: the grid search lists the query sets it flags and the culled kernel walks that list (0: a block per set, most of which leave at once)
+  uint32_t *bcull_sets = nullptr; size_t bcull_sets_cap = 0;
+  int cull_list_w = 2;                                   // waves per query set of the set-list launch of the culled kernel (1, 2 or 4)
+  int grid_debug = 0;                                    // 1: every fused pass prints how its queries split between the three searches (synchronises: diagnostics only)
   int grid_wide = 1;                                     // 1: wide BOUNDED queries of the grid search get a wave each (0: flagged for the culled kernel like the unbounded ones)
   uint32_t *bwide_count = nullptr;                       // [2 * kBatchPairs ...] their counts (zeroed by the pass's moments launch)
   uint8_t *bheavy = nullptr; size_t bheavy_cap = 0;      // [sources of all pairs] grid search: queries left to the culled kernel (wide balls)
@@ -311,6 +319,7 @@ struct CullPair {
   uint32_t *mark = nullptr;      // optional, with key_by_pos: [nt] start bounds of the reverse searches, by the target's sorted position (all ~0 on entry).  A query that finds a match within the cap stores the bits of its d2 at its match's position -- what a separate "flag the matched targets" launch did by re-reading all the keys.  Any matching source's distance is a valid bound: relaxed stores, last one wins.
   uint32_t key_by_pos = 0;       // plain queries only: key slot = the query's sorted position (coalesced stores) instead of its original index, AND the key's low word = the match's sorted position instead of its original index
   uint32_t seed_from_keys = 0;   // with key_by_pos: keys[] still holds the previous result of the same queries against the same target point set; every search starts from the distance of its previous match
+  const uint32_t *setlist = nullptr, *setcount = nullptr;     // with qflags: the query sets that HOLD a flagged query (written by the launch that set the flags) -- launch_nn_cull_list_batch walks these instead of starting a block per set
 };
 struct CullBatch { CullPair p[kBatchPairs]; float cap2; };
 CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys);
@@ -346,6 +355,7 @@ inline void xcd_map_plan(XcdMap &map, int forced_slices, unsigned *grid_blocks)
   *grid_blocks = 8u * per_xcd;
 }
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);
+int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);     // only the query sets on the pairs' set lists (Q = 1)
 // ---- grid search (mvr_grid.hip): exact 1-NN of seeded / bounded queries, one thread per query
 struct GridPair {
   const float4 *qs = nullptr;                 // queries: a Hilbert-ordered posed cloud (w = original index)
@@ -368,12 +378,13 @@ struct GridPair {
   // neither walked by its own thread (the wave would wait for it) nor flagged for the culled kernel (one such query
   // per 64 would wake every block): its ordinal is appended here and a second launch gives each of them a whole wave
   uint32_t *wide_list = nullptr, *wide_count = nullptr;
+  uint32_t *cull_sets = nullptr, *cull_count = nullptr;      // with heavy, one lane per query: the 64-query sets that hold a flagged query (what launch_nn_cull_list_batch walks)
 };
 constexpr int kGridBatchPairs = 12;
 constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
 constexpr int kGridDtMax = 12;        // dilation steps of the distance map
 constexpr int kGridLightRows = 4;     // default number of rows of cells (x-runs) a thread walks by itself (2 x 2: a ball up to half a cell edge in radius); wider balls go to the culled kernel
-struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; };
+struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the queries the first launch put on the wide lists
 // the set's grid (built from `canon`, a cloud holding the set's canonical coordinates) and the posed copy's grid-ordered
@@ -399,7 +410,7 @@ struct GluePair {
   double *partials = nullptr, *out = nullptr;             // [blocks][29] scratch, 32 doubles result
   unsigned long long q_begin = 0, q_count = 0;
   int blocks = 0, by_pos = 0;
-  uint32_t *zero_a = nullptr, *zero_b = nullptr;          // optional: two device words the moments launch resets to 0 (the grid search's wide-list counters of this pair)
+  uint32_t *zero_a = nullptr, *zero_b = nullptr, *zero_c = nullptr;          // optional: two device words the moments launch resets to 0 (the grid search's wide-list counters of this pair)
 };
 struct GlueBatch { GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal; };
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);

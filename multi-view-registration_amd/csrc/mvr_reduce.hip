@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(kRT) accept_moments2_batch_kernel(GlueBatch b)
   if ((int)blockIdx.x >= a.blocks) return;
   // the start bounds the forward launch marked have been consumed by the reverse launch: back to "no target matched",
   // ready for the next pass's forward launch (nothing in this kernel reads them)
-  if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0u; if (a.zero_b) *a.zero_b = 0u; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0u; if (a.zero_b) *a.zero_b = 0u; if (a.zero_c) *a.zero_c = 0u; }
   if (a.bound && b.reciprocal)
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.nt; i += (unsigned long long)a.blocks * blockDim.x)
       a.bound[i] = 0xFFFFFFFFu;
