@@ -139,6 +139,10 @@ __device__ __forceinline__ float gdist2(const float4 t, float qx, float qy, floa
 }
 
 constexpr int kGridThreads = 256;
+#ifndef MVR_GRID_ROW4
+#define MVR_GRID_ROW4 1
+#endif
+struct __attribute__((packed, aligned(4))) Start4 { uint32_t a, b, c, d; };      // four consecutive cell starts, 4-byte aligned (the array is padded by four entries)
 
 // G lanes share a query: lane `sub` of the group walks rows sub, sub + G, ... of the ball's rows of cells, the group's
 // answers meet in log2(G) shuffles.  (One lane per query leaves a wave waiting for its widest ball -- rows times points
@@ -205,31 +209,62 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     if (!to_cull && !to_wave) {
       float bd = bound;                 // candidates beyond the bound cannot be the answer; at the bound they can (inclusive)
       uint32_t bi = kNone, bk = 0;
-      if (worth && (int)sub < nrows) {
-        // rows of cells (x-runs: ONE contiguous range of the grid-ordered array each); this lane's next row's range is
-        // requested while this row's points are evaluated, the points four at a time (a short row repeats its last
-        // point: re-evaluating a point changes nothing)
-        uint32_t row = (uint32_t)(((z0 + (int)sub / ny) * a.dim[1] + (y0 + (int)sub % ny)) * a.dim[0]);
-        uint32_t s = a.start[row + (uint32_t)x0], e = a.start[row + (uint32_t)x1 + 1u];
-        for (int it = (int)sub; it < nrows; it += G) {
+      if (worth) {
+        // rows of cells (x-runs: ONE contiguous range of the grid-ordered array each); the next row's range is requested
+        // while this row's points are evaluated.
+        // (a row's range = two entries of the cell-start array at most three cells apart in all but the widest balls:
+        // ONE 16-byte load from the first of them brings both)
+        const uint32_t nxm = (uint32_t)(x1 - x0);
+        auto row_range = [&](uint32_t row, uint32_t &s, uint32_t &e) {
+#if MVR_GRID_ROW4
+          const Start4 v = *reinterpret_cast<const Start4 *>(a.start + row + (uint32_t)x0);
+          s = v.a;
+          e = nxm == 0u ? v.b : nxm == 1u ? v.c : v.d;
+          if (nxm > 2u) e = a.start[row + (uint32_t)x1 + 1u];
+#else
+          s = a.start[row + (uint32_t)x0]; e = a.start[row + (uint32_t)x1 + 1u];
+#endif
+        };
+        uint32_t s, e;
+        uint32_t row = (uint32_t)((z0 * a.dim[1] + y0) * a.dim[0]);          // rows in y-major order: the next one is dim[0] further, or at the next z
+        const uint32_t row_step = (uint32_t)a.dim[0], z_step = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
+        int yy = 0;
+        row_range(row, s, e);
+        for (int it = 0; it < nrows; ++it) {
           uint32_t s2 = 0, e2 = 0;
-          if (it + G < nrows) {
-            const int y = y0 + (it + G) % ny, z = z0 + (it + G) / ny;
-            row = (uint32_t)((z * a.dim[1] + y) * a.dim[0]);
-            s2 = a.start[row + (uint32_t)x0]; e2 = a.start[row + (uint32_t)x1 + 1u];
+          if (it + 1 < nrows) {
+            row += row_step;
+            if (++yy == ny) { yy = 0; row += z_step; }
+            row_range(row, s2, e2);
           }
-          n_eval += e - s;
-          for (uint32_t k = s; k < e; k += 4) {
-            const uint32_t last = e - 1u;
-            const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
-            const float4 t0 = a.gts[k], t1 = a.gts[k1], t2 = a.gts[k2], t3 = a.gts[k3];
-            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
-            const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
-            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
-            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
-            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
-            if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; bk = k2; }
-            if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; bk = k3; }
+          if (sub == 0) n_eval += e - s;
+          if (G == 1) {
+            // one lane per query: the points four at a time (a short row repeats its last point: re-evaluating a point
+            // changes nothing)
+            for (uint32_t k = s; k < e; k += 4) {
+              const uint32_t last = e - 1u;
+              const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
+              const float4 t0 = a.gts[k], t1 = a.gts[k1], t2 = a.gts[k2], t3 = a.gts[k3];
+              const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
+              const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
+              const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
+              if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+              if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
+              if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; bk = k2; }
+              if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; bk = k3; }
+            }
+          } else {
+            // G lanes per query: they take CONSECUTIVE points of the row -- one instruction, one cache line per query
+            // (what a gather costs in the L1 is the number of distinct lines its lanes touch, not the bytes per lane:
+            // tools/exp_ta.hip), two rounds in flight
+            for (uint32_t k = s + sub; k < e; k += 2 * G) {
+              const uint32_t k1 = k + G < e ? k + G : k;
+              const float4 t0 = a.gts[k], t1 = a.gts[k1];
+              const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
+              const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w);
+              if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+              if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
+            }
           }
           s = s2; e = e2;
         }
@@ -405,7 +440,7 @@ bool ensure_grid(Ctx *c, Cloud &canon)
   const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
   uint32_t *cid_a = nullptr, *cid_b = nullptr, *idx_a = nullptr;
   uint8_t *dt_tmp = nullptr;
-  bool ok = hipMalloc(&g->start, (cells + 1) * 4) == hipSuccess && hipMalloc(&g->gperm, n * 4) == hipSuccess &&
+  bool ok = hipMalloc(&g->start, (cells + 1 + 4) * 4) == hipSuccess && hipMalloc(&g->gperm, n * 4) == hipSuccess &&
             hipMalloc(&g->graw, n * sizeof(float4)) == hipSuccess && hipMalloc(&g->g2h, n * 4) == hipSuccess &&
             hipMalloc(&g->dt, cells) == hipSuccess && hipMalloc(&dt_tmp, cells) == hipSuccess && hipMalloc(&cid_a, n * 4) == hipSuccess &&
             hipMalloc(&cid_b, n * 4) == hipSuccess && hipMalloc(&idx_a, n * 4) == hipSuccess;

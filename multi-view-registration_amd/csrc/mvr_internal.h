@@ -137,7 +137,7 @@ struct Ctx {
   uint64_t next_set_id = 1;
   std::map<uint64_t, std::weak_ptr<Order> > orders;   // set_id -> ordering (shared between posed copies)
   std::map<uint64_t, std::weak_ptr<CellGrid> > grids;     // set_id -> uniform grid (shared between posed copies)
-  int grid_light_rows = 4;                            // grid search (default = kGridLightRows): rows of cells a thread walks itself before handing the query to the culled kernel
+  int grid_light_rows = 12;                           // grid search (default = kGridLightRows): rows of cells a thread walks itself; wider balls leave for a wave of their own or for the culled kernel
   int ring_search = 1;                                // fused pass: 1 = seeded searches walk the uniform grid (thread per query), 0 = always the culled kernel
   std::shared_ptr<OrderPool> order_pool = std::make_shared<OrderPool>();
   // per-pair work buffers (grown on demand)
@@ -164,7 +164,7 @@ struct Ctx {
   int cull_w = 0;                                     // culled kernel: waves sharing one query set (1, 2, 4; 0 = by launch size)
   int cull_slices = 0;                                // culled kernel: interleaved slices a pair's query sets are dealt to the XCDs in (1, 2, 4, 8; 0 = 8 / gcd(pairs, 8))
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
-  int fused_mark = 1;                                 // fused pass: the forward launch itself records the matched targets' start bounds (0: a separate launch re-reads the keys)
+  int fused_mark = 0;                                 // fused pass: the forward launch itself records the matched targets' start bounds (0: a separate launch re-reads the keys)
   std::vector<unsigned long long> fused_sig;          // what the forward keys in bkeys[] belong to (point-set ids, ranges, offsets): the previous fused pass on this context
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
   // workers: contexts with their own stream and work buffers that BORROW clouds of this
@@ -179,9 +179,9 @@ struct Ctx {
   nnkey_t *bkeys = nullptr; size_t bkeys_cap = 0;
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint32_t *bwide = nullptr; size_t bwide_cap = 0;       // [sources + targets of all pairs] grid search: ordinals of the wide bounded queries
-  int grid_cell_points = 10;                             // points per occupied cell the grid's cell edge aims at (grids built from then on)
-  int grid_lanes = 4;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
-  int grid_cluster = 16;                                 // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
+  int grid_cell_points = 4;                              // points per occupied cell the grid's cell edge aims at (grids built from then on)
+  int grid_lanes = 1;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
+  int grid_cluster = 8;                                  // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
   int grid_wide_waves = 32;                              // waves per CU of the wave-per-query launch
   int cull_list = 1;                                     // 1: the grid search lists the query sets it flags and the culled kernel walks that list (0: a block per set, most of which leave at once)
   uint32_t *bcull_sets = nullptr; size_t bcull_sets_cap = 0;
@@ -383,7 +383,7 @@ struct GridPair {
 constexpr int kGridBatchPairs = 12;
 constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
 constexpr int kGridDtMax = 12;        // dilation steps of the distance map
-constexpr int kGridLightRows = 4;     // default number of rows of cells (x-runs) a thread walks by itself (2 x 2: a ball up to half a cell edge in radius); wider balls go to the culled kernel
+constexpr int kGridLightRows = 12;    // default number of rows of cells (x-runs) a thread walks by itself (measured on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
 struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the queries the first launch put on the wide lists
