@@ -252,7 +252,8 @@ def main():
                                % (V, N, V),
                    "views": V, "points_per_scan": N, "max_distance": args.max_dist, "pairs": V,
                    "dist_mode": "fma" if args.fma else "rounded-per-op (spec)",
-                   "nn_search": "exact, spatially culled (Hilbert tiles)" if culled else "exact, brute force",
+                   "nn_search": ("exact: bounded queries (seeded forward, every reverse search) by a uniform-grid walk, the rest by the spatially culled kernel (Hilbert tiles)"
+                                 if culled else "exact, brute force"),
                    "sharding": "source queries of the %d ring pairs split evenly over %d rank(s)" % (V, world)},
         "accepted_correspondences_per_step": reg.last["n_corr"], "mse": reg.last["mse"],
         "device": name, "n_cu": n_cu,
@@ -315,6 +316,7 @@ def main():
         barrier(); iso_elapsed = time.perf_counter() - ti
         ctx.prof_enable(False)
         iso = dict(nn=ctx.prof_get(mvr.K_NN), rd=ctx.prof_get(mvr.K_REDUCE), gl=ctx.prof_get(mvr.K_GLUE),
+                   grid=ctx.prof_get(mvr.K_NN_GRID), wide=ctx.prof_get(mvr.K_NN_WIDE), xf=ctx.prof_get(mvr.K_XFORM),
                    ms_per_step=1e3 * iso_elapsed / args.steps)
         rd_launches, rd_ms, rd_bytes = iso["rd"]
     # the brute-force kernel (the plain VALU-roofline kernel) on the same pairs: one extra, untimed ring pass
@@ -335,7 +337,38 @@ def main():
                              bev, traffic_of("nn_traffic.json", None))
     kname = "nn_cull_kernel (exact culled 1-NN; one fused launch per direction for all scan pairs of a step)" if culled else "nn_kernel<8,32> (brute-force 1-NN, fwd + reciprocal)"
     ktraffic = traffic_of("nn_cull_traffic.json", "mvr_cull.hip") if culled else traffic_of("nn_traffic.json", None)
-    if iso and iso["nn"][0]:
+    grid_dominant = bool(iso and culled and iso["grid"][0] and iso["grid"][1] >= iso["nn"][1])
+    if grid_dominant:
+        # the fused pass answers its bounded queries (all of them from the second pass on) by the grid search: that
+        # launch is the dominant kernel of a step; the culled kernel keeps the flagged query sets (and the first pass)
+        gl_, gms, gev = iso["grid"]
+        wl_, wms, wev = iso["wide"]
+        cl_, cms, cev = iso["nn"]
+        q_per_launch = V * N * args.steps / gl_ * (1.0 + reg.last["n_corr"] / float(V * N))      # forward: every source; reverse: about one per accepted pair
+        alg_bytes = 32.0 * q_per_launch + 16.0 * gev / gl_                  # query + previous key read, key written; 16 B per candidate point
+        avg_s = gms * 1e-3 / gl_
+        extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; per step one forward "
+                             "launch (all %d x %d source queries) and one reverse launch (the matched targets) for all scan pairs" % (args.steps, V, N),
+                 "ms_per_step_one_stream_profiled": iso["ms_per_step"],
+                 "limiter": "the L1 gather path, not the ALUs: per-lane 16-byte loads of a few candidates each (rocprofv3 --pmc: TA busy 89 % of "
+                            "the launch, 14 distinct cache lines per load instruction; DESIGN.md 4.3) -- `frac` prices the executed evaluations "
+                            "against the FP32 peak as SURVEY 8(d) asks and FALLS as the search gets smarter; the step time is the figure of merit",
+                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gb_per_s": alg_bytes / avg_s / 1e9,
+                 "frac_of_hbm_peak_on_algorithmic_bytes": alg_bytes / avg_s / 1e9 / PEAK_HBM_GBS,
+                 "evals_bruteforce_equivalent_per_step": brute_equiv}
+        if brute_equiv:
+            tot_ms = gms + wms + cms
+            extra["culling_factor"] = brute_equiv / ((gev + wev + cev) / args.steps)
+            extra["bruteforce_equivalent_tflops"] = FLOP_PER_EVAL * brute_equiv / (tot_ms * 1e-3 / args.steps) / 1e12
+        out["roofline"] = nn_roofline("nn_grid_kernel (exact 1-NN of the BOUNDED queries of a fused pass over a pose-invariant cell grid, one thread "
+                                      "per query; forward and reverse launches of all scan pairs)", gl_, gms, gev,
+                                      traffic_of("nn_grid_traffic.json", "mvr_grid.hip"), extra)
+        if wl_:
+            out["roofline_stragglers"] = nn_roofline("nn_grid_wide_kernel + nn_cull_list_kernel (wide bounded queries, a wave each; flagged query sets, "
+                                                     "culled kernel over a set list)", wl_, wms, wev, (None, "not measured"))
+        if cl_:
+            out["roofline_culled"] = nn_roofline(kname, cl_, cms, cev, ktraffic, {"measured": "the culled launches among the same steps (none once every query has a bound)"})
+    elif iso and iso["nn"][0]:
         il, ims, iev = iso["nn"]
         extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; one launch = "
                              "the searches of all %d scan pairs of a step" % (args.steps, V),
@@ -346,7 +379,7 @@ def main():
                 extra["culling_factor"] = brute_equiv / (iev / args.steps)
                 extra["bruteforce_equivalent_tflops"] = FLOP_PER_EVAL * brute_equiv / (ims * 1e-3 / args.steps) / 1e12
         out["roofline"] = nn_roofline(kname, il, ims, iev, ktraffic, extra)
-    if nn_launches:      # the same kernel inside the timed region, overlapped with other pairs' kernels
+    if nn_launches and not grid_dominant:      # the same kernel inside the timed region, overlapped with other pairs' kernels
         r = nn_roofline(kname, nn_launches, nn_ms, nn_evals, ktraffic,
                         {"measured": "timed region (only the NN launches carry HIP events there; evaluations from running totals)"})
         if "roofline" in out:

@@ -362,7 +362,10 @@ void   mvr_mat4f_mul(const float A[16], const float B[16], float C[16]);
 /* per-kernel-family device time measured with HIP events on the ctx stream.
  * family: 0 = nn (brute-force NN, fwd + reciprocal), 1 = reductions (K5/K6/K8),
  * 2 = transform/copy, 3 = glue (mark/compact/weights). */
-enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_COUNT = 4 };
+enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
+       MVR_K_NN_GRID = 4,   /* the grid search of the fused pass: one thread per bounded query (work = point-pair evaluations) */
+       MVR_K_NN_WIDE = 5,   /* its stragglers: wide bounded queries (a wave each) and flagged query sets (culled kernel over a set list) */
+       MVR_K_COUNT = 6 };
 /* knobs of the exact NN search.  "nn_mode": 1 (default) = spatially culled
  * kernel, 0 = brute-force kernel (also MVR_NN_MODE in the environment);
  * brute-force launch shape: "nn_q" (queries per lane: 2,4,6,8), "nn_sub"
@@ -379,7 +382,18 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3, MVR_K_CO
  * launch deals each pair's query sets to the XCDs in that many interleaved slices, so that a pair's target is read
  * through that many of the eight L2s instead of all of them; 8 = every XCD visits every pair; also MVR_CULL_SLICES);
  * "seed_forward" (1, default: when a fused pass searches the very same point sets as the previous one on this context,
- * every forward search starts from the distance of its previous match; also MVR_SEED_FORWARD).
+ * every forward search starts from the distance of its previous match; also MVR_SEED_FORWARD);
+ * "ring_search" (1, default: in a fused pass every query that HAS a bound -- a forward search seeded by its previous
+ * match, every reverse search -- walks a pose-invariant uniform grid over the target, one thread per query; 0: the
+ * culled kernel answers everything; also MVR_RING_SEARCH), with its knobs "grid_cell_points" (points per occupied
+ * cell the cell edge aims at, default 4; applies to grids built afterwards), "grid_light_rows" (rows of cells a thread
+ * walks itself, default 12; wider balls leave the thread-per-query walk), "grid_wide" (1, default: a wide BOUNDED query
+ * gets a wave of its own; 0: flagged for the culled kernel), "grid_cluster" (a wave of the walk with at least this many
+ * wide queries hands them all to the culled kernel, default 8; 65: never), "cull_list" (1, default: the culled kernel
+ * visits only the query sets the walk listed; 0: a block per set), "cull_list_w" (waves per listed set: 1, 2, 4),
+ * "grid_lanes" (lanes sharing a query: 1 (default), 2, 4, 8), "grid_wide_waves" (waves per CU of the wave-per-query
+ * launch), "fused_mark" (1: the forward search records the start bounds of the reverse searches itself; 0, default: a
+ * separate launch re-reads the keys), "grid_debug" (1: every pass prints how its queries split; synchronises).
  * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,
@@ -388,7 +402,7 @@ int  mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset);
 /* per-launch HIP-event timing: 0 off, 1 all kernel families, 2 the NN search kernels only */
 int  mvr_prof_enable(mvr_ctx *ctx, int on);
 int  mvr_prof_reset(mvr_ctx *ctx);
-/* launches, total ms, point-pair evals (nn family) / bytes (others) */
+/* launches, total ms, point-pair evals (nn families) / bytes (others) */
 int  mvr_prof_get(mvr_ctx *ctx, int family, uint64_t *launches, double *ms, double *work);
 
 /* ---- synthetic turntable scans (host only, no GPU needed) --------- */

@@ -61,7 +61,7 @@ MAX_SLOTS = 256
 OK, E_ARG, E_HIP, E_NOCORR, E_NOMEM, E_SINGULAR, E_RCCL = 0, -1, -2, -3, -4, -5, -6
 CONV_STATES = ("NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE",
                "NO_CORRESPONDENCES")
-K_NN, K_REDUCE, K_XFORM, K_GLUE = 0, 1, 2, 3
+K_NN, K_REDUCE, K_XFORM, K_GLUE, K_NN_GRID, K_NN_WIDE = 0, 1, 2, 3, 4, 5
 
 
 class MvrError(RuntimeError):

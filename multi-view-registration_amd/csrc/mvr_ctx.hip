@@ -1535,7 +1535,7 @@ API int mvr_prof_enable(mvr_ctx *ctx, int on)
   Ctx *c = CTX(ctx);
   if (int rc = prof_drain(c)) return rc;                    // settle what the previous mode collected
   c->prof = on != 0;
-  c->prof_mask = (on == 2) ? (1u << MVR_K_NN) : ~0u;       // 2: time the search kernels only (cheapest)
+  c->prof_mask = (on == 2) ? ((1u << MVR_K_NN) | (1u << MVR_K_NN_GRID) | (1u << MVR_K_NN_WIDE)) : ~0u;       // 2: time the search kernels only (cheapest)
   c->prof_totals = on == 2;
   for (Ctx *w : c->workers) { w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals; w->prof_totals = c->prof_totals; }
   return MVR_OK;

@@ -822,7 +822,7 @@ int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float 
     const dim3 grid((unsigned)std::max(1, c->n_cu * 8 / std::max(1, m)), (unsigned)m);
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
-    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    ProfScope ps(c, MVR_K_NN_WIDE, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
 #define MVR_LAUNCH_LIST(F, WW) hipLaunchKernelGGL((nn_cull_list_kernel<F, WW>), grid, dim3(64 * WW), 0, c->stream, batch, c->evals)
     if (fma) { if (W == 1) MVR_LAUNCH_LIST(true, 1); else if (W == 2) MVR_LAUNCH_LIST(true, 2); else MVR_LAUNCH_LIST(true, 4); }
     else     { if (W == 1) MVR_LAUNCH_LIST(false, 1); else if (W == 2) MVR_LAUNCH_LIST(false, 2); else MVR_LAUNCH_LIST(false, 4); }

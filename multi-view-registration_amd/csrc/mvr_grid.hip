@@ -564,7 +564,7 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     xcd_map_plan(map, c->cull_slices, &grid_blocks);
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
-    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    ProfScope ps(c, MVR_K_NN_GRID, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
 #define MVR_GRID_LAUNCH(F, GG) hipLaunchKernelGGL((nn_grid_kernel<F, GG>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals)
     switch (lanes) {
       case 1: if (fma) MVR_GRID_LAUNCH(true, 1); else MVR_GRID_LAUNCH(false, 1); break;
@@ -597,7 +597,7 @@ int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * c->grid_wide_waves / (std::max(1, m) * kWideWaves));
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
-    ProfScope ps(c, MVR_K_NN, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    ProfScope ps(c, MVR_K_NN_WIDE, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
     if (fma) hipLaunchKernelGGL((nn_grid_wide_kernel<true>), dim3(blocks_x, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals);
     else hipLaunchKernelGGL((nn_grid_wide_kernel<false>), dim3(blocks_x, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals);
     MVR_HIP_TRY(c, hipGetLastError());

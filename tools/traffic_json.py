@@ -7,16 +7,20 @@ kernel source measured."""
 import csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
-V, N, STEPS, WARM = 12, 200000, 10, 2
+GRID = len(sys.argv) > 2 and sys.argv[2] == "grid"        # the grid-search launches (nn_grid_kernel) instead of the culled ones
+V, N, STEPS, WARM = 12, 200000, 10, (25 if GRID else 2)
+NAME = "nn_grid_kernel" if GRID else "nn_cull_kernel"
 
 
 def per_dispatch(counter):
     rows = {}
     for f in glob.glob(os.path.join(d, counter, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "nn_cull" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if NAME in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 rows[int(r["Dispatch_Id"])] = rows.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     vals = [rows[k] for k in sorted(rows)]
+    if GRID:
+        return vals[-2 * STEPS:]              # the first pass of all takes the culled kernel; the timed steps are the last ones
     return vals[2 * max(WARM, 1):]            # forward + reverse per step; the warm-up steps come first
 
 
@@ -31,9 +35,15 @@ m = probe["n_corr"] / V                      # accepted pairs per scan pair ~ di
 # keys written + start bounds preset; reverse = matched targets (gathered 16 B) + source cloud + bounds + keys
 alg_fwd = V * (16 * N + 16 * N * (1 + 2 / 64.0) + 8 * N + 4 * N)
 alg_rev = V * (16 * m + 4 * m + 4 * m + 16 * N * (1 + 2 / 64.0) + 8 * m)
-src = os.path.join(ROOT, "multi-view-registration_amd", "csrc", "mvr_cull.hip")
+src = os.path.join(ROOT, "multi-view-registration_amd", "csrc", "mvr_grid.hip" if GRID else "mvr_cull.hip")
+if GRID:
+    # the grid walk: query (16 B) + previous key or start bound (8 B) + key written (8 B) per query, the posed target once
+    # (16 B per point, grid order) -- the candidates a query evaluates are that same target array, re-read through the caches
+    alg_fwd = V * (32 * N + 16 * N)
+    alg_rev = V * (32 * m + 4 * m + 16 * N)
 out = {
-    "kernel": "nn_cull_kernel<false,1,1> (exact culled NN, fused launch over the %d scan pairs of a ring step)" % V,
+    "kernel": ("nn_grid_kernel<false,1> (exact grid walk of the bounded queries, fused launch over the %d scan pairs of a ring step)" if GRID else
+               "nn_cull_kernel<false,1,1> (exact culled NN, fused launch over the %d scan pairs of a ring step)") % V,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/step_probe.py %d %d %d %d, MVR_PAIR_GROUPS=1 "
               "(tools/measure_traffic.sh); mean over the %d timed steps" % (V, N, STEPS, WARM, STEPS),
     "fetch_size_kb_forward": ff, "fetch_size_kb_reverse": fr, "write_size_kb_forward": wf, "write_size_kb_reverse": wr,
