@@ -259,6 +259,11 @@ int  mvr_fitness(mvr_ctx *ctx, int input_slot, int tgt_slot, const float T[16],
 int  mvr_lum_edge_from_moments(const mvr_pair_moments2_t *m2, const double pose_s[6],
                                const double pose_t[6], double MM[36], double MZ[6],
                                double *ss);
+/* The same for FOUR edges in one pass (one per AVX2 lane; what mvr_lum_compute runs its edges through): m2[4],
+ * pose_s / pose_t [4][6], MM [4][36], MZ [4][6], ss [4].  Bit-identical to four calls of the function above;
+ * MVR_E_NOCORR (outputs untouched) when a lane needs one of its special paths (n < 3, an unsafe Cholesky pivot). */
+int  mvr_lum_edge_from_moments_x4(const mvr_pair_moments2_t *m2, const double *pose_s, const double *pose_t,
+                                  double *MM, double *MZ, double *ss);
 /* LUM::compute on n vertices / ne edges given per-edge moments; poses n*6
  * in/out, vertex 0 fixed.  Returns iterations done in *iters. */
 int  mvr_lum_compute(int n, int ne, const int *edge_src, const int *edge_tgt,

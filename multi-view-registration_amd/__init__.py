@@ -149,6 +149,7 @@ SIGNATURES = {
                                 C.POINTER(IcpStats)]),
     "mvr_fitness": (C.c_int, [_vp, C.c_int, C.c_int, _fp, C.c_double, C.c_int, _dp]),
     "mvr_lum_edge_from_moments": (C.c_int, [C.POINTER(PairMoments2), _dp, _dp, _dp, _dp, _dp]),
+    "mvr_lum_edge_from_moments_x4": (C.c_int, [C.POINTER(PairMoments2), _dp, _dp, _dp, _dp, _dp]),
     "mvr_lum_compute": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(PairMoments2), C.c_int, C.c_double, _dp,
                                   C.POINTER(C.c_int)]),
@@ -326,6 +327,15 @@ def lum_edge_from_moments(m2: PairMoments2, pose_s, pose_t):
     rc = _lib.mvr_lum_edge_from_moments(C.byref(m2), _p(ps, C.c_double), _p(pt, C.c_double),
                                         _p(MM, C.c_double), _p(MZ, C.c_double), C.byref(ss))
     return rc, MM.reshape(6, 6), MZ, ss.value
+
+
+def lum_edge_from_moments_x4(m2s, poses_s, poses_t):
+    """Four edges through the AVX2 pass of LUM::computeEdge: (rc, MM[4,6,6], MZ[4,6], ss[4])."""
+    arr = (PairMoments2 * 4)(*m2s)
+    ps, pt = np.ascontiguousarray(poses_s, np.float64).reshape(4, 6), np.ascontiguousarray(poses_t, np.float64).reshape(4, 6)
+    MM, MZ, ss = np.empty((4, 36)), np.empty((4, 6)), np.empty(4)
+    rc = _lib.mvr_lum_edge_from_moments_x4(arr, _p(ps, C.c_double), _p(pt, C.c_double), _p(MM, C.c_double), _p(MZ, C.c_double), _p(ss, C.c_double))
+    return rc, MM.reshape(4, 6, 6), MZ, ss
 
 
 _edge_cache = {}

@@ -459,6 +459,149 @@ static int lum_edge_from_moments_T(const mvr_pair_moments2_t *m2, const double T
   return MVR_OK;
 }
 
+// ---- the same computeEdge for FOUR edges at once (one edge per AVX2 lane).  LUM::compute spends most of an iteration
+// in the 12 (or 36) edges' small dense algebra -- a dozen 3 x 3 products and a 6 x 6 Cholesky each, all of it one long
+// dependency chain per edge; four independent edges side by side fill the chain's bubbles.  Every lane executes exactly
+// the operations of lum_edge_from_moments_T in the same order (IEEE add / mul / div / sqrt per lane, no contraction):
+// the results are bit-identical to the scalar function, which tests/test_host.py asserts.  A group in which any lane
+// needs one of the scalar function's special paths (fewer than 3 pairs, an unsafe Cholesky pivot) is recomputed by it.
+namespace {
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef long v4i __attribute__((ext_vector_type(4)));
+inline v4d vsplat(double x) { return v4d{x, x, x, x}; }
+inline v4d vsqrt(v4d x) { return __builtin_elementwise_sqrt(x); }
+inline v4d vabs(v4d x) { return __builtin_elementwise_abs(x); }
+inline v4d vmax(v4d a, v4d b) { const v4i m = a < b; return v4d{m[0] ? b[0] : a[0], m[1] ? b[1] : a[1], m[2] ? b[2] : a[2], m[3] ? b[3] : a[3]}; }      // std::max(a, b): (a < b) ? b : a
+struct M3v { v4d a[3][3]; v4d &operator()(int r, int c) { return a[r][c]; } const v4d &operator()(int r, int c) const { return a[r][c]; } };
+inline M3v vzero3() { M3v m; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m(r, c) = vsplat(0.0); return m; }
+inline M3v vmul(const M3v &A, const M3v &B)
+{
+  M3v C = vzero3();
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) C(r, c) += A(r, k) * B(k, c);
+  return C;
+}
+inline M3v vtranspose(const M3v &A) { M3v T; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T(r, c) = A(c, r); return T; }
+inline M3v vadd(const M3v &A, const M3v &B) { M3v C; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C(r, c) = A(r, c) + vsplat(1.0) * B(r, c); return C; }
+inline M3v vadd_s(const M3v &A, const M3v &B, v4d sb) { M3v C; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C(r, c) = A(r, c) + sb * B(r, c); return C; }
+inline M3v vouter(const v4d u[3], const v4d v[3]) { M3v C; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C(r, c) = u[r] * v[c]; return C; }
+inline void vmulv(const M3v &A, const v4d v[3], v4d out[3]) { for (int r = 0; r < 3; ++r) out[r] = A(r, 0) * v[0] + A(r, 1) * v[1] + A(r, 2) * v[2]; }
+inline M3v vsym6(const v4d s[6]) { M3v m; m(0, 0) = s[0]; m(0, 1) = m(1, 0) = s[1]; m(0, 2) = m(2, 0) = s[2]; m(1, 1) = s[3]; m(1, 2) = m(2, 1) = s[4]; m(2, 2) = s[5]; return m; }
+
+// solve6_spd, four systems at once; false if any lane's pivot is not safely positive (the caller falls back)
+inline bool solve6_spd_x4(const v4d A[36], const v4d b[6], v4d x[6])
+{
+  v4d L[6][6], y[6];
+  v4d amax = vsplat(0.0);
+  for (int k = 0; k < 6; ++k) amax = vmax(amax, vabs(A[7 * k]));
+  for (int j = 0; j < 6; ++j) {
+    v4d d = A[7 * j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    const v4i okm = d > vsplat(1e-13) * amax;
+    if (!(okm[0] && okm[1] && okm[2] && okm[3])) return false;
+    const v4d ljj = vsqrt(d), inv = vsplat(1.0) / ljj;
+    L[j][j] = ljj;
+    for (int i = j + 1; i < 6; ++i) {
+      v4d v = A[6 * i + j];
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
+  }
+  for (int i = 0; i < 6; ++i) { v4d v = b[i]; for (int k = 0; k < i; ++k) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
+  for (int i = 5; i >= 0; --i) { v4d v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k]; x[i] = v / L[i][i]; }
+  return true;
+}
+
+// m2 / Ts / Tt: four edges (lane l = edge l of the group); outputs row-major per lane.  false: use the scalar function.
+bool lum_edge_from_moments_x4(const mvr_pair_moments2_t *const m2[4], const double *const Ts[4], const double *const Tt[4],
+                              double MM[4][36], double MZ[4][6], double ss[4])
+{
+  for (int l = 0; l < 4; ++l) if (m2[l]->n < 3.0) return false;
+#define LANES(expr) v4d{[&](int l) { return (expr); }(0), [&](int l) { return (expr); }(1), [&](int l) { return (expr); }(2), [&](int l) { return (expr); }(3)}
+  const v4d n = LANES(m2[l]->n);
+  M3v Rs, Rt;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Rs(r, c) = LANES(Ts[l][r + 4 * c]); Rt(r, c) = LANES(Tt[l][r + 4 * c]); }
+  v4d o[3], tsv[3], ttv[3], sp[3], sq[3], spp[6], sqq[6];
+  for (int k = 0; k < 3; ++k) { o[k] = LANES(m2[l]->origin[k]); tsv[k] = LANES(Ts[l][12 + k]); ttv[k] = LANES(Tt[l][12 + k]); sp[k] = LANES(m2[l]->sp[k]); sq[k] = LANES(m2[l]->sq[k]); }
+  for (int k = 0; k < 6; ++k) { spp[k] = LANES(m2[l]->spp[k]); sqq[k] = LANES(m2[l]->sqq[k]); }
+  M3v spq; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) spq(r, c) = LANES(m2[l]->spq[3 * r + c]);
+#undef LANES
+  v4d cs[3], ct[3], t3[3];
+  vmulv(Rs, o, t3); for (int k = 0; k < 3; ++k) cs[k] = t3[k] + tsv[k] - o[k];
+  vmulv(Rt, o, t3); for (int k = 0; k < 3; ++k) ct[k] = t3[k] + ttv[k] - o[k];
+  v4d Rsp[3], Rtq[3];
+  vmulv(Rs, sp, Rsp); vmulv(Rt, sq, Rtq);
+  v4d sa[3], sb[3];
+  for (int k = 0; k < 3; ++k) { sa[k] = Rsp[k] + n * cs[k]; sb[k] = Rtq[k] + n * ct[k]; }
+  M3v Saa = vadd(vadd(vmul(vmul(Rs, vsym6(spp)), vtranspose(Rs)), vouter(Rsp, cs)), vadd_s(vouter(cs, Rsp), vouter(cs, cs), n));
+  M3v Sbb = vadd(vadd(vmul(vmul(Rt, vsym6(sqq)), vtranspose(Rt)), vouter(Rtq, ct)), vadd_s(vouter(ct, Rtq), vouter(ct, ct), n));
+  M3v Sab = vadd(vadd(vmul(vmul(Rs, spq), vtranspose(Rt)), vouter(Rsp, ct)), vadd_s(vouter(cs, Rtq), vouter(cs, ct), n));
+  M3v Sba = vtranspose(Sab);
+  v4d sav[3], sdf[3];
+  for (int k = 0; k < 3; ++k) { sav[k] = vsplat(0.5) * (sa[k] + sb[k]); sdf[k] = sa[k] - sb[k]; }
+  M3v Savav, Savdf;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+    Savav(r, c) = vsplat(0.25) * (Saa(r, c) + Sab(r, c) + Sba(r, c) + Sbb(r, c));
+    Savdf(r, c) = vsplat(0.5) * (Saa(r, c) - Sab(r, c) + Sba(r, c) - Sbb(r, c));
+  }
+  const v4d tr_dfdf = (Saa(0, 0) + Saa(1, 1) + Saa(2, 2)) - vsplat(2.0) * (Sab(0, 0) + Sab(1, 1) + Sab(2, 2)) +
+                      (Sbb(0, 0) + Sbb(1, 1) + Sbb(2, 2));
+  v4d Sx[3]; M3v Sxx, Sxd;
+  for (int k = 0; k < 3; ++k) Sx[k] = sav[k] + n * o[k];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+    Sxx(r, c) = Savav(r, c) + o[r] * sav[c] + sav[r] * o[c] + n * o[r] * o[c];
+    Sxd(r, c) = Savdf(r, c) + o[r] * sdf[c];
+  }
+  v4d M[36], Z[6], D[6];
+  for (int k = 0; k < 36; ++k) M[k] = vsplat(0.0);
+#define MV(r, c) M[6 * (r) + (c)]
+  MV(0, 4) = -Sx[1]; MV(0, 5) = Sx[2]; MV(1, 3) = -Sx[2]; MV(1, 4) = Sx[0]; MV(2, 3) = Sx[1]; MV(2, 5) = -Sx[0];
+  MV(3, 4) = -Sxx(0, 2); MV(3, 5) = -Sxx(0, 1); MV(4, 5) = -Sxx(1, 2);
+  MV(3, 3) = Sxx(1, 1) + Sxx(2, 2); MV(4, 4) = Sxx(0, 0) + Sxx(1, 1); MV(5, 5) = Sxx(0, 0) + Sxx(2, 2);
+  MV(0, 0) = MV(1, 1) = MV(2, 2) = n;
+  for (int r = 0; r < 6; ++r) for (int c = r + 1; c < 6; ++c) MV(c, r) = MV(r, c);
+#undef MV
+  Z[0] = sdf[0]; Z[1] = sdf[1]; Z[2] = sdf[2];
+  Z[3] = Sxd(1, 2) - Sxd(2, 1);
+  Z[4] = Sxd(0, 1) - Sxd(1, 0);
+  Z[5] = Sxd(2, 0) - Sxd(0, 2);
+  if (!solve6_spd_x4(M, Z, D)) return false;
+  M3v Cm = vzero3();
+  Cm(0, 1) = -D[4]; Cm(0, 2) = D[5]; Cm(1, 0) = D[4]; Cm(1, 2) = -D[3]; Cm(2, 0) = -D[5]; Cm(2, 1) = D[3];
+  v4d Co[3], Dt[3];
+  vmulv(Cm, o, Co);
+  for (int k = 0; k < 3; ++k) Dt[k] = D[k] + Co[k];
+  const M3v CtC = vmul(vtranspose(Cm), Cm);
+  v4d tr_ctc_savav = vsplat(0.0), tr_c_savdf = vsplat(0.0);
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { tr_ctc_savav += CtC(r, c) * Savav(c, r); tr_c_savdf += Cm(r, c) * Savdf(c, r); }
+  v4d Csav[3];
+  vmulv(Cm, sav, Csav);
+  const v4d dt2 = Dt[0] * Dt[0] + Dt[1] * Dt[1] + Dt[2] * Dt[2];
+  const v4d dt_sdf = Dt[0] * sdf[0] + Dt[1] * sdf[1] + Dt[2] * sdf[2];
+  const v4d dt_csav = Dt[0] * Csav[0] + Dt[1] * Csav[1] + Dt[2] * Csav[2];
+  const v4d ssv = tr_dfdf + n * dt2 + tr_ctc_savav - vsplat(2.0) * dt_sdf - vsplat(2.0) * tr_c_savdf + vsplat(2.0) * dt_csav;
+  for (int l = 0; l < 4; ++l) {
+    for (int k = 0; k < 36; ++k) MM[l][k] = M[k][l];
+    for (int k = 0; k < 6; ++k) MZ[l][k] = Z[k][l];
+    ss[l] = ssv[l];
+  }
+  return true;
+}
+}  // namespace
+
+// test hook: the four-lane computeEdge next to the scalar one (tests/test_host.py compares the bytes)
+API int mvr_lum_edge_from_moments_x4(const mvr_pair_moments2_t *m2 /* [4] */, const double *pose_s /* [4][6] */,
+                                     const double *pose_t /* [4][6] */, double *MM /* [4][36] */, double *MZ /* [4][6] */, double *ss /* [4] */)
+{
+  if (!m2 || !pose_s || !pose_t || !MM || !MZ || !ss) return MVR_E_ARG;
+  double Ts[4][16], Tt[4][16];
+  const mvr_pair_moments2_t *mp[4]; const double *ps[4], *pt[4];
+  for (int l = 0; l < 4; ++l) { mvr_pose_to_mat4(pose_s + 6 * l, Ts[l]); mvr_pose_to_mat4(pose_t + 6 * l, Tt[l]); mp[l] = m2 + l; ps[l] = Ts[l]; pt[l] = Tt[l]; }
+  double M[4][36], Z[4][6], S[4];
+  if (!lum_edge_from_moments_x4(mp, ps, pt, M, Z, S)) return MVR_E_NOCORR;        // a lane needs the scalar function's special paths
+  std::memcpy(MM, M, sizeof M); std::memcpy(MZ, Z, sizeof Z); std::memcpy(ss, S, sizeof S);
+  return MVR_OK;
+}
+
 // LUM::incidenceCorrection (pcl/registration/impl/lum.hpp): H(X) with
 //   d(R(theta) p + t)/dX = M(p') H(X),   p' = R p + t,   R = Rx Ry Rz (Borrmann et al.),
 // M = [I | ex x p', ez x p', ey x p'] being the matrix LUM::computeEdge builds its sums from (rotational unknowns in
@@ -536,9 +679,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   int it = 0;
   for (; it < max_iterations; ++it) {
     for (int v = 0; v < n; ++v) mvr_pose_to_mat4(poses + 6 * v, &Tv[(size_t)v * 16]);
-    for (int e = 0; e < ne; ++e) {
-      double MM[36], MZ[6], ss;
-      const int rc = lum_edge_from_moments_T(&m2[e], &Tv[(size_t)es[e] * 16], &Tv[(size_t)et[e] * 16], MM, MZ, &ss);
+    auto store_edge = [&](int e, int rc, const double *MM, const double *MZ, double ss) {
       if (rc != MVR_OK || ss < 0.0000000000001 || !std::isfinite(ss)) {
         std::fill(cinv.begin() + 36 * e, cinv.begin() + 36 * (e + 1), 0.0);
         std::fill(cinvd.begin() + 6 * e, cinvd.begin() + 6 * (e + 1), 0.0);
@@ -546,6 +687,26 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
         for (int k = 0; k < 36; ++k) cinv[36 * e + k] = MM[k] * (1.0 / ss);
         for (int k = 0; k < 6; ++k) cinvd[6 * e + k] = MZ[k] * (1.0 / ss);
       }
+    };
+    int e = 0;
+    for (; e + 4 <= ne; e += 4) {           // four edges per AVX2 pass (bit-identical to the scalar function)
+      const mvr_pair_moments2_t *mp[4]; const double *ps[4], *pt[4];
+      for (int l = 0; l < 4; ++l) { mp[l] = &m2[e + l]; ps[l] = &Tv[(size_t)es[e + l] * 16]; pt[l] = &Tv[(size_t)et[e + l] * 16]; }
+      double MM4[4][36], MZ4[4][6], ss4[4];
+      if (lum_edge_from_moments_x4(mp, ps, pt, MM4, MZ4, ss4)) {
+        for (int l = 0; l < 4; ++l) store_edge(e + l, MVR_OK, MM4[l], MZ4[l], ss4[l]);
+      } else {
+        for (int l = 0; l < 4; ++l) {
+          double MM[36], MZ[6], ss;
+          const int rc = lum_edge_from_moments_T(mp[l], ps[l], pt[l], MM, MZ, &ss);
+          store_edge(e + l, rc, MM, MZ, ss);
+        }
+      }
+    }
+    for (; e < ne; ++e) {
+      double MM[36], MZ[6], ss;
+      const int rc = lum_edge_from_moments_T(&m2[e], &Tv[(size_t)es[e] * 16], &Tv[(size_t)et[e] * 16], MM, MZ, &ss);
+      store_edge(e, rc, MM, MZ, ss);
     }
     std::fill(G.begin(), G.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
     for (int vi = 1; vi < n; ++vi)

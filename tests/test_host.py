@@ -125,6 +125,39 @@ def test_moments2_to_moments_and_lum_edge(mvr, orc):
         assert abs(ssg - ss) <= 1e-7 * ss
 
 
+def test_lum_edge_four_at_once_is_bit_identical_to_the_scalar_function(mvr):
+    """mvr_lum_compute sends its edges four at a time through an AVX2 pass (one edge per lane): every lane must give
+    the bytes of the scalar LUM::computeEdge -- and a group with a degenerate edge must be refused (-> scalar path)."""
+    rng = np.random.default_rng(77)
+    origin = np.array([-13.4, 50.2, 917.5])
+    for trial in range(25):
+        m2s, ps, pt = [], [], []
+        for l in range(4):
+            n = int(rng.integers(3, 4000))
+            src = rand_cloud(rng, n, scale=float(rng.uniform(5, 120)), centre=tuple(origin + rng.standard_normal(3) * 30))
+            tgt = src.copy(); tgt[:, :3] += rng.standard_normal((n, 3)).astype(np.float32) * float(rng.uniform(0.01, 2.0))
+            idx = np.arange(n)
+            m2s.append(mvr.moments2_from_row(_moments_numpy(src, tgt, idx, idx, origin)))
+            ps.append(np.r_[rng.standard_normal(3) * 2.0, rng.standard_normal(3) * 0.05])
+            pt.append(np.r_[rng.standard_normal(3) * 2.0, rng.standard_normal(3) * 0.05])
+        rc, MM, MZ, ss = mvr.lum_edge_from_moments_x4(m2s, ps, pt)
+        assert rc == 0
+        for l in range(4):
+            rc1, MM1, MZ1, ss1 = mvr.lum_edge_from_moments(m2s[l], ps[l], pt[l])
+            assert rc1 == 0
+            assert MM[l].tobytes() == MM1.tobytes() and MZ[l].tobytes() == MZ1.tobytes()
+            assert np.float64(ss[l]).tobytes() == np.float64(ss1).tobytes()
+    # an edge with two pairs only: the group is refused, nothing written
+    few = mvr.moments2_from_row(_moments_numpy(src, tgt, np.arange(2), np.arange(2), origin))
+    rc, _, _, _ = mvr.lum_edge_from_moments_x4([m2s[0], few, m2s[2], m2s[3]], ps, pt)
+    assert rc == mvr.E_NOCORR
+    # collinear points: MM is singular, the Cholesky pivot test refuses the group
+    line = np.zeros((50, 4), np.float32); line[:, 0] = np.arange(50)
+    flat = mvr.moments2_from_row(_moments_numpy(line, line, np.arange(50), np.arange(50), np.zeros(3)))
+    rc, _, _, _ = mvr.lum_edge_from_moments_x4([flat, m2s[1], m2s[2], m2s[3]], ps, pt)
+    assert rc == mvr.E_NOCORR
+
+
 def test_lum_compute_from_moments_matches_oracle(mvr, orc):
     rng = np.random.default_rng(22)
     base = rand_cloud(rng, 500, scale=40, centre=(0, 0, 900))
