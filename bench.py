@@ -345,7 +345,7 @@ def main():
         wl_, wms, wev = iso["wide"]
         cl_, cms, cev = iso["nn"]
         q_per_launch = V * N * args.steps / gl_ * (1.0 + reg.last["n_corr"] / float(V * N))      # forward: every source; reverse: about one per accepted pair
-        alg_bytes = 32.0 * q_per_launch + 16.0 * gev / gl_                  # query + previous key read, key written; 16 B per candidate point
+        alg_bytes = 32.0 * q_per_launch + 16.0 * V * N                       # per query: its point, its previous key or start bound, the key written; the posed target array once
         avg_s = gms * 1e-3 / gl_
         extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; per step one forward "
                              "launch (all %d x %d source queries) and one reverse launch (the matched targets) for all scan pairs" % (args.steps, V, N),

@@ -157,6 +157,38 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
         assert runs[0] == runs[1], (V, N)
 
 
+@pytest.mark.parametrize("knobs", [
+    dict(grid_lanes=2), dict(grid_lanes=4), dict(grid_lanes=8, grid_cell_points=20),
+    dict(grid_wide=0), dict(grid_wide=0, grid_light_rows=1), dict(grid_light_rows=1), dict(grid_light_rows=64),
+    dict(cull_list=0), dict(cull_list_w=1), dict(cull_list_w=4, grid_cluster=1), dict(grid_cluster=65),
+    dict(grid_cell_points=1), dict(grid_cell_points=40, grid_light_rows=3), dict(fused_mark=1), dict(fused_mark=1, grid_lanes=4, pair_groups=1),
+    dict(grid_wide_waves=1), dict(pair_groups=3, cull_slices=8),
+], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
+    """Every routing knob of the grid search (lanes per query, cell size, what counts as a wide ball, where the wide ones
+    go, set lists, marking) only moves queries between three exact searches: six passes of the 12 x 20k ring from the
+    prior give the same poses and edge tables, bit for bit, as the default settings."""
+    V, N, max_d = 12, 20000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for kn in ({}, knobs):
+        with mvr.Context(0) as ctx:
+            ctx.tune(**kn)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, log = [p.copy() for p in poses0], []
+            for _ in range(6):
+                poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin)
+                log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+            runs.append(log)
+    assert runs[0] == runs[1], knobs
+
+
 def test_transform_batch_equals_single_transforms(gpu, mvr):
     """mvr_cloud_transform_batch poses many clouds in one launch, bit for bit like mvr_cloud_transform."""
     g = load_golden("ring_12x2048.npz")
