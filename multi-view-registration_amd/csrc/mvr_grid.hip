@@ -35,7 +35,7 @@ namespace mvr {
 
 CellGrid::~CellGrid()
 {
-  for (void *p : {(void *)start, (void *)gperm, (void *)graw, (void *)g2h, (void *)dt}) if (p) (void)hipFree(p);
+  for (void *p : {(void *)start, (void *)gperm, (void *)graw, (void *)g2h, (void *)h2g, (void *)dt}) if (p) (void)hipFree(p);
 }
 
 namespace {
@@ -107,10 +107,11 @@ __global__ void grid_gather_kernel(const float4 *__restrict__ p, const uint32_t 
   graw[k] = v;
 }
 
-__global__ void g2h_kernel(const uint32_t *__restrict__ gperm, const uint32_t *__restrict__ inv, size_t n, uint32_t *__restrict__ g2h)
+__global__ void g2h_kernel(const uint32_t *__restrict__ gperm, const uint32_t *__restrict__ inv, size_t n, uint32_t *__restrict__ g2h,
+                           uint32_t *__restrict__ h2g)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) g2h[k] = inv[gperm[k]];
+  if (k < n) { const uint32_t h = inv[gperm[k]]; g2h[k] = h; h2g[h] = (uint32_t)k; }
 }
 
 // posed coordinates in grid order: the SAME function of the same inputs as the posed points themselves
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) { bound = __uint_as_float(v); seeded = true; } }
     if (a.seed_from_keys) {
       const uint32_t prev = (uint32_t)a.keys[qpos];
-      if (prev < a.nt) { const float d = gdist2<FMA>(a.ts[prev], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }
+      if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }      // (the same point, read from the array the walk is about to read)
     }
     // the ball in the target's canonical frame.  The mapping itself is done in double; what the margin has to cover is
     // that both clouds' posed coordinates are FLOAT roundings of the exact motion (half an ulp per coordinate and cloud:
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch
     if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) bound = __uint_as_float(v); }
     if (a.seed_from_keys) {
       const uint32_t prev = (uint32_t)a.keys[qpos];
-      if (prev < a.nt) { const float d = gdist2<FMA>(a.ts[prev], q.x, q.y, q.z); if (d <= bound) bound = d; }
+      if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
     }
     const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
     const double qx = q.x, qy = q.y, qz = q.z;
@@ -441,7 +442,7 @@ bool ensure_grid(Ctx *c, Cloud &canon)
   uint32_t *cid_a = nullptr, *cid_b = nullptr, *idx_a = nullptr;
   uint8_t *dt_tmp = nullptr;
   bool ok = hipMalloc(&g->start, (cells + 1 + 4) * 4) == hipSuccess && hipMalloc(&g->gperm, n * 4) == hipSuccess &&
-            hipMalloc(&g->graw, n * sizeof(float4)) == hipSuccess && hipMalloc(&g->g2h, n * 4) == hipSuccess &&
+            hipMalloc(&g->graw, n * sizeof(float4)) == hipSuccess && hipMalloc(&g->g2h, n * 4) == hipSuccess && hipMalloc(&g->h2g, n * 4) == hipSuccess &&
             hipMalloc(&g->dt, cells) == hipSuccess && hipMalloc(&dt_tmp, cells) == hipSuccess && hipMalloc(&cid_a, n * 4) == hipSuccess &&
             hipMalloc(&cid_b, n * 4) == hipSuccess && hipMalloc(&idx_a, n * 4) == hipSuccess;
   if (ok) {
@@ -494,7 +495,7 @@ int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
       if (!cl || !cl->grid || !cl->pose_known || cl->gcoords_valid || cl->n == 0 || cl->grid->n != cl->n) continue;
       if (int rc = ensure(c, cl->gsorted, cl->gsorted_cap, cl->n)) return rc;
       if (cl->order && cl->grid->built_for != cl->order.get()) {
-        hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h);
+        hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h, cl->grid->h2g);
         cl->grid->built_for = cl->order.get();
       }
       b.graw[used] = cl->grid->graw; b.out[used] = cl->gsorted; b.n[used] = cl->n;
@@ -517,7 +518,7 @@ GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cl
   GridPair p;
   const CellGrid &g = *t.grid;
   p.qs = q.sorted; p.q_begin = (uint32_t)q_begin; p.q_count = (uint32_t)q_count;
-  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h;
+  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h; p.h2g = g.h2g;
   for (int k = 0; k < 3; ++k) { p.lo[k] = g.lo[k]; p.dim[k] = g.dim[k]; }
   p.inv_h = g.inv_h; p.h = g.h;
   // inverse of the pose's affine map x -> A x + t (column-major 4 x 4, column-vector; A is a rotation up to float rounding:

@@ -54,6 +54,7 @@ struct CellGrid {
   uint32_t *gperm = nullptr;             // [n] grid position -> original index
   float4 *graw = nullptr;                // [n] canonical coordinates in grid order, w = bits(original index)
   uint32_t *g2h = nullptr;               // [n] grid position -> position in the set's Hilbert ordering (what the fused pass's keys carry)
+  uint32_t *h2g = nullptr;               // [n] its inverse: where a seed (a Hilbert position) sits in grid order -- the seed's coordinates then come from the array the walk reads anyway
   uint8_t *dt = nullptr;                 // [cells] Chebyshev distance, in cells, to the nearest occupied cell (0 = occupied, 255 = farther than kGridDtMax): "is there any point near here at all" in ONE byte
   const Order *built_for = nullptr;      // the ordering g2h refers to
   ~CellGrid();
@@ -363,7 +364,7 @@ struct GridPair {
   uint32_t q_begin = 0, q_count = 0;
   const float4 *gts = nullptr;                // target: posed coordinates in GRID order (w = original index)
   const float4 *ts = nullptr;                 // target in Hilbert order (only to price the seed: the previous match's position)
-  const uint32_t *start = nullptr, *g2h = nullptr;
+  const uint32_t *start = nullptr, *g2h = nullptr, *h2g = nullptr;
   const uint8_t *dt = nullptr;
   float lo[3] = {0, 0, 0}, inv_h = 1.f, h = 1.f;
   int dim[3] = {1, 1, 1};
