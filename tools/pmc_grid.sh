@@ -15,12 +15,12 @@ for set in "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SAL
   echo "pass $i: $set" >> $O/progress.txt; MVR_PROBE_PROF=0 timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python3 $R/tools/step_probe.py 12 200000 6 25 pair_groups=1 "$@" > $O/p$i/log.txt 2>&1 || echo "pass $i failed" >> $O/summary.txt
 done
 python3 - $O >> $O/summary.txt <<'P'
-import csv, sys, glob, collections
+import csv, sys, glob, collections, os
 for f in sorted(glob.glob(sys.argv[1] + '/p*/**/*counter_collection.csv', recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].replace('mvr::(anonymous namespace)::','').replace('void ','').split('(')[0][:40]
-        if 'nn_' not in k: continue
+        if os.environ.get('PMC_PATTERN', 'nn_') not in k: continue
         acc[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[k].add(r['Dispatch_Id'])
     for k in acc:
         n = len(cnt[k])
