@@ -189,6 +189,45 @@ def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
     assert runs[0] == runs[1], knobs
 
 
+@pytest.mark.parametrize("case", ["fma", "sheared_pose", "sub_ranges"])
+def test_grid_search_equals_culled_search_off_the_main_road(mvr, case):
+    """ring_search 1 == ring_search 0, bit for bit, also (a) with the fused multiply-add form of the distance, (b) when a
+    view's pose is not rigid (a sheared matrix: the grid of that scan cannot be mapped into by an inverse pose, the
+    pass must notice and keep the culled kernel) and (c) when a rank only owns sub-ranges of the queries."""
+    V, N, max_d = 12, 15000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    if case == "sheared_pose":
+        poses0[5] = poses0[5].copy(); poses0[5][0, 1] += 3e-3
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for mode in (0, 1):
+        with mvr.Context(0) as ctx:
+            ctx.tune(ring_search=mode)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            log = []
+            if case == "sub_ranges":
+                ranges = [(0, None), (100, 7000), (0, 0), (14000, None), (5, 1), (0, None), (1024, 1024), (3, 14040), (0, None), (7, 1000), (0, None), (64, 64)]
+                for it in range(4):
+                    P = [p.copy() for p in poses0]
+                    for v in range(1, V):
+                        P[v] = mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V) + 1e-4 * it * v)      # the clouds move a little between the passes
+                    ctx.transform_batch(list(range(V)), [V + v for v in range(V)], P)
+                    rows = ctx.pair_moments2_batch(edges, max_d, origin, ranges=ranges)
+                    log.append(b"".join(bytes(r) for r in rows))
+            else:
+                poses = [p.copy() for p in poses0]
+                for _ in range(5):
+                    poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin, fma=(case == "fma"))
+                    log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+            runs.append(log)
+    assert runs[0] == runs[1], case
+
+
 def test_transform_batch_equals_single_transforms(gpu, mvr):
     """mvr_cloud_transform_batch poses many clouds in one launch, bit for bit like mvr_cloud_transform."""
     g = load_golden("ring_12x2048.npz")
