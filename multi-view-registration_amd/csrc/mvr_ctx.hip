@@ -1071,20 +1071,23 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     std::vector<Cloud *> used;
     for (int k = 0; k < n_pairs; ++k) { used.push_back(&c->slots[src[k]]); used.push_back(&c->slots[dst[k]]); }
     if (int rc = ensure_index_batch(c, used.data(), (int)used.size())) return rc;      // one refresh launch for all views
-    if (c->pair_fused && c->ring_search && max_dist * max_dist < (double)FLT_MAX) {
+    if (c->pair_fused && c->ring_search && c->fused_passes > 0 && max_dist * max_dist < (double)FLT_MAX) {
       // the grid search's side: every posed copy finds its set's grid (built once, from the cloud that holds the set's
-      // canonical coordinates) and refreshes its coordinates in grid order -- one launch for all views
+      // canonical coordinates) and refreshes its coordinates in grid order -- one launch for all views.  Not in the
+      // first fused pass of a context: it has no seeds and would not use a grid, and a caller that runs a single pass
+      // should not pay for twelve of them (0.85 ms each at 200k points; tools/first_passes.py)
       std::sort(used.begin(), used.end());
       used.erase(std::unique(used.begin(), used.end()), used.end());
       for (Cloud *cl : used) {
         if (cl->grid || !cl->pose_known || cl->n == 0) continue;
         for (Cloud &o : c->slots)
-          if (o.set_id == cl->set_id && o.canonical && o.n == cl->n) { if (ensure_grid(c, o)) cl->grid = o.grid; break; }
+          if (o.set_id == cl->set_id && o.canonical && o.n == cl->n) { if (ensure_grid(c, o, max_dist + 0.5)) cl->grid = o.grid; break; }
       }
       if (int rc = refresh_grid_coords_batch(c, used.data(), (int)used.size())) return rc;
     }
   }
   if (c->nn_mode != 0 && c->pair_fused) {
+    ++c->fused_passes;
     // Optionally in G groups of pairs, group 0 on the caller's stream and the others on worker streams: a group's
     // glue kernels and the tail of its searches then overlap the other groups' searches.
     // (only when there are pairs to spare: with fewer than four per group the second stream just doubles the launches --

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       // however far the query itself lies outside the grid
       const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
       const uint32_t d = a.dt[((size_t)cz * a.dim[1] + cy) * a.dim[0] + cx];
-      const float least = (d == 255u ? (float)kGridDtMax : (float)d - 1.f) * a.h;
+      const float least = (d == 255u ? (float)a.dt_max : (float)d - 1.f) * a.h;
       worth = !(least > rad);
     }
     const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch
 }  // namespace
 
 // ---- build: once per point set, from a cloud that holds the set's canonical coordinates
-bool ensure_grid(Ctx *c, Cloud &canon)
+bool ensure_grid(Ctx *c, Cloud &canon, double reach)
 {
   const size_t n = canon.n;
   if (!canon.canonical || n == 0 || n > 0xFFFFFFF0ull) return false;
@@ -461,10 +461,14 @@ bool ensure_grid(Ctx *c, Cloud &canon)
     if (ok) {
       hipLaunchKernelGGL(cell_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, cid_b, n, cells, g->start);
       hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, c->stream, canon.pts, g->gperm, n, g->graw);
-      // distance map: kGridDtMax dilation steps, ping-pong (an even count: the result ends in g->dt)
+      // distance map: as many dilation steps as ruling out `reach` takes (dt - 1 cell edges > reach + a cell), at most
+      // kGridDtMax; ping-pong (an even count: the result ends in g->dt).  Half of a grid's build time is these steps.
       static_assert(kGridDtMax % 2 == 0, "ping-pong ends in dt");
+      int steps = (int)std::ceil(std::max(0.0, reach) / h) + 2;
+      steps = std::min(kGridDtMax, std::max(2, steps + (steps & 1)));
+      g->dt_steps = steps;
       hipLaunchKernelGGL(dt_init_kernel, dim3(cb), dim3(256), 0, c->stream, g->start, cells, g->dt);
-      for (int step = 1; step <= kGridDtMax; ++step) {
+      for (int step = 1; step <= steps; ++step) {
         uint8_t *in = (step & 1) ? g->dt : dt_tmp, *out = (step & 1) ? dt_tmp : g->dt;
         hipLaunchKernelGGL(dt_step_kernel, dim3(cb), dim3(256), 0, c->stream, in, out, g->dim[0], g->dim[1], g->dim[2], step);
       }
@@ -518,7 +522,7 @@ GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cl
   GridPair p;
   const CellGrid &g = *t.grid;
   p.qs = q.sorted; p.q_begin = (uint32_t)q_begin; p.q_count = (uint32_t)q_count;
-  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h; p.h2g = g.h2g;
+  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h; p.h2g = g.h2g; p.dt_max = g.dt_steps;
   for (int k = 0; k < 3; ++k) { p.lo[k] = g.lo[k]; p.dim[k] = g.dim[k]; }
   p.inv_h = g.inv_h; p.h = g.h;
   // inverse of the pose's affine map x -> A x + t (column-major 4 x 4, column-vector; A is a rotation up to float rounding:

@@ -55,7 +55,8 @@ struct CellGrid {
   float4 *graw = nullptr;                // [n] canonical coordinates in grid order, w = bits(original index)
   uint32_t *g2h = nullptr;               // [n] grid position -> position in the set's Hilbert ordering (what the fused pass's keys carry)
   uint32_t *h2g = nullptr;               // [n] its inverse: where a seed (a Hilbert position) sits in grid order -- the seed's coordinates then come from the array the walk reads anyway
-  uint8_t *dt = nullptr;                 // [cells] Chebyshev distance, in cells, to the nearest occupied cell (0 = occupied, 255 = farther than kGridDtMax): "is there any point near here at all" in ONE byte
+  uint8_t *dt = nullptr;                 // [cells] Chebyshev distance, in cells, to the nearest occupied cell (0 = occupied, 255 = farther than dt_steps): "is there any point near here at all" in ONE byte
+  int dt_steps = 0;                      // dilation steps dt was built with: 255 means "farther than dt_steps cells"
   const Order *built_for = nullptr;      // the ordering g2h refers to
   ~CellGrid();
 };
@@ -166,6 +167,7 @@ struct Ctx {
   int cull_slices = 0;                                // culled kernel: interleaved slices a pair's query sets are dealt to the XCDs in (1, 2, 4, 8; 0 = 8 / gcd(pairs, 8))
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
   int fused_mark = 0;                                 // fused pass: the forward launch itself records the matched targets' start bounds (0: a separate launch re-reads the keys)
+  unsigned long long fused_passes = 0;                // fused pair batches run on this context so far
   std::vector<unsigned long long> fused_sig;          // what the forward keys in bkeys[] belong to (point-set ids, ranges, offsets): the previous fused pass on this context
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
   // workers: contexts with their own stream and work buffers that BORROW clouds of this
@@ -375,6 +377,7 @@ struct GridPair {
   const uint32_t *qbound = nullptr;           // optional start bounds by query position (bits of a d2; ~0 = none)
   uint32_t *mark = nullptr;                   // optional: start bounds of the reverse searches, by the match's Hilbert position
   uint32_t key_by_pos = 0, seed_from_keys = 0;
+  int dt_max = 12;                       // what dt == 255 stands for (the grid's dt_steps)
   // a BOUNDED query whose ball is wide (scattered among the others: a match that moved far, a long correspondence) is
   // neither walked by its own thread (the wave would wait for it) nor flagged for the culled kernel (one such query
   // per 64 would wake every block): its ordinal is appended here and a second launch gives each of them a whole wave
@@ -383,7 +386,7 @@ struct GridPair {
 };
 constexpr int kGridBatchPairs = 12;
 constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
-constexpr int kGridDtMax = 12;        // dilation steps of the distance map
+constexpr int kGridDtMax = 12;        // most dilation steps of the distance map (a grid is built with as many as the first search radius it serves needs)
 constexpr int kGridLightRows = 12;    // default number of rows of cells (x-runs) a thread walks by itself (measured on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
 struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
@@ -391,7 +394,7 @@ int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
 // the set's grid (built from `canon`, a cloud holding the set's canonical coordinates) and the posed copy's grid-ordered
 // coordinates; false = not available (the caller uses the culled kernel)
 int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo xyz, hi xyz} on the host (synchronises the stream)
-bool ensure_grid(Ctx *c, Cloud &canon);
+bool ensure_grid(Ctx *c, Cloud &canon, double reach);      // reach: the search radius the distance map should be able to rule out (mm)
 int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
 GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cloud &t, nnkey_t *keys);
 int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
