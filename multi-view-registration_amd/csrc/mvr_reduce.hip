@@ -21,11 +21,36 @@ struct Vec3d { double x, y, z; };
 constexpr int kRT = 256;          // threads per reduction block
 constexpr int kMaxBlocks = 1024;  // partial rows
 
+// Sum of a double over the 64 lanes of a wave, the same value in every lane, without the LDS crossbar: an inclusive
+// scan inside each row of 16 lanes by DPP row shifts (lanes shifted in from outside the row read as 0), then the four row
+// totals -- lanes 15, 31, 47, 63 -- are read as scalars and added in order.  (`__shfl_down` of a double is two
+// `ds_bpermute` per step: the 29 sums of the moments kernel cost 348 of them per wave and made that kernel LDS-bound,
+// 59 us for the 12 pairs of a ring step.)  Fixed order, so the sums are reproducible run to run.
+__device__ __forceinline__ double dpp_row_shr(double v, int ctrl)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+  switch (ctrl) {      // the control word is an immediate
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xF, 0xF, true); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xF, 0xF, true); break;
+  }
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_row_shr(v, 1);
+  v += dpp_row_shr(v, 2);
+  v += dpp_row_shr(v, 4);
+  v += dpp_row_shr(v, 8);
+  return ((lane_value(v, 15) + lane_value(v, 31)) + lane_value(v, 47)) + lane_value(v, 63);
 }
 
 // block-wide sums of K per-thread doubles -> row `blockIdx.x` of partials
