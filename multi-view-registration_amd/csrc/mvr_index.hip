@@ -165,6 +165,25 @@ __global__ void finish_order_kernel(const uint32_t *__restrict__ perm, size_t n,
   if (k < n) inv[perm[k]] = (uint32_t)k;
 }
 
+// minimum / maximum of a float over the 64 lanes, the same value in every lane: a running min / max inside each row of
+// 16 lanes by DPP row shifts (a lane with no source keeps its own value: min and max are idempotent), then the row results
+// (lanes 15, 31, 47, 63) as scalars
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_f32(float v)
+{
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  int b = __float_as_int(v);
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x111, 0xF, 0xF, false))); b = __float_as_int(v);
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x112, 0xF, 0xF, false))); b = __float_as_int(v);
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x114, 0xF, 0xF, false))); b = __float_as_int(v);
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(b, b, 0x118, 0xF, 0xF, false))); b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 15)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 47)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 63));
+  return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_min_f32(float v) { return wave_minmax_f32<false>(v); }
+__device__ __forceinline__ float wave_max_f32(float v) { return wave_minmax_f32<true>(v); }
+
 // sorted[k] = {pts[perm[k]].xyz, bits(perm[k])}; one wave per 256-point tile also reduces the AABBs
 // of its four 64-point cells (cbox[tile][cell] = {lo, hi}) and of the tile (their union)
 // blockIdx.y = cloud of the batch (posed scans of one global iteration are refreshed in one launch)
@@ -201,12 +220,10 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
       sorted[k] = v;
       lo[0] = hi[0] = v.x; lo[1] = hi[1] = v.y; lo[2] = hi[2] = v.z;
     }
+    // box of the 64 points: minimum / maximum over the wave without the LDS crossbar (DPP row shifts, then the four row
+    // results read as scalars; six 6-step shuffle reductions per cell kept this kernel on the ds_bpermute pipe)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-      for (int k2 = 0; k2 < 3; ++k2) {
-        lo[k2] = fminf(lo[k2], __shfl_xor(lo[k2], o, 64));
-        hi[k2] = fmaxf(hi[k2], __shfl_xor(hi[k2], o, 64));
-      }
+    for (int k2 = 0; k2 < 3; ++k2) { lo[k2] = wave_min_f32(lo[k2]); hi[k2] = wave_max_f32(hi[k2]); }
     if (lane == 0) {
       cbox[(tile * 4 + r) * 2 + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);
       cbox[(tile * 4 + r) * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
