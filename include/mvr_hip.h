@@ -397,8 +397,8 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * wide queries hands them all to the culled kernel, default 8; 65: never), "cull_list" (1, default: the culled kernel
  * visits only the query sets the walk listed; 0: a block per set), "cull_list_w" (waves per listed set: 1, 2, 4),
  * "grid_lanes" (lanes sharing a query: 1 (default), 2, 4, 8), "grid_wide_waves" (waves per CU of the wave-per-query
- * launch), "fused_mark" (1: the forward search records the start bounds of the reverse searches itself; 0, default: a
- * separate launch re-reads the keys), "grid_debug" (1: every pass prints how its queries split; synchronises).
+ * launch), "fused_mark" (1, default: the forward searches record the start bounds of the reverse searches themselves when
+ * they are the grid walk; 2: always; 0: never -- a separate launch re-reads the keys), "grid_debug" (1: every pass prints how its queries split; synchronises).
  * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,

@@ -931,7 +931,6 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     fwd[k] = make_cull_pair(s, qb[k], qn[k], nullptr, t, w->bkeys + off_s[k]);
     fwd[k].key_by_pos = 1;       // forward keys live in sorted space from here on: slot = the query's position, low word = the match's position
     fwd[k].seed_from_keys = seed ? 1u : 0u;
-    if (reciprocal && qn[k] && c->fused_mark) fwd[k].mark = w->bbound + off_t[k];      // the forward launch records where the reverse searches start
     // reverse queries = the distinct matched targets, compacted in Hilbert order (list position = key slot)
     rev[k] = make_cull_pair(t, 0, std::min(qn[k], t.n), nullptr, s, w->brkeys + off_t[k]);
     rev[k].qlist = w->blist + off_t[k]; rev[k].qcount = counts + k;
@@ -977,6 +976,13 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       }
     }
   }
+  // Who records where the reverse searches start (a matching d2 per matched target)?  The forward searches themselves when
+  // they are the grid walk (+5 us there, a launch of 12 us less), a separate launch over the keys when the culled kernel
+  // answers every query (marking inside it measured 3 % slower); fused_mark = 2 / 0 force one or the other.  Decided with
+  // the forward launches (phase 1), remembered for the rest of the pass.
+  if (phases & 1) w->marked_in_search = reciprocal && (c->fused_mark == 2 || (c->fused_mark == 1 && grid_ok && seed));
+  if (w->marked_in_search)
+    for (int k = 0; k < n_pairs; ++k) if (qn[k]) { fwd[k].mark = w->bbound + off_t[k]; if (grid_ok) gfwd[k].mark = fwd[k].mark; }
   if (phases & 1) {
     if (reciprocal && !w->bbound_clean) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, w->bbound_cap * sizeof(uint32_t), w->stream));
     if (reciprocal) w->bbound_clean = false;        // dirty until this pass's moments launch has put it back
@@ -1026,7 +1032,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       if (grid_ok) { g.zero_a = w->bwide_count + k; g.zero_b = w->bwide_count + kWideCounters + k; g.zero_c = w->bwide_count + 2 * kWideCounters + k; }
     }
     if (recip) {
-      if (!c->fused_mark) { if (int rc = launch_flag_matched_batch(w, gb, m)) return rc; }      // (else: marked by the forward launch itself)
+      if (!w->marked_in_search) { if (int rc = launch_flag_matched_batch(w, gb, m)) return rc; }      // (else: marked by the forward launches themselves)
       if (int rc = launch_compact_flags_batch(w, gb, m)) return rc;
       if (grid_ok) {
         if (int rc = launch_nn_grid_batch(w, grev.data() + base, m, cap2, fma != 0)) return rc;
@@ -1461,7 +1467,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
   else if (!std::strcmp(key, "cull_slices")) c->cull_slices = value;
   else if (!std::strcmp(key, "seed_forward")) c->seed_forward = value != 0;
-  else if (!std::strcmp(key, "fused_mark")) c->fused_mark = value != 0;
+  else if (!std::strcmp(key, "fused_mark")) { if (value < 0 || value > 2) return MVR_E_ARG; c->fused_mark = value; }
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
   else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;

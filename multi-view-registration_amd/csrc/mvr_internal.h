@@ -166,7 +166,8 @@ struct Ctx {
   int cull_w = 0;                                     // culled kernel: waves sharing one query set (1, 2, 4; 0 = by launch size)
   int cull_slices = 0;                                // culled kernel: interleaved slices a pair's query sets are dealt to the XCDs in (1, 2, 4, 8; 0 = 8 / gcd(pairs, 8))
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
-  int fused_mark = 0;                                 // fused pass: the forward launch itself records the matched targets' start bounds (0: a separate launch re-reads the keys)
+  int fused_mark = 1;                                 // fused pass: the forward launches themselves record the matched targets' start bounds -- 1: when they are the grid walk, 2: always, 0: never (a separate launch re-reads the keys)
+  bool marked_in_search = false;                      // ... what this pass does (decided with its forward launches)
   unsigned long long fused_passes = 0;                // fused pair batches run on this context so far
   std::vector<unsigned long long> fused_sig;          // what the forward keys in bkeys[] belong to (point-set ids, ranges, offsets): the previous fused pass on this context
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
