@@ -393,6 +393,31 @@ __global__ void __launch_bounds__(kChunk) compact_flags_batch_kernel(GlueBatch b
   if (f) { const unsigned at = a.chunks[blockIdx.x] + r; a.list[at] = (uint32_t)pos; a.slot[pos] = at; }
 }
 
+// the same without the scan launch, for pairs of up to kOwnPrefixChunks chunks: chunks[] holds the RAW counts and every
+// block sums the counts before its own (a few hundred L2-resident words; the scan launch cost 6 us per pass for that)
+constexpr unsigned kOwnPrefixChunks = 1024;
+__global__ void __launch_bounds__(kChunk) compact_flags_own_prefix_batch_kernel(GlueBatch b)
+{
+  const GluePair &a = b.p[blockIdx.y];
+  const size_t pos = (size_t)blockIdx.x * kChunk + threadIdx.x;
+  if ((size_t)blockIdx.x * kChunk >= a.nt) return;            // block-uniform
+  __shared__ unsigned psum[kChunk / 64];
+  unsigned mine = 0;
+  for (unsigned c = threadIdx.x; c < blockIdx.x; c += kChunk) mine += a.chunks[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) psum[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  unsigned prefix = 0;
+#pragma unroll
+  for (int w = 0; w < kChunk / 64; ++w) prefix += psum[w];
+  const bool f = pos < a.nt && (a.bound ? a.bound[pos] != 0xFFFFFFFFu : a.flags[pos] != 0);
+  unsigned total;
+  const unsigned r = chunk_rank(f, &total);
+  if (f) { const unsigned at = prefix + r; a.list[at] = (uint32_t)pos; a.slot[pos] = at; }
+  if (threadIdx.x == 0 && (size_t)(blockIdx.x + 1) * kChunk >= a.nt) *a.qcount = prefix + total;      // the pair's last chunk knows the count
+}
+
 __global__ void scatter_slot_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, size_t cap,
                                     uint32_t *__restrict__ slot)
 {
@@ -643,8 +668,12 @@ int launch_compact_flags_batch(Ctx *c, const GlueBatch &b, int n_pairs)
   ProfScope ps(c, MVR_K_GLUE, work);
   const dim3 grid((unsigned)((tmax + kChunk - 1) / kChunk), (unsigned)n_pairs);
   hipLaunchKernelGGL(count_flags_batch_kernel, grid, dim3(kChunk), 0, c->stream, b);
-  hipLaunchKernelGGL(scan_chunks_batch_kernel, dim3((unsigned)n_pairs), dim3(256), 0, c->stream, b);
-  hipLaunchKernelGGL(compact_flags_batch_kernel, grid, dim3(kChunk), 0, c->stream, b);
+  if (grid.x <= kOwnPrefixChunks) {
+    hipLaunchKernelGGL(compact_flags_own_prefix_batch_kernel, grid, dim3(kChunk), 0, c->stream, b);
+  } else {
+    hipLaunchKernelGGL(scan_chunks_batch_kernel, dim3((unsigned)n_pairs), dim3(256), 0, c->stream, b);
+    hipLaunchKernelGGL(compact_flags_batch_kernel, grid, dim3(kChunk), 0, c->stream, b);
+  }
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
