@@ -6,8 +6,8 @@ MVR_PROBE_PROF=0 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $
 python3 - "$(find $O -name '*kernel_trace.csv' | head -1)" > $O/timeline.txt <<'P'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'moments2_final_batch' in r['Kernel_Name']]
-i0,i1=idx[-2]+1,idx[-1]; t0=int(rows[i0]['Start_Timestamp'])
+idx=[i for i,r in enumerate(rows) if 'refresh_sorted' in r['Kernel_Name']]      # the first kernel of a step
+i0,i1=idx[-2],idx[-1]-1; t0=int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i1+1]:
     s=int(r['Start_Timestamp'])-t0; e=int(r['End_Timestamp'])-t0
     name=r['Kernel_Name'].replace('mvr::(anonymous namespace)::','').replace('mvr::','').replace('void ','').split('(')[0][:48]
