@@ -522,7 +522,7 @@ GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cl
   GridPair p;
   const CellGrid &g = *t.grid;
   p.qs = q.sorted; p.q_begin = (uint32_t)q_begin; p.q_count = (uint32_t)q_count;
-  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h; p.h2g = g.h2g; p.dt_max = g.dt_steps;
+  p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h; p.h2g = g.h2g; p.tinv = t.order ? t.order->inv : nullptr; p.dt_max = g.dt_steps;
   for (int k = 0; k < 3; ++k) { p.lo[k] = g.lo[k]; p.dim[k] = g.dim[k]; }
   p.inv_h = g.inv_h; p.h = g.h;
   // inverse of the pose's affine map x -> A x + t (column-major 4 x 4, column-vector; A is a rotation up to float rounding:
@@ -578,6 +578,180 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
       default: if (fma) MVR_GRID_LAUNCH(true, 4); else MVR_GRID_LAUNCH(false, 4); break;
     }
 #undef MVR_GRID_LAUNCH
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
+}
+
+// ---- the listed query sets (flagged queries: the rim of the overlap, matches that lie far): ONE BLOCK per set.  The
+// culled kernel answered these by walking its box hierarchy -- some fifty dependent loads per wave, 40 us for a set
+// whatever the number of waves, a latency chain.  With a grid the candidates are an address computation here too: the
+// union of the flagged queries' balls in cells -> its rows of cells (one range each) -> every point of those ranges
+// into LDS once, by all 256 threads -> every query against every staged point, the four waves sharing out the points
+// (lane = query; a broadcast LDS read feeds 64 evaluations).  Same bounds (inclusive), same distances, same
+// (d2, original index) minimum: the keys the culled kernel would have written.
+constexpr int kSetRows = 512;        // rows of cells staged per round
+constexpr int kSetPoints = 768;      // points staged per round (the shared arrays stay under 20 KB: eight blocks per CU)
+template <bool FMA>
+__global__ void __launch_bounds__(256, 8) nn_grid_set_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+{
+  const GridPair &a = batch.p[blockIdx.y];
+  if (!a.cull_count) return;
+  __shared__ float4 lq[64];                       // query (x, y, z, bound as bits)
+  __shared__ int ubox[8];
+  __shared__ uint32_t rs[kSetRows], roff[kSetRows + 1], wtot[4];
+  __shared__ float4 lpts[kSetPoints];
+  __shared__ unsigned long long lbest[4][64];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const float cap2 = batch.cap2;
+  const uint32_t n_sets = *a.cull_count;
+  unsigned long long n_eval = 0;
+  for (uint32_t si = blockIdx.x; si < n_sets; si += gridDim.x) {
+    const uint32_t set = a.cull_sets[si];
+    // ---- the set's queries (wave 0): bound, ball in cells, union of the flagged ones
+    bool valid = false;
+    uint32_t qpos = 0;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wv == 0) {
+      const uint32_t pos = set * 64u + (uint32_t)lane;
+      int c0[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, c1[3] = {-1, -1, -1};
+      float bound = cap2;
+      if (pos < a.q_count) {
+        qpos = a.q_begin + pos;
+        valid = a.heavy[qpos] != 0;
+      }
+      if (valid) {
+        q = a.qs[qpos];
+        if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) bound = __uint_as_float(v); }
+        if (a.seed_from_keys) {
+          const uint32_t prev = (uint32_t)a.keys[qpos];
+          if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
+        }
+        const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+        const double qx = q.x, qy = q.y, qz = q.z;
+        const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
+        const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
+        const float rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+        c0[0] = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]); c1[0] = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+        c0[1] = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]); c1[1] = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+        c0[2] = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]); c1[2] = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { c0[k] = min(c0[k], __shfl_xor(c0[k], o, 64)); c1[k] = max(c1[k], __shfl_xor(c1[k], o, 64)); }
+      lq[lane] = make_float4(q.x, q.y, q.z, bound);
+      if (lane == 0) { for (int k = 0; k < 3; ++k) { ubox[k] = c0[k]; ubox[3 + k] = c1[k]; } }
+    }
+    __syncthreads();
+    const int X0 = ubox[0], Y0 = ubox[1], Z0 = ubox[2], X1 = ubox[3], Y1 = ubox[4], Z1 = ubox[5];
+    const float4 mq = lq[lane];                     // this lane's query in every wave
+    unsigned long long best = ((unsigned long long)__float_as_uint(mq.w) << 32) | 0xFFFFFFFFull;      // a candidate AT the bound still beats it
+    if (X1 >= X0) {                                 // (no flagged query: nothing to do -- cannot happen for a listed set)
+      const int ny = Y1 - Y0 + 1, rows = ny * (Z1 - Z0 + 1);
+      for (int r0 = 0; r0 < rows; r0 += kSetRows) {
+        const int nr = min(kSetRows, rows - r0);
+        // ---- the rows' ranges, and where each begins in the staged list (block-wide exclusive scan of the lengths)
+        uint32_t mine = 0;
+        for (int r = t * 2; r < min(nr, t * 2 + 2); ++r) {
+          const int rr = r0 + r;
+          const uint32_t row = (uint32_t)(((Z0 + rr / ny) * a.dim[1] + (Y0 + rr % ny)) * a.dim[0]);
+          const uint32_t s = a.start[row + (uint32_t)X0], e = a.start[row + (uint32_t)X1 + 1u];
+          rs[r] = s; roff[r] = e - s;
+          mine += e - s;
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wv; ++w) before += wtot[w];
+        const uint32_t total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        for (int r = t * 2; r < min(nr, t * 2 + 2); ++r) { const uint32_t len = roff[r]; roff[r] = before; before += len; }
+        if (t == 0) roff[nr] = total;
+        __syncthreads();
+        // ---- stage the points of those ranges, kSetPoints at a time, and evaluate: wave w takes every fourth point
+        for (uint32_t base = 0; base < total; base += kSetPoints) {
+          const uint32_t cnt = min((uint32_t)kSetPoints, total - base);
+          // (one staged point per thread and round, its row found by bisection of the offsets: independent loads, all in
+          // flight at once -- a thread copying its rows point after point waited for every one of them)
+#pragma unroll
+          for (int u = 0; u < kSetPoints / 256; ++u) {
+            const uint32_t j = base + (uint32_t)(u * 256 + t);
+            if (j - base < cnt) {
+              int lo = 0, hi = nr - 1;
+              while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (roff[mid] <= j) lo = mid; else hi = mid - 1; }
+              lpts[j - base] = a.gts[rs[lo] + (j - roff[lo])];
+            }
+          }
+          __syncthreads();
+          uint32_t j = (uint32_t)wv;
+          for (; j + 4u < cnt; j += 8u) {            // two points in flight
+            const float4 p0 = lpts[j], p1 = lpts[j + 4u];
+            const unsigned long long k0 = ((unsigned long long)__float_as_uint(gdist2<FMA>(p0, mq.x, mq.y, mq.z)) << 32) | __float_as_uint(p0.w);
+            const unsigned long long k1 = ((unsigned long long)__float_as_uint(gdist2<FMA>(p1, mq.x, mq.y, mq.z)) << 32) | __float_as_uint(p1.w);
+            const unsigned long long k = k0 < k1 ? k0 : k1;
+            best = k < best ? k : best;
+          }
+          if (j < cnt) {
+            const float4 p = lpts[j];
+            const unsigned long long key = ((unsigned long long)__float_as_uint(gdist2<FMA>(p, mq.x, mq.y, mq.z)) << 32) | __float_as_uint(p.w);
+            best = key < best ? key : best;
+          }
+          n_eval += cnt;
+          __syncthreads();
+        }
+      }
+    }
+    // ---- the four waves' answers meet; wave 0 writes the flagged queries' keys (and the start bounds of the reverse searches)
+    lbest[wv][lane] = best;
+    __syncthreads();
+    if (wv == 0 && valid) {
+      unsigned long long m = lbest[0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const unsigned long long v = lbest[w][lane]; m = v < m ? v : m; }
+      const uint32_t bi = (uint32_t)m;
+      const bool found = bi != kNone && __uint_as_float((uint32_t)(m >> 32)) <= cap2;
+      const uint32_t ord = a.key_by_pos ? qpos : __float_as_uint(q.w);
+      uint32_t low = bi;
+      if (found && (a.key_by_pos || a.mark)) {
+        const uint32_t hp = a.tinv[bi];
+        if (a.key_by_pos) low = hp;
+        if (a.mark) __hip_atomic_store(&a.mark[hp], (uint32_t)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      a.keys[ord] = found ? ((m & 0xFFFFFFFF00000000ull) | low) : kKeyInit;
+    }
+    __syncthreads();                                // lq / ubox / lbest are reused by the next set
+  }
+  if (evals && lane == 0 && n_eval) {
+    unsigned long long *sh = evals + (size_t)((blockIdx.x * 4u + (uint32_t)wv) & (kEvalShards - 1)) * kEvalStride;
+    atomicAdd(sh, n_eval * 16ull);      // every staged point is evaluated by the 64 lanes of one of the four waves
+    atomicAdd(sh + kEvalRegion, n_eval * 16ull);
+  }
+}
+
+int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma)
+{
+  for (int base = 0; base < n_pairs; base += kGridBatchPairs) {
+    GridBatch batch;
+    const int m = std::min(kGridBatchPairs, n_pairs - base);
+    bool any = false;
+    for (int k = 0; k < kGridBatchPairs; ++k) {
+      batch.p[k] = k < m ? pairs[base + k] : GridPair{};
+      GridPair &p = batch.p[k];
+      if (k >= m || p.nt == 0 || p.q_count == 0 || !p.cull_sets || !p.heavy || !p.tinv || p.qlist) p.cull_count = nullptr;
+      any = any || p.cull_count != nullptr;
+    }
+    if (!any) continue;
+    batch.cap2 = cap2;
+    batch.light_rows = c->grid_light_rows;
+    const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * 8 / std::max(1, m));      // listed sets are strided over (every block's loop ends at the count)
+    const bool per_launch = c->prof && !c->prof_totals;
+    if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+    ProfScope ps(c, MVR_K_NN_WIDE, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    if (fma) hipLaunchKernelGGL((nn_grid_set_kernel<true>), dim3(blocks_x, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals);
+    else hipLaunchKernelGGL((nn_grid_set_kernel<false>), dim3(blocks_x, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals);
     MVR_HIP_TRY(c, hipGetLastError());
   }
   return MVR_OK;

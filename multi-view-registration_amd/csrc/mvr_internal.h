@@ -187,6 +187,7 @@ struct Ctx {
   int grid_lanes = 1;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
   int grid_cluster = 8;                                  // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
   int grid_wide_waves = 32;                              // waves per CU of the wave-per-query launch
+  int grid_sets = 1;                                     // 1: the listed query sets of a seeded forward pass are answered over the grid (nn_grid_set_kernel), 0: by the culled kernel over the set list
   int cull_list = 1;                                     // 1: the grid search lists the query sets it flags and the culled kernel walks that list (0: a block per set, most of which leave at once)
   uint32_t *bcull_sets = nullptr; size_t bcull_sets_cap = 0;
   int cull_list_w = 2;                                   // waves per query set of the set-list launch of the culled kernel (1, 2 or 4)
@@ -367,7 +368,7 @@ struct GridPair {
   uint32_t q_begin = 0, q_count = 0;
   const float4 *gts = nullptr;                // target: posed coordinates in GRID order (w = original index)
   const float4 *ts = nullptr;                 // target in Hilbert order (only to price the seed: the previous match's position)
-  const uint32_t *start = nullptr, *g2h = nullptr, *h2g = nullptr;
+  const uint32_t *start = nullptr, *g2h = nullptr, *h2g = nullptr, *tinv = nullptr;      // (tinv: original index -> Hilbert position in the searched cloud)
   const uint8_t *dt = nullptr;
   float lo[3] = {0, 0, 0}, inv_h = 1.f, h = 1.f;
   int dim[3] = {1, 1, 1};
@@ -391,7 +392,8 @@ constexpr int kGridDtMax = 12;        // most dilation steps of the distance map
 constexpr int kGridLightRows = 12;    // default number of rows of cells (x-runs) a thread walks by itself (measured on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
 struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
-int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the queries the first launch put on the wide lists
+int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
+int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the 64-query sets the first launch listed (flagged queries only): a block per set over the grid     // the queries the first launch put on the wide lists
 // the set's grid (built from `canon`, a cloud holding the set's canonical coordinates) and the posed copy's grid-ordered
 // coordinates; false = not available (the caller uses the culled kernel)
 int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo xyz, hi xyz} on the host (synchronises the stream)
