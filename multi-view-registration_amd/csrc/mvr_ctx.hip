@@ -867,7 +867,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -1000,15 +1000,20 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
         }
         std::fprintf(stderr, "[grid] forward: %zu queries, %zu to a wave each, %zu to the culled kernel in %zu sets\n", off_s[n_pairs], wide, cull, sets);
       }
+      const bool sets_on_grid = c->cull_list && c->grid_lanes == 1 && c->grid_sets;
+      if (c->grid_wide && sets_on_grid && c->grid_tail) {           // the wide queries and the listed sets in ONE launch
+        if (int rc = launch_nn_grid_tail_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc;
+      } else {
       if (c->grid_wide) { if (int rc = launch_nn_grid_wide_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc; }
       // ... and the queries it flagged, in place (blocks without a flagged query leave at once)
       for (int k = 0; k < n_pairs; ++k) {
         fwd[k].qflags = qn[k] ? w->bheavy + off_s[k] : nullptr;
         fwd[k].setlist = gfwd[k].cull_sets; fwd[k].setcount = gfwd[k].cull_count;
       }
-      if (c->cull_list && c->grid_lanes == 1 && c->grid_sets) { if (int rc = launch_nn_grid_sets_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc; }
+      if (sets_on_grid) { if (int rc = launch_nn_grid_sets_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc; }
       else if (c->cull_list && c->grid_lanes == 1) { if (int rc = launch_nn_cull_list_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc; }
       else if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
+      }
     } else if (int rc = launch_nn_cull_batch(w, fwd.data(), n_pairs, cap2, fma != 0)) return rc;
   }
   if (!(phases & 2)) return MVR_OK;
@@ -1475,6 +1480,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "grid_debug")) c->grid_debug = value != 0;
   else if (!std::strcmp(key, "cull_list")) c->cull_list = value != 0;
   else if (!std::strcmp(key, "grid_sets")) c->grid_sets = value != 0;
+  else if (!std::strcmp(key, "grid_tail")) c->grid_tail = value != 0;
   else if (!std::strcmp(key, "cull_list_w")) { if (value != 1 && value != 2 && value != 4) return MVR_E_ARG; c->cull_list_w = value; }
   else if (!std::strcmp(key, "grid_cluster")) { if (value < 1) return MVR_E_ARG; c->grid_cluster = value; }
   else if (!std::strcmp(key, "grid_wide_waves")) { if (value < 1 || value > 64) return MVR_E_ARG; c->grid_wide_waves = value; }

@@ -320,16 +320,16 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
 // its whole wave up: a wave is as slow as its slowest lane).
 constexpr int kWideWaves = 4;      // waves per block
 template <bool FMA>
-__global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+__device__ __forceinline__ void nn_grid_wide_body(const GridBatch &batch, unsigned long long *__restrict__ evals, const uint32_t bx, const uint32_t nbx)
 {
   const GridPair &a = batch.p[blockIdx.y];
   if (!a.wide_count) return;
   __shared__ uint32_t row_s[kWideWaves][64], row_off[kWideWaves][65];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t n_wide = *a.wide_count, stride = gridDim.x * kWideWaves;
+  const uint32_t n_wide = *a.wide_count, stride = nbx * kWideWaves;
   const float cap2 = batch.cap2;
   unsigned long long n_eval = 0;
-  for (uint32_t i = blockIdx.x * kWideWaves + wv; i < n_wide; i += stride) {
+  for (uint32_t i = bx * kWideWaves + wv; i < n_wide; i += stride) {
     const uint32_t pos = a.wide_list[i];
     const uint32_t qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;
     const float4 q = a.qs[qpos];
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch
     }
   }
   if (evals && lane == 0 && n_eval) {
-    unsigned long long *s = evals + (size_t)((blockIdx.x * kWideWaves + wv) & (kEvalShards - 1)) * kEvalStride;
+    unsigned long long *s = evals + (size_t)((bx * kWideWaves + wv) & (kEvalShards - 1)) * kEvalStride;
     atomicAdd(s, n_eval);
     atomicAdd(s + kEvalRegion, n_eval);
   }
@@ -583,6 +583,12 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
   return MVR_OK;
 }
 
+template <bool FMA>
+__global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+{
+  nn_grid_wide_body<FMA>(batch, evals, blockIdx.x, gridDim.x);
+}
+
 // ---- the listed query sets (flagged queries: the rim of the overlap, matches that lie far): ONE BLOCK per set.  The
 // culled kernel answered these by walking its box hierarchy -- some fifty dependent loads per wave, 40 us for a set
 // whatever the number of waves, a latency chain.  With a grid the candidates are an address computation here too: the
@@ -593,7 +599,7 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
 constexpr int kSetRows = 512;        // rows of cells staged per round
 constexpr int kSetPoints = 768;      // points staged per round (the shared arrays stay under 20 KB: eight blocks per CU)
 template <bool FMA>
-__global__ void __launch_bounds__(256, 8) nn_grid_set_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+__device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigned long long *__restrict__ evals, const uint32_t bx, const uint32_t nbx)
 {
   const GridPair &a = batch.p[blockIdx.y];
   if (!a.cull_count) return;
@@ -606,7 +612,7 @@ __global__ void __launch_bounds__(256, 8) nn_grid_set_kernel(GridBatch batch, un
   const float cap2 = batch.cap2;
   const uint32_t n_sets = *a.cull_count;
   unsigned long long n_eval = 0;
-  for (uint32_t si = blockIdx.x; si < n_sets; si += gridDim.x) {
+  for (uint32_t si = bx; si < n_sets; si += nbx) {
     const uint32_t set = a.cull_sets[si];
     // ---- the set's queries (wave 0): bound, ball in cells, union of the flagged ones
     bool valid = false;
@@ -725,10 +731,56 @@ __global__ void __launch_bounds__(256, 8) nn_grid_set_kernel(GridBatch batch, un
     __syncthreads();                                // lq / ubox / lbest are reused by the next set
   }
   if (evals && lane == 0 && n_eval) {
-    unsigned long long *sh = evals + (size_t)((blockIdx.x * 4u + (uint32_t)wv) & (kEvalShards - 1)) * kEvalStride;
+    unsigned long long *sh = evals + (size_t)((bx * 4u + (uint32_t)wv) & (kEvalShards - 1)) * kEvalStride;
     atomicAdd(sh, n_eval * 16ull);      // every staged point is evaluated by the 64 lanes of one of the four waves
     atomicAdd(sh + kEvalRegion, n_eval * 16ull);
   }
+}
+
+template <bool FMA>
+__global__ void __launch_bounds__(256, 8) nn_grid_set_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+{
+  nn_grid_set_body<FMA>(batch, evals, blockIdx.x, gridDim.x);
+}
+
+// both stragglers' launches in one: the first `wide_blocks` blocks of a pair give the wide bounded queries a wave each,
+// the others take the listed query sets -- neither waits for the other (two launches of 8 and 24 us ran one after the other)
+static_assert(64 * kWideWaves == 256, "the two bodies share a block shape");
+template <bool FMA>
+__global__ void __launch_bounds__(256, 8) nn_grid_tail_kernel(GridBatch batch, unsigned long long *__restrict__ evals, uint32_t wide_blocks)
+{
+  if (blockIdx.x < wide_blocks) nn_grid_wide_body<FMA>(batch, evals, blockIdx.x, wide_blocks);
+  else nn_grid_set_body<FMA>(batch, evals, blockIdx.x - wide_blocks, gridDim.x - wide_blocks);
+}
+
+// wide bounded queries and listed sets of the same pairs in one launch
+int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma)
+{
+  for (int base = 0; base < n_pairs; base += kGridBatchPairs) {
+    GridBatch batch;
+    const int m = std::min(kGridBatchPairs, n_pairs - base);
+    bool any = false;
+    for (int k = 0; k < kGridBatchPairs; ++k) {
+      batch.p[k] = k < m ? pairs[base + k] : GridPair{};
+      GridPair &p = batch.p[k];
+      const bool live = k < m && p.nt != 0 && p.q_count != 0;
+      if (!live || !p.wide_list) p.wide_count = nullptr;
+      if (!live || !p.cull_sets || !p.heavy || !p.tinv || p.qlist) p.cull_count = nullptr;
+      any = any || p.wide_count != nullptr || p.cull_count != nullptr;
+    }
+    if (!any) continue;
+    batch.cap2 = cap2;
+    batch.light_rows = c->grid_light_rows;
+    const unsigned wide_blocks = (unsigned)std::max(1, c->n_cu * c->grid_wide_waves / (std::max(1, m) * kWideWaves * 4));
+    const unsigned set_blocks = (unsigned)std::max(1, c->n_cu * 8 / std::max(1, m));
+    const bool per_launch = c->prof && !c->prof_totals;
+    if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+    ProfScope ps(c, MVR_K_NN_WIDE, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+    if (fma) hipLaunchKernelGGL((nn_grid_tail_kernel<true>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals, wide_blocks);
+    else hipLaunchKernelGGL((nn_grid_tail_kernel<false>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals, wide_blocks);
+    MVR_HIP_TRY(c, hipGetLastError());
+  }
+  return MVR_OK;
 }
 
 int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma)

@@ -187,6 +187,7 @@ struct Ctx {
   int grid_lanes = 1;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
   int grid_cluster = 8;                                  // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
   int grid_wide_waves = 32;                              // waves per CU of the wave-per-query launch
+  int grid_tail = 1;                                     // 1: the wave-per-query launch and the listed-sets launch of a forward pass are one launch
   int grid_sets = 1;                                     // 1: the listed query sets of a seeded forward pass are answered over the grid (nn_grid_set_kernel), 0: by the culled kernel over the set list
   int cull_list = 1;                                     // 1: the grid search lists the query sets it flags and the culled kernel walks that list (0: a block per set, most of which leave at once)
   uint32_t *bcull_sets = nullptr; size_t bcull_sets_cap = 0;
@@ -393,6 +394,7 @@ constexpr int kGridLightRows = 12;    // default number of rows of cells (x-runs
 struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
+int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the two launches below in one
 int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the 64-query sets the first launch listed (flagged queries only): a block per set over the grid     // the queries the first launch put on the wide lists
 // the set's grid (built from `canon`, a cloud holding the set's canonical coordinates) and the posed copy's grid-ordered
 // coordinates; false = not available (the caller uses the culled kernel)
