@@ -1000,7 +1000,16 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
         }
         std::fprintf(stderr, "[grid] forward: %zu queries, %zu to a wave each, %zu to the culled kernel in %zu sets\n", off_s[n_pairs], wide, cull, sets);
       }
-      const bool sets_on_grid = c->cull_list && c->grid_lanes == 1 && c->grid_sets;
+      // the listed sets: over the grid (a block per set stages the union of the flagged balls) while that union is a few
+      // hundred rows of cells -- with dense scans (small cells) it is thousands of points per set and the culled kernel's
+      // box hierarchy is the better tool again (36 x 1M: 5.9 ms per pass against 6.4).  grid_sets = 2 forces the grid.
+      bool sets_on_grid = c->cull_list && c->grid_lanes == 1 && c->grid_sets;
+      if (sets_on_grid && c->grid_sets == 1)
+        for (int k = 0; k < n_pairs && sets_on_grid; ++k) {
+          if (!qn[k]) continue;
+          const double span = (2.0 * max_dist + 4.0) / (double)c->slots[dst[k]].grid->h;      // cells across a rim set's union, roughly
+          sets_on_grid = span * span <= 300.0;
+        }
       if (c->grid_wide && sets_on_grid && c->grid_tail) {           // the wide queries and the listed sets in ONE launch
         if (int rc = launch_nn_grid_tail_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc;
       } else {
@@ -1479,7 +1488,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;
   else if (!std::strcmp(key, "grid_debug")) c->grid_debug = value != 0;
   else if (!std::strcmp(key, "cull_list")) c->cull_list = value != 0;
-  else if (!std::strcmp(key, "grid_sets")) c->grid_sets = value != 0;
+  else if (!std::strcmp(key, "grid_sets")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_sets = value; }
   else if (!std::strcmp(key, "grid_tail")) c->grid_tail = value != 0;
   else if (!std::strcmp(key, "cull_list_w")) { if (value != 1 && value != 2 && value != 4) return MVR_E_ARG; c->cull_list_w = value; }
   else if (!std::strcmp(key, "grid_cluster")) { if (value < 1) return MVR_E_ARG; c->grid_cluster = value; }

@@ -188,7 +188,7 @@ struct Ctx {
   int grid_cluster = 8;                                  // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
   int grid_wide_waves = 32;                              // waves per CU of the wave-per-query launch
   int grid_tail = 1;                                     // 1: the wave-per-query launch and the listed-sets launch of a forward pass are one launch
-  int grid_sets = 1;                                     // 1: the listed query sets of a seeded forward pass are answered over the grid (nn_grid_set_kernel), 0: by the culled kernel over the set list
+  int grid_sets = 1;                                     // the listed query sets of a seeded forward pass: 1 = over the grid (nn_grid_set_kernel) while a set's union of balls is a few hundred rows of cells, 2 = always over the grid, 0 = by the culled kernel over the set list
   int cull_list = 1;                                     // 1: the grid search lists the query sets it flags and the culled kernel walks that list (0: a block per set, most of which leave at once)
   uint32_t *bcull_sets = nullptr; size_t bcull_sets_cap = 0;
   int cull_list_w = 2;                                   // waves per query set of the set-list launch of the culled kernel (1, 2 or 4)
