@@ -394,7 +394,10 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * cell the cell edge aims at, default 4; applies to grids built afterwards), "grid_light_rows" (rows of cells a thread
  * walks itself, default 12; wider balls leave the thread-per-query walk), "grid_wide" (1, default: a wide BOUNDED query
  * gets a wave of its own; 0: flagged for the culled kernel), "grid_cluster" (a wave of the walk with at least this many
- * wide queries hands them all to the culled kernel, default 8; 65: never), "cull_list" (1, default: the culled kernel
+ * wide queries hands them all to the culled kernel, default 8; 65: never), "grid_sets" (1, default: the 64-query
+ * sets that hold a flagged query are answered a block per set over the grid while a set's union of balls is a few hundred
+ * rows of cells; 2: always; 0: by the culled kernel over the set list), "grid_tail" (1, default: that launch and the
+ * wave-per-query launch of a forward pass are one launch), "cull_list" (1, default: the culled kernel
  * visits only the query sets the walk listed; 0: a block per set), "cull_list_w" (waves per listed set: 1, 2, 4),
  * "grid_lanes" (lanes sharing a query: 1 (default), 2, 4, 8), "grid_wide_waves" (waves per CU of the wave-per-query
  * launch), "fused_mark" (1, default: the forward searches record the start bounds of the reverse searches themselves when
