@@ -186,3 +186,28 @@ def test_config5_fused_step_36x1M_properties(mvr, ring):
         _, info2 = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, new, max_d, origin)
         n1 = sum(info2["pair_n"]); mse1 = sum(a * b for a, b in zip(info2["pair_n"], info2["pair_mse"])) / n1
         assert n1 > n0 and mse1 < mse0
+
+
+def test_config4_full_size_ring_every_search_route_gives_the_same_tables(mvr):
+    """BASELINE configs[3] at full size, 12 x 200k: thirty passes from the mis-calibrated prior give the same poses and
+    the same 12 x 32 edge table, bit for bit, whichever exact search answers which query -- the culled kernel alone
+    (ring_search 0), the grid walk with its stragglers on the grid (default), with the listed sets on the culled kernel,
+    with separate straggler launches, with the marks set by a separate launch."""
+    V, N, max_d = 12, 200000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for knobs in ({}, dict(ring_search=0), dict(grid_sets=0), dict(grid_sets=2, grid_tail=0, fused_mark=0), dict(grid_wide=0, pair_groups=1)):
+        with mvr.Context(0) as ctx:
+            ctx.tune(**knobs)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=30)
+            runs.append((np.asarray(poses).tobytes(), info["rows"].tobytes(), sum(info["pair_n"])))
+    assert runs[0][2] > 900000
+    for r in runs[1:]:
+        assert r == runs[0]
