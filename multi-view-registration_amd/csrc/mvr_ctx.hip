@@ -139,15 +139,23 @@ void note_pose(Cloud &dst, const Cloud &src, bool src_canonical, const double T[
   dst.canonical = false; dst.pose_known = false;
   if (!src_canonical || &dst == &src) return;
   if (T[3] != 0.0 || T[7] != 0.0 || T[11] != 0.0 || T[15] != 1.0) return;
-  // rigid to within FLOAT rounding: the poses of a registration are products with PCL-style float 4x4s
-  // (lum.getTransformation is an Eigen::Affine3f), orthonormal to ~1e-7 only.  The search maps its queries with the true
-  // inverse of the 3x3 (make_grid_pair), so what is left of the non-rigidity is a relative distortion of distances of
-  // that size, inside the search ball's relative margin (1e-5).
+  // NEARLY rigid: the poses of a registration are products with PCL-style float 4x4s (lum.getTransformation is an
+  // Eigen::Affine3f), each orthonormal to ~1e-7 only, and the product of a few hundred of them is off by 1e-5 and more
+  // (a 2e-6 bar here silently sent every pass after the ~200th back to the culled kernel).  The search maps its queries
+  // with the TRUE inverse of the 3 x 3 (make_grid_pair), which is right for any invertible matrix; what rigidity buys is
+  // that a ball stays a ball.  With G = A^T A and e = |G - I|_F the smallest singular value of A is at least
+  // sqrt(1 - e) (Weyl), so the inverse lengthens no distance by more than 1 / sqrt(1 - e): the search widens its ball by
+  // that factor.  Accepted up to e = 1e-3 (a ball 0.05 % wider); beyond that the scan is simply not grid-searched.
+  double e2 = 0.0;
   for (int a = 0; a < 3; ++a)
-    for (int b = a; b < 3; ++b) {
+    for (int b = 0; b < 3; ++b) {
       const double d = T[4 * a] * T[4 * b] + T[4 * a + 1] * T[4 * b + 1] + T[4 * a + 2] * T[4 * b + 2];
-      if (std::fabs(d - (a == b ? 1.0 : 0.0)) > 2e-6) return;
+      const double x = d - (a == b ? 1.0 : 0.0);
+      e2 += x * x;
     }
+  const double e = std::sqrt(e2);
+  if (!(e <= 1e-3)) return;
+  dst.pose_stretch = 1.0 / std::sqrt(1.0 - e);
   dst.pose_known = true;
   std::memcpy(dst.pose, T, 16 * sizeof(double));
   dst.grid = src.grid;

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     // the ball in the target's canonical frame.  The mapping itself is done in double; what the margin has to cover is
     // that both clouds' posed coordinates are FLOAT roundings of the exact motion (half an ulp per coordinate and cloud:
     // 1e-4 mm at |p| ~ 1e3 mm) and the float cell arithmetic below -- scaled with the coordinates' magnitude
-    const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+    const float rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * a.stretch;
     const double qx = q.x, qy = q.y, qz = q.z;
     const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
     const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
@@ -339,7 +339,7 @@ __device__ __forceinline__ void nn_grid_wide_body(const GridBatch &batch, unsign
       const uint32_t prev = (uint32_t)a.keys[qpos];
       if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
     }
-    const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+    const float rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * a.stretch;
     const double qx = q.x, qy = q.y, qz = q.z;
     const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
     const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
@@ -523,6 +523,7 @@ GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cl
   const CellGrid &g = *t.grid;
   p.qs = q.sorted; p.q_begin = (uint32_t)q_begin; p.q_count = (uint32_t)q_count;
   p.gts = t.gsorted; p.ts = t.sorted; p.start = g.start; p.dt = g.dt; p.g2h = g.g2h; p.h2g = g.h2g; p.tinv = t.order ? t.order->inv : nullptr; p.dt_max = g.dt_steps;
+  p.stretch = std::nextafterf((float)(t.pose_stretch * (1.0 + 1e-6)), INFINITY);      // (the ball is in posed space, the cells in the canonical frame)
   for (int k = 0; k < 3; ++k) { p.lo[k] = g.lo[k]; p.dim[k] = g.dim[k]; }
   p.inv_h = g.inv_h; p.h = g.h;
   // inverse of the pose's affine map x -> A x + t (column-major 4 x 4, column-vector; A is a rotation up to float rounding:
@@ -633,7 +634,7 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
           const uint32_t prev = (uint32_t)a.keys[qpos];
           if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
         }
-        const float rad = sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+        const float rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * a.stretch;
         const double qx = q.x, qy = q.y, qz = q.z;
         const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
         const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);

@@ -93,6 +93,7 @@ struct Cloud {
   // pose bookkeeping for the grid search: `canonical` = these ARE the set's upload coordinates; otherwise, when
   // pose_known, pts = pose * (canonical coordinates of the set) exactly as mvr_cloud_transform computes it
   bool canonical = false, pose_known = false;
+  double pose_stretch = 1.0;             // with pose_known: an upper bound of how much the INVERSE pose can lengthen a distance (1 for a rigid pose; the poses of a long registration are products of float-rounded matrices and drift away from orthonormal)
   double pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::shared_ptr<CellGrid> grid;          // the set's grid (shared)
   float4 *gsorted = nullptr; size_t gsorted_cap = 0;      // posed coordinates in grid order, w = bits(original index)
@@ -380,6 +381,7 @@ struct GridPair {
   const uint32_t *qbound = nullptr;           // optional start bounds by query position (bits of a d2; ~0 = none)
   uint32_t *mark = nullptr;                   // optional: start bounds of the reverse searches, by the match's Hilbert position
   uint32_t key_by_pos = 0, seed_from_keys = 0;
+  float stretch = 1.f;                   // distances in the searched cloud's canonical frame are at most this times the posed ones (Cloud::pose_stretch, rounded up)
   int dt_max = 12;                       // what dt == 255 stands for (the grid's dt_steps)
   // a BOUNDED query whose ball is wide (scattered among the others: a match that moved far, a long correspondence) is
   // neither walked by its own thread (the wave would wait for it) nor flagged for the culled kernel (one such query

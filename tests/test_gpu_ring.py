@@ -189,7 +189,7 @@ def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
     assert runs[0] == runs[1], knobs
 
 
-@pytest.mark.parametrize("case", ["fma", "sheared_pose", "sub_ranges"])
+@pytest.mark.parametrize("case", ["fma", "sheared_pose", "slightly_sheared_pose", "sub_ranges"])
 def test_grid_search_equals_culled_search_off_the_main_road(mvr, case):
     """ring_search 1 == ring_search 0, bit for bit, also (a) with the fused multiply-add form of the distance, (b) when a
     view's pose is not rigid (a sheared matrix: the grid of that scan cannot be mapped into by an inverse pose, the
@@ -201,6 +201,8 @@ def test_grid_search_equals_culled_search_off_the_main_road(mvr, case):
     poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
     if case == "sheared_pose":
         poses0[5] = poses0[5].copy(); poses0[5][0, 1] += 3e-3
+    if case == "slightly_sheared_pose":          # within the bar: the grid is used, with a ball widened by the pose's stretch
+        poses0[5] = poses0[5].copy(); poses0[5][0, 1] += 2e-4; poses0[7] = poses0[7].copy(); poses0[7][:3, :3] *= 1.0003
     origin = np.array(sp.pivot)
     edges = [(i, (i + 1) % V) for i in range(V)]
     runs = []
@@ -226,6 +228,37 @@ def test_grid_search_equals_culled_search_off_the_main_road(mvr, case):
                     log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
             runs.append(log)
     assert runs[0] == runs[1], case
+
+
+def test_grid_search_survives_the_drift_of_a_long_registration(mvr):
+    """The poses of pass k are products of k float-rounded LUM matrices: after a few hundred passes they are off
+    orthonormal by 1e-5 and more.  The grid search must neither give up (a 2e-6 rigidity bar once sent every pass after
+    the ~200th back to the culled kernel, unnoticed: same results, twice the time) nor lose a neighbour: 600 passes of
+    the 12 x 20k ring end in the same poses and table, bit for bit, with and without it, and the last pass still runs
+    on the grid kernels."""
+    V, N, max_d = 12, 20000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for mode in (0, 1):
+        with mvr.Context(0) as ctx:
+            ctx.tune(ring_search=mode)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=600)
+            ctx.prof_reset(); ctx.prof_enable(1)
+            poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin, steps=1)
+            ctx.prof_enable(False)
+            grid_launches = ctx.prof_get(mvr.K_NN_GRID)[0]
+            assert (grid_launches > 0) == (mode == 1), (mode, grid_launches)
+            runs.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+            drift = max(np.abs(np.asarray(p)[:3, :3].T @ np.asarray(p)[:3, :3] - np.eye(3)).max() for p in poses)
+            assert drift > 2e-6 or mode == 0, drift          # (the case this test is about did occur)
+    assert runs[0] == runs[1]
 
 
 def test_transform_batch_equals_single_transforms(gpu, mvr):
