@@ -261,6 +261,44 @@ def test_grid_search_survives_the_drift_of_a_long_registration(mvr):
     assert runs[0] == runs[1]
 
 
+def test_grid_search_through_the_events_of_a_session(mvr):
+    """ring_search 1 == ring_search 0, pass by pass, through what a session does between passes: scans of different
+    sizes, a scan uploaded again (its grid goes with the old point set), a different search radius (the distance map
+    was built for the first one), a different set of pairs (no seeds for that pass), a view posed by hand."""
+    V, max_d = 8, 4.0
+    sp = mvr.synth_params(V, 3)
+    sizes = [15000 - 1700 * v for v in range(V)]
+    scans = [mvr.synth_view(sp, v, sizes[v]) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    ring = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for mode in (0, 1):
+        with mvr.Context(0) as ctx:
+            ctx.tune(ring_search=mode)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, log = [p.copy() for p in poses0], []
+            for k in range(12):
+                edges, md = ring, max_d
+                if k == 3:
+                    ctx.upload(V + 2, scans[2])                                   # the same scan again: a new point set
+                if k == 5:
+                    ctx.upload(V + 4, scans[4][: sizes[4] - 999])                 # ... and a shorter one
+                if k in (6, 7):
+                    md = 7.5                                                      # wider than the distance map was built for
+                if k == 8:
+                    edges = [(b, a) for a, b in ring]                             # other pairs: nothing to seed from
+                if k == 10:
+                    poses[3] = mvr.axis_rotation(piv, ax, mvr.turntable_angle(3, V) + 2e-3)
+                poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, md, origin)
+                log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+            runs.append(log)
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert a == b, k
+
+
 def test_transform_batch_equals_single_transforms(gpu, mvr):
     """mvr_cloud_transform_batch poses many clouds in one launch, bit for bit like mvr_cloud_transform."""
     g = load_golden("ring_12x2048.npz")
