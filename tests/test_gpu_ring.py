@@ -299,6 +299,48 @@ def test_grid_search_through_the_events_of_a_session(mvr):
         assert a == b, k
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_grid_search_equals_culled_search_on_odd_rings(mvr, seed):
+    """ring_search 1 == ring_search 0 over six passes on rings nobody would scan: empty and one-point views, views of
+    63 / 64 / 65 / 257 points, duplicated points (ties: the lowest index must win in both searches), a view that is a
+    line, views that barely overlap, radii from a tenth of the point spacing to the whole object."""
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.integers(3, 7))
+    sp = mvr.synth_params(V, 3)
+    piv, ax = mvr.synth_prior(sp)
+    sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 257, 1500, 4000, 9000])) for _ in range(V)]
+    sizes[int(rng.integers(V))] = 6000                                    # at least one real view
+    scans = []
+    for v in range(V):
+        c = mvr.synth_view(sp, v, max(sizes[v], 1))[: sizes[v]].copy()
+        if len(c) > 10 and rng.random() < 0.5:                               # duplicates, some of them many times over
+            k = int(rng.integers(1, len(c) // 3 + 1))
+            c[rng.integers(0, len(c), k)] = c[rng.integers(0, len(c), 1)]
+            c[-k:] = c[:k]
+        if len(c) > 100 and rng.random() < 0.2:                              # a line
+            c[:, 1] = c[0, 1]; c[:, 2] = c[0, 2]
+        scans.append(c)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V) + float(rng.normal(0, 2e-3))) for v in range(1, V)]
+    max_d = float(rng.choice([0.05, 0.5, 4.0, 25.0, 300.0]))
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)] + ([(0, 2)] if rng.random() < 0.5 else [])
+    runs = []
+    for mode in (0, 1):
+        with mvr.Context(0) as ctx:
+            ctx.tune(ring_search=mode)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, log = [p.copy() for p in poses0], []
+            for _ in range(6):
+                ctx.transform_batch(list(range(V)), [V + v for v in range(V)], poses)
+                rows = ctx.pair_moments2_batch(edges, max_d, origin)
+                log.append(b"".join(bytes(r) for r in rows))
+                poses = [p @ mvr.axis_rotation(piv, ax, float(rng.normal(0, 1e-4))) if i else p for i, p in enumerate(poses)] if mode < 0 else \
+                        [poses[i] if i == 0 else mvr.axis_rotation(piv, ax, mvr.turntable_angle(i, V) + 1e-4 * (len(log) + i)) for i in range(V)]
+            runs.append(log)
+    assert runs[0] == runs[1], (seed, sizes, max_d)
+
+
 def test_transform_batch_equals_single_transforms(gpu, mvr):
     """mvr_cloud_transform_batch poses many clouds in one launch, bit for bit like mvr_cloud_transform."""
     g = load_golden("ring_12x2048.npz")
