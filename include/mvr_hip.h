@@ -205,6 +205,13 @@ int  mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src_slots, co
                              const size_t *q_count, const double origin[3],
                              mvr_pair_moments2_t *out, double *dev_out);
 
+/* The accepted correspondences of pair k of the LAST fused mvr_pair_moments2_batch / mvr_ring_step on this context (the
+ * culled / grid search with pair_fused, the default), as determineReciprocalCorrespondences lists them for that pair
+ * (registrator.cpp:496-502, :644-649): ascending query index, squared distances; *m = number found (may exceed cap).
+ * Read back from the keys the batch left on the device: valid until the next batch or any change of the pair's clouds
+ * (MVR_E_ARG then).  What computeError shows and what the tests compare with the oracle's lists pair by pair. */
+int  mvr_pair_batch_correspondences(mvr_ctx *ctx, int k, int32_t *query, int32_t *match, float *dist2, size_t cap, size_t *m);
+
 /* ---- target sharding over ranks (sequential mode, registrator.cpp:563-577, is loop-carried and does not
  * shard by pair: the growing TARGET is split by points, every rank holds the full source).  A target slot
  * can be a shard: mvr_cloud_set_global_base / mvr_cloud_append_range record which GLOBAL point numbers its

@@ -141,6 +141,7 @@ SIGNATURES = {
     "mvr_pair_moments2_batch": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, C.c_int,
                                           C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _dp,
                                           C.POINTER(PairMoments2), _vp]),
+    "mvr_pair_batch_correspondences": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _fp, _sz, C.POINTER(_sz)]),
     "mvr_pair_moments2_from_corr": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _sz, _dp,
                                               C.POINTER(PairMoments2)]),
     "mvr_umeyama_from_moments": (C.c_int, [C.POINTER(PairMoments), _fp, _dp]),
@@ -501,6 +502,14 @@ class Context:
                                       C.byref(cnt)), self._h)
         k = cnt.value
         return q[:k].copy(), m[:k].copy(), d[:k].copy()
+
+    def pair_batch_correspondences(self, k, cap):
+        """(query, match, d2) of pair k of the last fused batch / ring step (mvr_pair_batch_correspondences)"""
+        q, m, d = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32)
+        cnt = _sz()
+        _chk(_lib.mvr_pair_batch_correspondences(self._h, int(k), _p(q, C.c_int32), _p(m, C.c_int32), _p(d, C.c_float), cap, C.byref(cnt)), self._h)
+        n = min(cnt.value, cap)
+        return q[:n].copy(), m[:n].copy(), d[:n].copy()
 
     def pair_moments(self, s, t, max_dist, reciprocal=True, fma=False) -> PairMoments:
         out = PairMoments()

@@ -570,7 +570,7 @@ API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
   }
   d.n = s.n;
   inherit_point_set(d, s);
-  d.canonical = s.canonical; d.pose_known = s.pose_known; std::memcpy(d.pose, s.pose, sizeof d.pose); d.grid = s.grid;
+  d.canonical = s.canonical; d.pose_known = s.pose_known; d.pose_stretch = s.pose_stretch; std::memcpy(d.pose, s.pose, sizeof d.pose); d.grid = s.grid;
   d.segs = s.segs;
   d.has_normals = false;
   if (s.has_normals && s.n) {
@@ -601,7 +601,11 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
     MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     // a different point set.  Its ordering: the old one extended by the appended scan's own (the points that were
     // there did not move: registrator.cpp:576 only ever appends), or -- when that is not possible -- rebuilt on next use
-    if (!(dst != src && d.segs.empty() && extend_point_set(c, d, d.n, s))) new_point_set(c, d);
+    if (dst != src && d.segs.empty() && extend_point_set(c, d, d.n, s)) {
+      // a different point set all the same: what it is now DEFINES it (as new_point_set says for the other branch); a pose
+      // or a grid of the set it grew from is not its own
+      d.canonical = true; d.pose_known = false; d.pose_stretch = 1.0; d.grid.reset(); d.gcoords_valid = false;
+    } else new_point_set(c, d);
     // normals survive only if both parts carry them
     const bool keep = s.has_normals && (d.has_normals || d.n == 0);
     if (keep) {
@@ -890,7 +894,8 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
 // phases: bit 0 = the forward searches, bit 1 = everything after them (so that the forward launches of several
 // groups can all be enqueued before any group's long tail of small launches).
 static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const int *dst, double max_dist, int reciprocal, int fma,
-                            const size_t *q_begin, const size_t *q_count, const double origin[3], double *table, int phases = 3)
+                            const size_t *q_begin, const size_t *q_count, const double origin[3], double *table, int phases = 3,
+                            int pair_base = 0)
 {
   std::vector<size_t> off_s((size_t)n_pairs + 1, 0), off_t((size_t)n_pairs + 1, 0), off_p((size_t)n_pairs + 1, 0), qb((size_t)n_pairs), qn((size_t)n_pairs);
   for (int k = 0; k < n_pairs; ++k) {
@@ -919,6 +924,12 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   uint32_t *counts = w->bchunks + off_c[n_pairs];
   const double max2 = max_dist * max_dist;
   const float cap2 = cap_from_max2(max2);
+  if ((phases & 2) && c->last_batch.size() >= (size_t)(pair_base + n_pairs))
+    for (int k = 0; k < n_pairs; ++k) {
+      BatchPairRec &r = c->last_batch[(size_t)(pair_base + k)];
+      r.w = w; r.off_s = off_s[k]; r.off_t = off_t[k]; r.qb = qb[k]; r.qn = qn[k]; r.src = src[k]; r.dst = dst[k]; r.max2 = max2; r.reciprocal = reciprocal;
+      r.src_set = c->slots[src[k]].set_id; r.dst_set = c->slots[dst[k]].set_id;
+    }
   // Do the forward keys left in bkeys[] by the previous fused pass on this context belong to the very same searches
   // (same point sets in the same order -- a posed copy keeps its scan's set id and ordering --, same query ranges,
   // same layout)?  Then every forward search starts from the distance of its previous match (seed_from_keys): the
@@ -1122,6 +1133,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     // (only when there are pairs to spare: with fewer than four per group the second stream just doubles the launches --
     // measured on 2 / 3 / 4 / 6 pairs of 200k: equal or up to 4 % slower)
     const int G = (n_pairs >= 4 * c->pair_groups) ? c->pair_groups : 1;
+    c->last_batch.assign((size_t)n_pairs, BatchPairRec());
     if (G == 1) {
       if (int rc = pair_batch_fused(c, c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
     } else {
@@ -1146,7 +1158,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
             }
           }
           status = pair_batch_fused(c, w, hi - lo, src + lo, dst + lo, max_dist, reciprocal, fma, q_begin ? q_begin + lo : nullptr,
-                                    q_count ? q_count + lo : nullptr, origin, table + (size_t)lo * 32, phase);
+                                    q_count ? q_count + lo : nullptr, origin, table + (size_t)lo * 32, phase, lo);
           if (status != MVR_OK && w != c) c->last_error = w->last_error;
         }
       for (int g = 1; g <= forked; ++g) {                            // join, always
@@ -1165,6 +1177,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     }
     return MVR_OK;
   }
+  c->last_batch.clear();
   if (!c->ev_fork) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   MVR_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
   int status = MVR_OK;
@@ -1194,6 +1207,64 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < n_pairs; ++k) std::memcpy(&out[k], &h[(size_t)k * 32], sizeof(mvr_pair_moments2_t));
   }
+  return MVR_OK;
+}
+
+// The accepted correspondences of pair k of the last fused batch, read back from where its searches left them: the forward
+// keys live in sorted space (slot = the query's Hilbert position, low word = the match's Hilbert position), the reverse
+// keys by list position with the ORIGINAL index of the source point they found.  Acceptance as the filter + sums launch
+// decides it (accept_moments2_body): a match within max2 whose target's reverse search, also within max2, names the query.
+API int mvr_pair_batch_correspondences(mvr_ctx *ctx, int k, int32_t *query, int32_t *match, float *dist2, size_t cap, size_t *m)
+{
+  if (!ctx || !m) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  *m = 0;
+  if (k < 0 || (size_t)k >= c->last_batch.size() || !c->last_batch[(size_t)k].w)
+    return set_error(c, MVR_E_ARG, "no fused batch on this context holds that pair (culled mode with pair_fused only)");
+  const BatchPairRec r = c->last_batch[(size_t)k];
+  const Cloud &s = c->slots[r.src], &t = c->slots[r.dst];
+  if (s.set_id != r.src_set || t.set_id != r.dst_set || !s.order || !t.order)
+    return set_error(c, MVR_E_ARG, "the clouds of that pair have changed since the batch");
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  if (r.qn == 0) return MVR_OK;
+  Ctx *w = r.w;
+  const size_t ns = s.n, nt = t.n;
+  std::vector<nnkey_t> keys(r.qn), rkeys(nt);
+  std::vector<uint32_t> slot(nt), sperm(ns), tperm(nt);
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (w != c) MVR_HIP_TRY(c, hipStreamSynchronize(w->stream));
+  MVR_HIP_TRY(c, hipMemcpy(keys.data(), w->bkeys + r.off_s + r.qb, r.qn * sizeof(nnkey_t), hipMemcpyDeviceToHost));
+  MVR_HIP_TRY(c, hipMemcpy(sperm.data(), s.order->perm, ns * 4, hipMemcpyDeviceToHost));
+  MVR_HIP_TRY(c, hipMemcpy(tperm.data(), t.order->perm, nt * 4, hipMemcpyDeviceToHost));
+  if (r.reciprocal) {
+    MVR_HIP_TRY(c, hipMemcpy(rkeys.data(), w->brkeys + r.off_t, nt * sizeof(nnkey_t), hipMemcpyDeviceToHost));
+    MVR_HIP_TRY(c, hipMemcpy(slot.data(), w->bslot + r.off_t, nt * 4, hipMemcpyDeviceToHost));
+  }
+  struct Rec { int32_t q, mt; uint32_t d; };
+  std::vector<Rec> acc;
+  for (size_t p = 0; p < r.qn; ++p) {
+    const nnkey_t key = keys[p];
+    const uint32_t tpos = (uint32_t)key, db = (uint32_t)(key >> 32);
+    float d; std::memcpy(&d, &db, 4);
+    if (tpos == kNone || tpos >= nt || (double)d > r.max2) continue;
+    const uint32_t qi = sperm[r.qb + p];
+    if (r.reciprocal) {
+      const uint32_t li = slot[tpos];
+      if (li >= nt) continue;
+      const nnkey_t rk = rkeys[li];
+      const uint32_t rb = (uint32_t)(rk >> 32);
+      float dr; std::memcpy(&dr, &rb, 4);
+      if ((uint32_t)rk != qi || (double)dr > r.max2) continue;
+    }
+    acc.push_back(Rec{(int32_t)qi, (int32_t)tperm[tpos], db});
+  }
+  std::sort(acc.begin(), acc.end(), [](const Rec &a, const Rec &b) { return a.q < b.q; });
+  for (size_t i = 0; i < acc.size() && i < cap; ++i) {
+    if (query) query[i] = acc[i].q;
+    if (match) match[i] = acc[i].mt;
+    if (dist2) std::memcpy(&dist2[i], &acc[i].d, 4);
+  }
+  *m = acc.size();
   return MVR_OK;
 }
 
@@ -1423,6 +1494,12 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
     c->slots[os].n = ns;
     if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
+    else {
+      // the aliased align(*source_) of registrator.cpp:920: the slot's points moved in place by a FLOAT matrix -- they are
+      // neither the set's upload coordinates nor a known f64 pose of them any more, and a grid built in the old frame
+      // must not be walked with them (the other in-place paths: mvr_cloud_transform, _f32, _batch)
+      c->slots[os].canonical = false; c->slots[os].pose_known = false; c->slots[os].pose_stretch = 1.0; c->slots[os].grid.reset();
+    }
     c->slots[os].stale_coords();
     if (c->slots[ss].has_normals && ns) {      // ICP::transformCloud rotates the source normals too
       if (int rc = ensure(c, c->slots[os].nrm, c->slots[os].nrm_cap, ns)) return rc;

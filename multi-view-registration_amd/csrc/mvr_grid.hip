@@ -139,6 +139,28 @@ __device__ __forceinline__ float gdist2(const float4 t, float qx, float qy, floa
   return r;
 }
 
+// The ball of a bounded query in the searched cloud's CANONICAL frame: centre r = minv (q, 1), radius rad.
+// What the margin has to cover (everything else is exact): the query q and the posed target points are FLOAT roundings
+// of the exact motion -- half an ulp per coordinate at the POSED magnitude (3e-5 mm at |p| ~ 1e3 mm), which the inverse
+// pose lengthens by at most `stretch`; the float distance formula (relative, the 1.00001); and the float arithmetic of
+// the cell range -- the rounding of r itself and of r -+ rad, half an ulp each at the CANONICAL magnitude.  The two
+// frames can differ by orders of magnitude (raw scans kept in a world frame 1e5 mm from the origin, posed next to it:
+// ulp(1e5) = 8e-3 mm), so each part scales with its own frame's coordinates (the second term was missing).
+struct Ball { float rx, ry, rz, rad; };
+__device__ __forceinline__ Ball grid_ball(const GridPair &a, const float4 q, const float bound)
+{
+  const double *mi = a.pose_dev ? a.pose_dev->minv : a.minv;
+  const float stretch = a.pose_dev ? a.pose_dev->stretch : a.stretch;
+  const double qx = q.x, qy = q.y, qz = q.z;
+  Ball b;
+  b.rx = (float)(((mi[0] * qx + mi[1] * qy) + mi[2] * qz) + mi[3]);
+  b.ry = (float)(((mi[4] * qx + mi[5] * qy) + mi[6] * qz) + mi[7]);
+  b.rz = (float)(((mi[8] * qx + mi[9] * qy) + mi[10] * qz) + mi[11]);
+  b.rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * stretch +
+          2.0e-6f * (fabsf(b.rx) + fabsf(b.ry) + fabsf(b.rz));
+  return b;
+}
+
 constexpr int kGridThreads = 256;
 #ifndef MVR_GRID_ROW4
 #define MVR_GRID_ROW4 1
@@ -173,14 +195,9 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       const uint32_t prev = (uint32_t)a.keys[qpos];
       if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }      // (the same point, read from the array the walk is about to read)
     }
-    // the ball in the target's canonical frame.  The mapping itself is done in double; what the margin has to cover is
-    // that both clouds' posed coordinates are FLOAT roundings of the exact motion (half an ulp per coordinate and cloud:
-    // 1e-4 mm at |p| ~ 1e3 mm) and the float cell arithmetic below -- scaled with the coordinates' magnitude
-    const float rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * a.stretch;
-    const double qx = q.x, qy = q.y, qz = q.z;
-    const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
-    const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
-    const float rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+    // the ball in the target's canonical frame (the mapping itself is done in double)
+    const Ball ball = grid_ball(a, q, bound);
+    const float rad = ball.rad, rx = ball.rx, ry = ball.ry, rz = ball.rz;
     const int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
     const int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
     const int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
@@ -339,11 +356,8 @@ __device__ __forceinline__ void nn_grid_wide_body(const GridBatch &batch, unsign
       const uint32_t prev = (uint32_t)a.keys[qpos];
       if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
     }
-    const float rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * a.stretch;
-    const double qx = q.x, qy = q.y, qz = q.z;
-    const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
-    const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
-    const float rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+    const Ball ball = grid_ball(a, q, bound);
+    const float rad = ball.rad, rx = ball.rx, ry = ball.ry, rz = ball.rz;
     const int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
     const int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
     const int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
@@ -413,7 +427,7 @@ __device__ __forceinline__ void nn_grid_wide_body(const GridBatch &batch, unsign
 bool ensure_grid(Ctx *c, Cloud &canon, double reach)
 {
   const size_t n = canon.n;
-  if (!canon.canonical || n == 0 || n > 0xFFFFFFF0ull) return false;
+  if (!canon.canonical || n == 0 || n > 0x7FFFFFFFull) return false;      // (hipCUB's sort takes an int count; the caller falls back to the culled kernel)
   if (canon.grid && canon.grid->n == n) return true;
   canon.grid.reset();
   auto it = c->grids.find(canon.set_id);
@@ -634,11 +648,8 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
           const uint32_t prev = (uint32_t)a.keys[qpos];
           if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
         }
-        const float rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * a.stretch;
-        const double qx = q.x, qy = q.y, qz = q.z;
-        const float rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
-        const float ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
-        const float rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+        const Ball ball = grid_ball(a, q, bound);
+        const float rad = ball.rad, rx = ball.rx, ry = ball.ry, rz = ball.rz;
         c0[0] = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]); c1[0] = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
         c0[1] = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]); c1[1] = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
         c0[2] = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]); c1[2] = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);

@@ -440,7 +440,7 @@ void new_point_set(Ctx *c, Cloud &cl)
 {
   cl.set_id = c->next_set_id++;
   cl.order.reset();
-  cl.grid.reset(); cl.canonical = true; cl.pose_known = false;        // its points, as they are now, DEFINE the new set: canonical coordinates
+  cl.grid.reset(); cl.canonical = true; cl.pose_known = false; cl.pose_stretch = 1.0;        // its points, as they are now, DEFINE the new set: canonical coordinates
   cl.stale_coords();
 }
 
@@ -453,7 +453,7 @@ void inherit_point_set(Cloud &dst, const Cloud &src)
   dst.set_id = src.set_id;
   if (src.order) dst.order = src.order;
   else if (!same) dst.order.reset();
-  dst.grid.reset(); dst.canonical = false; dst.pose_known = false;      // (the callers that know the pose say so afterwards)
+  dst.grid.reset(); dst.canonical = false; dst.pose_known = false; dst.pose_stretch = 1.0;      // (the callers that know the pose say so afterwards)
   dst.stale_coords();
 }
 

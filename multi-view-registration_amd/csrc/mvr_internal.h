@@ -128,6 +128,10 @@ constexpr size_t kTraceBlocks = 4096, kTraceRec = 16;   // diagnostic builds (-D
 // query count / evaluation count is only known on the device)
 struct ProfRec { int family; hipEvent_t a, b; double work; const uint64_t *h_count; int n_shards; double per_count; };
 
+// where the searches of one pair of the last fused batch left their keys (mvr_pair_batch_correspondences)
+struct Ctx;
+struct BatchPairRec { Ctx *w = nullptr; size_t off_s = 0, off_t = 0, qb = 0, qn = 0; int src = -1, dst = -1; double max2 = 0.0; int reciprocal = 0; unsigned long long src_set = 0, dst_set = 0; };
+
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -169,6 +173,7 @@ struct Ctx {
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
   int fused_mark = 1;                                 // fused pass: the forward launches themselves record the matched targets' start bounds -- 1: when they are the grid walk, 2: always, 0: never (a separate launch re-reads the keys)
   bool marked_in_search = false;                      // ... what this pass does (decided with its forward launches)
+  std::vector<BatchPairRec> last_batch;               // the pairs of the last fused mvr_pair_moments2_batch on this context
   unsigned long long fused_passes = 0;                // fused pair batches run on this context so far
   std::vector<unsigned long long> fused_sig;          // what the forward keys in bkeys[] belong to (point-set ids, ranges, offsets): the previous fused pass on this context
   int pair_streams = 6;                               // worker streams of mvr_pair_moments2_batch
@@ -364,6 +369,13 @@ inline void xcd_map_plan(XcdMap &map, int forced_slices, unsigned *grid_blocks)
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);     // only the query sets on the pairs' set lists (Q = 1)
 // ---- grid search (mvr_grid.hip): exact 1-NN of seeded / bounded queries, one thread per query
+// pose-derived parameters of one posed cloud, in DEVICE-VISIBLE memory: what the kernels of a pass that was enqueued
+// before its poses were known read instead of by-value arguments (the pipelined ring run, mvr_ctx.hip)
+struct PoseRec {
+  Mat44d T;                 // the pose (column-major 4 x 4)
+  double minv[12];          // its inverse affine map, row-major 3 x 4: posed frame -> canonical frame
+  float stretch, pad_;      // bound of how much the inverse lengthens a distance (1 for a rigid pose)
+};
 struct GridPair {
   const float4 *qs = nullptr;                 // queries: a Hilbert-ordered posed cloud (w = original index)
   const uint32_t *qlist = nullptr, *qcount = nullptr;     // optional: compacted query positions + their device count (key slot = list position)
@@ -381,6 +393,7 @@ struct GridPair {
   const uint32_t *qbound = nullptr;           // optional start bounds by query position (bits of a d2; ~0 = none)
   uint32_t *mark = nullptr;                   // optional: start bounds of the reverse searches, by the match's Hilbert position
   uint32_t key_by_pos = 0, seed_from_keys = 0;
+  const PoseRec *pose_dev = nullptr;     // optional: minv / stretch are read from here (device-visible) instead of the two by-value members
   float stretch = 1.f;                   // distances in the searched cloud's canonical frame are at most this times the posed ones (Cloud::pose_stretch, rounded up)
   int dt_max = 12;                       // what dt == 255 stands for (the grid's dt_steps)
   // a BOUNDED query whose ball is wide (scattered among the others: a match that moved far, a long correspondence) is
