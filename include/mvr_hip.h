@@ -233,6 +233,28 @@ int  mvr_pair_moments2_from_keys(mvr_ctx *ctx, int src_slot, int tgt_slot, const
                                  double max_dist, int reciprocal, int fma_dist, const double origin[3],
                                  double *dev_out);
 
+/* The native host of that loop (csrc/mvr_ctx.hip, collectives in csrc/mvr_world.cpp).  mvr_seq_align_sharded: ONE
+ * IterativeClosestPoint::align (registrator.cpp:569) of the full source in src_slot against the sharded target in tgt_slot
+ * (this rank's shard), collectives on the context's communicator (mvr_ctx_comm_init / mvr_world_create; none = a world of
+ * one): per iteration ncclAllReduce(ncclInt64, ncclMin) of the Ns keys and ncclAllReduce(ncclDouble, ncclSum) of the sums, on
+ * the context's stream, then the host solve and the convergence criteria.  out_slot receives final * input (may equal
+ * src_slot; < 0: none).  Every rank calls it with the same arguments and gets the same T_out / stats.
+ * mvr_seq_run_sharded: Registrator::registrationICP (registrator.cpp:526-588) on top of it -- views 1, V-1, 2, ... aligned
+ * one after the other against everything merged so far, pose_v <- T_icp * pose_v (:574), and `*target += aligned source`
+ * (:576) as "every rank appends its slice [n g / G, n (g + 1) / G) of the aligned scan to its shard".  poses: n_views x 16
+ * column-major, in / out; the per-align outputs (capacity repeat * (n_views - 1), any may be NULL) log the view, the
+ * transformation and the statistics of every align.  PCL's "not enough correspondences" does not stop the driver
+ * (registrator.cpp:569-574 never checks hasConverged()).
+ * Failures: a rank whose local work fails still joins the iteration's collectives (neutral keys, zero sums, a raised failure
+ * count), so every rank leaves the iteration together -- the failing one with its own status, the others with MVR_E_RCCL;
+ * a rank whose peers never arrive gives up after "wait_timeout_ms" (mvr_ctx_tune), aborts the communicator
+ * (ncclCommAbort) and returns MVR_E_RCCL.  The same holds for mvr_ring_run_sharded.  Never a hang. */
+int  mvr_seq_align_sharded(mvr_ctx *ctx, int src_slot, int tgt_slot, int out_slot, const mvr_icp_params *params,
+                           const double origin[3], float T_out[16], mvr_icp_stats *stats);
+int  mvr_seq_run_sharded(mvr_ctx *ctx, int n_views, const int *raw_slots, int target_slot, int source_slot, int out_slot,
+                         const mvr_icp_params *params, const double origin[3], int repeat, double *poses, int *align_view,
+                         float *align_T, mvr_icp_stats *align_stats, int *n_aligns);
+
 /* raw second moments of caller-supplied correspondences (lum.setCorrespondences,
  * registrator.cpp:650): query[k] indexes src_slot, match[k] indexes tgt_slot. */
 int  mvr_pair_moments2_from_corr(mvr_ctx *ctx, int src_slot, int tgt_slot, const int32_t *query,
@@ -296,7 +318,10 @@ int  mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int 
                    double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters,
                    double *rows, double *timing_ms);
 /* n_steps outer passes (the loop of registrator.cpp:625-664), each exactly one mvr_ring_step; the outputs are those
- * of the LAST pass, timing_ms the SUM over the passes.  Stops at the first pass that fails and returns its status. */
+ * of the LAST pass, timing_ms the SUM over the passes.  Stops at the first pass that fails and returns its status.
+ * In steady state (no allocation, no index or grid to build: from the third or fourth pass of a registration on) the
+ * passes are PIPELINED: the launch chain of pass k+1 is queued behind a gate while pass k runs and released by the host's
+ * solve with one store (tune key "pipeline"); same results, bit for bit. */
 int  mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
                   const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                   int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
@@ -328,8 +353,13 @@ const char *mvr_rccl_library(void);      /* what was loaded, or why nothing was 
 /* the partition: edge_queries[e] = source points of edge e; rank's ranges (edge, first query, count), at most ne of them */
 int  mvr_ring_segments(int ne, const size_t *edge_queries, int world, int rank, int *seg_edge, size_t *seg_begin, size_t *seg_count, int *n_seg);
 /* arguments as mvr_ring_run; every rank passes the same poses in and gets the same poses out.  timing_ms = {enqueue,
- * wait for the GPU incl. the all-reduce, host solve}, summed over the passes.  A rank that fails before a pass's
- * all-reduce leaves its peers waiting in theirs (RCCL has no peer-failure detection): treat any error as fatal. */
+ * wait for the GPU incl. the all-reduce, host solve}, summed over the passes.  A rank whose local work fails in a pass
+ * reports it THROUGH that pass's all-reduce (a status row of the table), so all ranks return from the same pass -- the
+ * failing rank with its own status, its peers with MVR_E_RCCL; a rank whose peers never arrive gives up after
+ * "wait_timeout_ms" (mvr_ctx_tune, default 60 000), aborts the communicator (ncclCommAbort) and returns MVR_E_RCCL
+ * (the context then refuses the multi-GPU entry points until mvr_ctx_comm_destroy + a new communicator).  The replicated
+ * solve relies on RCCL's all-reduce handing every rank the SAME bits (one reduction order per element, whatever the
+ * algorithm: ring and tree both reduce an element once and broadcast the result). */
 int  mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
                           const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                           int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
@@ -408,9 +438,19 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * visits only the query sets the walk listed; 0: a block per set), "cull_list_w" (waves per listed set: 1, 2, 4),
  * "grid_lanes" (lanes sharing a query: 1 (default), 2, 4, 8), "grid_wide_waves" (waves per CU of the wave-per-query
  * launch), "fused_mark" (1, default: the forward searches record the start bounds of the reverse searches themselves when
- * they are the grid walk; 2: always; 0: never -- a separate launch re-reads the keys), "grid_debug" (1: every pass prints how its queries split; synchronises).
+ * they are the grid walk; 2: always; 0: never -- a separate launch re-reads the keys), "grid_debug" (1: every pass prints how its queries split; synchronises);
+ * "pipeline" (1, default: mvr_ring_run / mvr_ring_run_sharded enqueue pass k+1's whole launch chain while pass k runs,
+ * behind a hipStreamWaitValue32 gate the host opens after its solve, the poses reaching the kernels through a device table,
+ * once a pass has run without allocating or waiting; 0: every pass is enqueued after the previous solve; also MVR_PIPELINE);
+ * multi-GPU: "wait_timeout_ms" (how long a rank waits for a pass that contains a collective before it aborts its
+ * communicator), and the test hooks "inject_fail_pass" / "inject_stall_pass" (the k-th sharded pass or iteration from now:
+ * this rank's local work fails / its stream stalls in front of the collective as if a peer never arrived; -1: off).
  * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
+/* counters of the context, by name: "piped_passes" (passes of mvr_ring_run / mvr_ring_run_sharded whose launch chain was
+ * enqueued ahead of their poses, see "pipeline"), "fused_passes" (fused pair batches run so far), "blocking_events"
+ * (times the library waited for its stream or re-allocated a buffer: a pass without any is in steady state) */
+int  mvr_ctx_stat(mvr_ctx *ctx, const char *key, double *value);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,
  * running total, max tiles processed by one wave, max tiles tested by one wave} */
 int  mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset);

@@ -141,6 +141,9 @@ SIGNATURES = {
     "mvr_pair_moments2_batch": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double, C.c_int,
                                           C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), _dp,
                                           C.POINTER(PairMoments2), _vp]),
+    "mvr_seq_align_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), _dp, _fp, C.POINTER(IcpStats)]),
+    "mvr_seq_run_sharded": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), _dp, C.c_int, _dp,
+                                      C.POINTER(C.c_int), _fp, C.POINTER(IcpStats), C.POINTER(C.c_int)]),
     "mvr_pair_batch_correspondences": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _fp, _sz, C.POINTER(_sz)]),
     "mvr_pair_moments2_from_corr": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _sz, _dp,
                                               C.POINTER(PairMoments2)]),
@@ -191,6 +194,7 @@ SIGNATURES = {
     "mvr_mat4d_mul": (None, [_dp, _dp, _dp]),
     "mvr_mat4f_mul": (None, [_fp, _fp, _fp]),
     "mvr_ctx_tune": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "mvr_ctx_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "mvr_debug_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
     "mvr_prof_enable": (C.c_int, [_vp, C.c_int]),
     "mvr_prof_reset": (C.c_int, [_vp]),
@@ -644,6 +648,32 @@ class Context:
                      fwd_queries=st.fwd_queries, ms=st.ms)
         return from_cm(T), stats, rc
 
+    @staticmethod
+    def _stats(st):
+        return dict(iterations=st.iterations, converged=bool(st.converged), state=CONV_STATES[st.state], n_corr=st.n_corr, mse=st.mse,
+                    evals=st.evals, fwd_queries=st.fwd_queries, ms=st.ms)
+
+    def seq_align_sharded(self, src, tgt, out, params: IcpParams, origin):
+        """mvr_seq_align_sharded: one align of the full source against this rank's target shard -> (T, stats, rc)"""
+        T, st, o = np.empty(16, np.float32), IcpStats(), np.ascontiguousarray(origin, np.float64)
+        rc = _chk(_lib.mvr_seq_align_sharded(self._h, src, tgt, out, C.byref(params), _p(o, C.c_double), _p(T, C.c_float), C.byref(st)),
+                  self._h, allow=(E_NOCORR,))
+        return from_cm(T), self._stats(st), rc
+
+    def seq_run_sharded(self, raw_slots, target_slot, source_slot, out_slot, params: IcpParams, origin, poses, repeat=1):
+        """mvr_seq_run_sharded: registrationICP with the growing target sharded over the context's communicator.
+        poses: V (4,4) float64 -> (new poses (V,4,4), log: list of dict(view, T, iterations, state, n_corr, mse, ...))"""
+        V = len(raw_slots)
+        rs = (C.c_int * V)(*[int(v) for v in raw_slots])
+        P = np.ascontiguousarray(np.asarray(poses, np.float64).transpose(0, 2, 1)).reshape(V, 16)
+        cap = max(1, repeat * (V - 1))
+        views, Ts, sts, n = (C.c_int * cap)(), np.zeros((cap, 16), np.float32), (IcpStats * cap)(), C.c_int()
+        o = np.ascontiguousarray(origin, np.float64)
+        _chk(_lib.mvr_seq_run_sharded(self._h, V, rs, int(target_slot), int(source_slot), int(out_slot), C.byref(params), _p(o, C.c_double),
+                                      int(repeat), _p(P, C.c_double), views, _p(Ts, C.c_float), sts, C.byref(n)), self._h)
+        log = [dict(self._stats(sts[k]), view=views[k], T=from_cm(Ts[k])) for k in range(n.value)]
+        return np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1)), log
+
     def fitness(self, inp, tgt, T, max_range=np.finfo(np.float64).max, fma=False) -> float:
         t, s = to_cm(T, np.float32), C.c_double()
         _chk(_lib.mvr_fitness(self._h, inp, tgt, _p(t, C.c_float), float(max_range), int(fma),
@@ -664,6 +694,12 @@ class Context:
         """NN launch knobs (nn_q, nn_sub, nn_blocks_per_cu); results do not depend on them."""
         for k, v in kw.items():
             _chk(_lib.mvr_ctx_tune(self._h, k.encode(), int(v)), self._h)
+
+    def stat(self, key) -> float:
+        """mvr_ctx_stat: "piped_passes", "fused_passes", "blocking_events", "pipeline" """
+        v = C.c_double()
+        _chk(_lib.mvr_ctx_stat(self._h, key.encode(), C.byref(v)), self._h)
+        return v.value
 
     def debug_counters(self, reset=False):
         out = (C.c_uint64 * 4)()

@@ -105,6 +105,7 @@ bool slot_ok(int s) { return s >= 0 && s < MVR_MAX_SLOTS; }
 int cloud_reserve(Ctx *c, Cloud &cl, size_t cap, bool keep)
 {
   if (cl.cap >= cap) return MVR_OK;
+  MVR_MAY_BLOCK(c, "a cloud has to grow");
   size_t ncap = std::max(cap, cl.cap + cl.cap / 2);
   float4 *np = nullptr;
   MVR_HIP_TRY(c, hipMalloc(&np, ncap * sizeof(float4)));
@@ -332,6 +333,7 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_RING_SEARCH")) c->ring_search = std::atoi(m);   // fused pass: 1 = grid search for bounded queries, 0 = culled kernel only
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_PIPELINE")) c->pipeline = std::atoi(m) != 0;      // 0: no pass is enqueued ahead of its poses
   if (const char *m = std::getenv("MVR_POSED_REFRESH")) c->posed_refresh = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PAIR_GROUPS")) c->pair_groups = std::max(1, std::min(8, std::atoi(m)));
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
@@ -383,6 +385,13 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
                   c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  if (c->h_stall) (void)hipHostFree(c->h_stall);
+  if (c->seq_keys) (void)hipFree(c->seq_keys);
+  if (c->seq_row) (void)hipFree(c->seq_row);
+  if (c->h_pose_in) (void)hipHostFree(c->h_pose_in);
+  if (c->pose_tab) (void)hipFree(c->pose_tab);
+  if (c->gate) { if (c->gate_is_signal) (void)hipFree(c->gate); else (void)hipHostFree(c->gate); }
+  if (c->h_done) (void)hipHostFree(c->h_done);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_table) (void)hipHostFree(c->h_table);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -686,6 +695,13 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
     else { c->slots[dst[k]].canonical = false; c->slots[dst[k]].pose_known = false; c->slots[dst[k]].grid.reset(); }
     c->slots[dst[k]].stale_coords();
+    if (c->pose_from_table && c->slots[dst[k]].pose_dev && dst[k] != src[k]) {
+      // a pass enqueued ahead of its poses: the kernels read pose, inverse and stretch from the destination's device
+      // record, which pose_prep_kernel fills for ANY invertible matrix (a pose that is not nearly rigid gets a wider
+      // ball, not another kernel); the host's copy of the pose follows when the solve has produced it (ring_passes)
+      Cloud &d = c->slots[dst[k]];
+      d.canonical = false; d.pose_known = src_canon; d.grid = src_canon ? c->slots[src[k]].grid : nullptr; d.posed_by_table = true;
+    } else
     note_pose(c->slots[dst[k]], c->slots[src[k]], src_canon && dst[k] != src[k], T + (size_t)k * 16);
     c->slots[dst[k]].has_normals = false;
   }
@@ -713,7 +729,9 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     if (!d.empty()) { if (int rc = refresh_posed_batch(c, (int)d.size(), d.data(), s.data(), Ts.data(), pass == 0, handled.data())) return rc; }
     if (pass == 0) {
       for (size_t i = 0; i < which.size(); ++i) if (handled[i]) { done[which[i]] = 1; n[which[i]] = 0; }    // posed by the refresh launch
-      if (int rc = launch_transform_f64_batch(c, count, in.data(), out.data(), n.data(), T)) return rc;
+      std::vector<const Mat44d *> Tp((size_t)count, nullptr);
+      if (c->pose_from_table) for (int k = 0; k < count; ++k) if (in[k] && c->slots[dst[k]].pose_dev && dst[k] != src[k]) Tp[k] = &c->slots[dst[k]].pose_dev->T;
+      if (int rc = launch_transform_f64_batch(c, count, in.data(), out.data(), n.data(), T, Tp.data())) return rc;
       for (size_t i = 0; i < which.size(); ++i) if (handled[i]) n[which[i]] = c->slots[dst[which[i]]].n;
     }
   }
@@ -970,6 +988,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     if (int rc = ensure(w, w->bheavy, w->bheavy_cap, off_s[n_pairs] + off_t[n_pairs])) return rc;      // forward flags by source position, then reverse flags by list position
     if (int rc = ensure(w, w->bwide, w->bwide_cap, off_s[n_pairs] + off_t[n_pairs])) return rc;        // the lists of wide bounded queries, same layout
     if (!w->bwide_count) {                                                                              // their counters: zero now, put back to zero by every pass's moments launch
+      MVR_MAY_BLOCK(w, "the wide-query counters are not allocated yet");
       MVR_HIP_TRY(w, hipMalloc(&w->bwide_count, 3 * kWideCounters * sizeof(uint32_t)));
       MVR_HIP_TRY(w, hipMemsetAsync(w->bwide_count, 0, 3 * kWideCounters * sizeof(uint32_t), w->stream));
     }
@@ -1008,6 +1027,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     if (grid_ok && seed) {
       if (int rc = launch_nn_grid_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc;
       if (c->grid_debug) {          // diagnostics (tune key grid_debug): how many queries left the thread-per-query walk, per pass
+        MVR_MAY_BLOCK(c, "grid_debug reads counters back");
         std::vector<uint32_t> cnt((size_t)kWideCounters); std::vector<uint8_t> hv(off_s[n_pairs]);
         MVR_HIP_TRY(w, hipStreamSynchronize(w->stream));
         MVR_HIP_TRY(w, hipMemcpy(cnt.data(), w->bwide_count, kWideCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1071,6 +1091,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       if (grid_ok) {
         if (int rc = launch_nn_grid_batch(w, grev.data() + base, m, cap2, fma != 0)) return rc;
         if (c->grid_debug && c->grid_wide) {
+          MVR_MAY_BLOCK(c, "grid_debug reads counters back");
           std::vector<uint32_t> cnt((size_t)2 * kWideCounters), qc((size_t)n_pairs);
           MVR_HIP_TRY(w, hipStreamSynchronize(w->stream));
           MVR_HIP_TRY(w, hipMemcpy(cnt.data(), w->bwide_count, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1132,7 +1153,9 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     // glue kernels and the tail of its searches then overlap the other groups' searches.
     // (only when there are pairs to spare: with fewer than four per group the second stream just doubles the launches --
     // measured on 2 / 3 / 4 / 6 pairs of 200k: equal or up to 4 % slower)
-    const int G = (n_pairs >= 4 * c->pair_groups) ? c->pair_groups : 1;
+    // (a pass enqueued ahead of its poses runs its pairs as ONE group: the groups measure the same since the grid search --
+    // 0.508 / 0.506 / 0.504 ms with 1 / 2 / 3 -- and one stream needs no fork / join events between queued passes)
+    const int G = (n_pairs >= 4 * c->pair_groups && !c->pose_from_table) ? c->pair_groups : 1;
     c->last_batch.assign((size_t)n_pairs, BatchPairRec());
     if (G == 1) {
       if (int rc = pair_batch_fused(c, c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
@@ -1268,82 +1291,358 @@ API int mvr_pair_batch_correspondences(mvr_ctx *ctx, int k, int32_t *query, int3
   return MVR_OK;
 }
 
-// One outer pass of registrationLUM without a host language in between (the Python / C++ drivers spend a tenth
-// of a 1.2 ms step on their own bookkeeping between the three calls this chains).
-API int mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
-                      const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
-                      double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters,
-                      double *rows, double *timing_ms)
+}  // extern "C" (reopened below)
+
+// ---- the pass loop of the global registration (registrator.cpp:625-664), pipelined ------------------------------------
+// One pass = a chain of ~15 launches (pose the scans, refresh their indices, forward searches, glue, reverse searches,
+// filter + sums) whose only input from the previous pass is V poses, produced by a 75 us host solve.  Enqueued the
+// ordinary way -- after that solve, launch by launch -- the GPU idles through the solve, through the wake-up after
+// hipStreamSynchronize and, worst, whenever a kernel ends before the host has pushed the next one (a launch costs the
+// host ~6 us, the small kernels run 4-16 us): 136 of 475 us per pass (profiles/r02_h_step_timeline_groups1.txt).
+// Here pass k+1's whole chain is enqueued WHILE pass k runs, behind a gate (hipStreamWaitValue32) that the host opens
+// with one store after its solve; the kernels read the poses from a device table (PoseRec, filled by a one-wave kernel
+// at the head of the chain from pinned host memory) instead of kernel arguments, and the host learns that a pass has
+// drained from a word the stream writes into pinned memory (hipStreamWriteValue32), spinning instead of sleeping in
+// hipStreamSynchronize.  tools/exp_gate.hip measures the hand-off alone: 24 us with synchronize, ~1 us with the gate.
+// Results are the same bits: the chain is the same chain, only the route of the poses differs.
+namespace mvr {
+namespace {
+
+__global__ void pose_prep_kernel(const double *__restrict__ in, PoseRec *__restrict__ out, int n_views)
 {
-  if (!ctx || n_views < 2 || ne < 0 || !posed_slots || !raw_slots || (ne && (!edge_src || !edge_tgt)) || !origin || !poses || !lum_pose)
-    return MVR_E_ARG;
-  for (int e = 0; e < ne; ++e) if (edge_src[e] < 0 || edge_src[e] >= n_views || edge_tgt[e] < 0 || edge_tgt[e] >= n_views) return MVR_E_ARG;
-  Ctx *c = CTX(ctx);
-  using clk = std::chrono::steady_clock;
-  const auto t0 = clk::now();
-  if (int rc = mvr_cloud_transform_batch(ctx, n_views, posed_slots, raw_slots, poses)) return rc;
-  std::vector<int> ss((size_t)ne), ts((size_t)ne);
-  for (int e = 0; e < ne; ++e) { ss[e] = posed_slots[edge_src[e]]; ts[e] = posed_slots[edge_tgt[e]]; }
-  // the 32 doubles per edge go straight into pinned host memory (the final kernels write them over the bus: no copy
-  // to enqueue, nothing to wait for but the stream itself)
-  if (c->h_table_cap < (size_t)std::max(ne, 1) * 32) {
-    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_table) (void)hipHostFree(c->h_table);
-    c->h_table = nullptr; c->h_table_cap = 0;
-    const size_t cap = (size_t)std::max(ne, 16) * 32;
-    MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), cap * sizeof(double), hipHostMallocMapped));
-    c->h_table_cap = cap;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_views) return;
+  PoseRec r;
+  double T[16];
+  for (int j = 0; j < 16; ++j) { T[j] = in[16 * v + j]; r.T.m[j] = T[j]; }
+  // inverse of x -> A x + t (column-major 4 x 4): by cofactors, in double, as make_grid_pair does on the host
+  const double A[3][3] = {{T[0], T[4], T[8]}, {T[1], T[5], T[9]}, {T[2], T[6], T[10]}};
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  const double id = 1.0 / det;
+  const double I[3][3] = {{(A[1][1] * A[2][2] - A[1][2] * A[2][1]) * id, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id},
+                          {(A[1][2] * A[2][0] - A[1][0] * A[2][2]) * id, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id},
+                          {(A[1][0] * A[2][1] - A[1][1] * A[2][0]) * id, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id}};
+  for (int rr = 0; rr < 3; ++rr) {
+    for (int k = 0; k < 3; ++k) r.minv[4 * rr + k] = I[rr][k];
+    r.minv[4 * rr + 3] = -(I[rr][0] * T[12] + I[rr][1] * T[13] + I[rr][2] * T[14]);
   }
-  double *d_table = nullptr;
-  MVR_HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&d_table), c->h_table, 0));
-  if (ne) { if (int rc = mvr_pair_moments2_batch(ctx, ne, ss.data(), ts.data(), max_dist, reciprocal, fma, nullptr, nullptr, origin, nullptr, d_table)) return rc; }
-  const auto t1 = clk::now();
-  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  std::vector<double> h(c->h_table, c->h_table + (size_t)ne * 32);
-  const auto t2 = clk::now();
-  if (rows && ne) std::memcpy(rows, h.data(), h.size() * sizeof(double));
-  std::vector<double> pn((size_t)ne), pm((size_t)ne);
-  const int rc = mvr_ring_host_step(n_views, ne, edge_src, edge_tgt, h.data(), origin, lum_iterations, poses, lum_pose, pair_T,
-                                    pair_n ? pair_n : pn.data(), pair_mse ? pair_mse : pm.data(), lum_iters);
-  const auto t3 = clk::now();
-  if (timing_ms) {
-    timing_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    timing_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    timing_ms[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  // (the host has checked e <= 1e-3 before it released this pass: note_pose's bar)
+  double e2 = 0.0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const double d = T[4 * a] * T[4 * b] + T[4 * a + 1] * T[4 * b + 1] + T[4 * a + 2] * T[4 * b + 2];
+      const double x = d - (a == b ? 1.0 : 0.0);
+      e2 += x * x;
+    }
+  const double e = fmin(sqrt(e2), 0.5);
+  r.stretch = __double2float_ru((1.0 / sqrt(1.0 - e)) * (1.0 + 1e-6));
+  r.pad_ = 0.f;
+  out[v] = r;
+}
+
+// note_pose's test: an affine matrix whose 3 x 3 is a rotation up to e = |A^T A - I|_F <= 1e-3
+bool pose_nearly_rigid(const double *T)
+{
+  if (T[3] != 0.0 || T[7] != 0.0 || T[11] != 0.0 || T[15] != 1.0) return false;
+  double e2 = 0.0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const double d = T[4 * a] * T[4 * b] + T[4 * a + 1] * T[4 * b + 1] + T[4 * a + 2] * T[4 * b + 2];
+      const double x = d - (a == b ? 1.0 : 0.0);
+      e2 += x * x;
+    }
+  return std::sqrt(e2) <= 1e-3;
+}
+
+int pipe_setup(Ctx *c, int n_views)
+{
+  if (!c->gate) {
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess || !can) return MVR_E_HIP;
+    // the gate: signal memory where the runtime offers it (the wait is then a barrier packet of the queue, no wave spins),
+    // else a word of pinned host memory
+    if (hipExtMallocWithFlags(reinterpret_cast<void **>(&c->gate), 8, hipMallocSignalMemory) == hipSuccess && c->gate) c->gate_is_signal = true;
+    else {
+      (void)hipGetLastError();
+      c->gate = nullptr; c->gate_is_signal = false;
+      if (hipHostMalloc(reinterpret_cast<void **>(&c->gate), 64, hipHostMallocMapped) != hipSuccess) { c->gate = nullptr; return MVR_E_HIP; }
+    }
+    *c->gate = 0u;
   }
-  if (rc != MVR_OK) return set_error(c, rc, "LUM solve");
+  if (!c->h_done) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_done), 64, hipHostMallocMapped) != hipSuccess) { c->h_done = nullptr; return MVR_E_HIP; }
+    *c->h_done = 0u;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_done), c->h_done, 0) != hipSuccess) return MVR_E_HIP;
+  }
+  if (c->pose_tab_cap < (size_t)n_views) {
+    if (c->h_pose_in) (void)hipHostFree(c->h_pose_in);
+    if (c->pose_tab) (void)hipFree(c->pose_tab);
+    c->h_pose_in = nullptr; c->pose_tab = nullptr; c->pose_tab_cap = 0;
+    const size_t cap = (size_t)std::max(n_views, 16);
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pose_in), 2 * cap * 16 * sizeof(double), hipHostMallocMapped) != hipSuccess) { c->h_pose_in = nullptr; return MVR_E_HIP; }
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_pose_in), c->h_pose_in, 0) != hipSuccess) return MVR_E_HIP;
+    if (hipMalloc(&c->pose_tab, 2 * cap * sizeof(PoseRec)) != hipSuccess) { c->pose_tab = nullptr; return MVR_E_HIP; }
+    c->pose_tab_cap = cap;
+  }
   return MVR_OK;
 }
 
+struct Spin { double t0 = now_ms(); unsigned n = 0; };
+// the host's wait for "pass seq has drained": a spin on pinned memory (a wake-up from hipStreamSynchronize costs tens of
+// microseconds), with a look at the stream every few thousand rounds so that a failed launch ends the wait, and a bound
+int wait_done(Ctx *c, uint32_t seq)
+{
+  Spin sp;
+  for (;;) {
+    if ((int32_t)(__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) - seq) >= 0) return MVR_OK;
+    __builtin_ia32_pause();
+    if ((++sp.n & 0xFFFu) == 0u) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return set_error(c, MVR_E_HIP, "a pass of the pipelined ring run failed on the device", e);
+      if (e == hipSuccess && (int32_t)(__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) - seq) >= 0) return MVR_OK;
+      if (int rc = comm_poll(c)) return rc;                 // (a peer's failure surfaces here: the communicator is aborted, the pass will not finish)
+      if (now_ms() - sp.t0 > (double)c->wait_timeout_ms)
+        return c->comm ? comm_abort(c, "a pass did not finish in time: a peer failed or never arrived")
+                       : set_error(c, MVR_E_HIP, "a pass of the pipelined ring run did not finish in time");
+    }
+  }
+}
+
+}  // namespace
+
+int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
+{
+  double sum[3] = {0.0, 0.0, 0.0};
+  const int V = L.n_views;
+  auto plain_pass = [&]() -> int {
+    const double t0 = now_ms();
+    if (int rc = L.enqueue(L.self)) return rc;
+    const double t1 = now_ms();
+    if (int rc = stream_wait(c)) return rc;
+    const double t2 = now_ms();
+    const int rc = L.solve(L.self);
+    sum[0] += t1 - t0; sum[1] += t2 - t1; sum[2] += now_ms() - t2;
+    return rc;
+  };
+  auto all_rigid = [&]() { for (int v = 0; v < V; ++v) if (!pose_nearly_rigid(L.poses + 16 * (size_t)v)) return false; return true; };
+  auto pipe_possible = [&]() {
+    if (!c->pipeline || c->nn_mode == 0 || !c->pair_fused || c->grid_debug || V < 2) return false;
+    for (int v = 0; v < V; ++v) {
+      if (L.posed_slots[v] == L.raw_slots[v] || c->slots[L.raw_slots[v]].has_normals) return false;
+      for (int u = 0; u < v; ++u) if (L.posed_slots[u] == L.posed_slots[v]) return false;
+    }
+    return true;
+  };
+  bool steady = L.sig != 0 && c->pipe_steady_sig == L.sig && c->pipe_steady_events == c->blocking_events;
+  int k = 0;
+  while (k < n_steps) {
+    if (!(steady && n_steps - k >= 2 && pipe_possible() && all_rigid() && pipe_setup(c, V) == MVR_OK)) {
+      const unsigned long long ev0 = c->blocking_events;
+      if (int rc = plain_pass()) return rc;
+      steady = c->blocking_events == ev0 && c->fused_passes >= 2;      // (the grids exist from the second fused pass on)
+      ++k;
+      continue;
+    }
+    // ---- a pipelined stretch: passes k, k + 1, ... while nothing has to wait or grow
+    const size_t cap = c->pose_tab_cap;
+    int parity = 0;
+    std::vector<double> last_in((size_t)V * 16);
+    auto write_poses = [&](int par, const double *P) {
+      std::memcpy(c->h_pose_in + (size_t)par * cap * 16, P, (size_t)V * 16 * sizeof(double));
+      std::memcpy(last_in.data(), P, (size_t)V * 16 * sizeof(double));
+    };
+    auto open_gate = [&](uint32_t seq) { __atomic_store_n(c->gate, seq, __ATOMIC_RELEASE); };
+    auto enqueue_chain = [&](int par, bool gated, uint32_t *seq_out) -> int {
+      for (int v = 0; v < V; ++v) c->slots[L.posed_slots[v]].pose_dev = c->pose_tab + (size_t)par * cap + (size_t)v;
+      const uint32_t seq = ++c->pipe_seq;
+      *seq_out = seq;
+      if (gated) MVR_HIP_TRY(c, hipStreamWaitValue32(c->stream, c->gate, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+      hipLaunchKernelGGL(pose_prep_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, c->stream, c->d_pose_in + (size_t)par * cap * 16,
+                         c->pose_tab + (size_t)par * cap, V);
+      int rc = hipGetLastError() == hipSuccess ? L.enqueue(L.self) : set_error(c, MVR_E_HIP, "pose_prep_kernel");
+      // whatever was queued drains into the completion word, also after a failed enqueue (the caller waits for it)
+      if (hipStreamWriteValue32(c->stream, c->d_done, seq, 0) != hipSuccess && rc == MVR_OK) rc = set_error(c, MVR_E_HIP, "hipStreamWriteValue32");
+      return rc;
+    };
+    auto leave = [&]() {      // back to by-value poses; the host's pose bookkeeping catches up with what the last chain computed
+      c->pose_from_table = false; c->no_sync = false;
+      for (int v = 0; v < V; ++v) {
+        Cloud &d = c->slots[L.posed_slots[v]];
+        d.pose_dev = nullptr;
+        if (!d.posed_by_table) continue;                 // (a rank of a sharded run poses only the views its share touches)
+        const bool was_known = d.pose_known;
+        d.posed_by_table = false;
+        note_pose(d, c->slots[L.raw_slots[v]], was_known, last_in.data() + 16 * (size_t)v);
+      }
+    };
+    c->pose_from_table = true;
+    write_poses(parity, L.poses);
+    uint32_t seq_cur = 0, seq_next = 0;
+    double t0 = now_ms();
+    const unsigned long long ev_first = c->blocking_events;
+    int rc = enqueue_chain(parity, false, &seq_cur);
+    sum[0] += now_ms() - t0;
+    if (rc != MVR_OK) { (void)hipStreamSynchronize(c->stream); leave(); return rc; }
+    bool fall_back = c->blocking_events != ev_first;      // the first chain itself was not in steady state after all
+    for (;;) {
+      const bool more = k + 1 < n_steps && !fall_back;
+      bool next_failed = false;
+      if (more) {          // pass k+1's chain goes into the queue now, behind the gate, while pass k runs
+        t0 = now_ms();
+        c->no_sync = true;
+        next_failed = enqueue_chain(parity ^ 1, true, &seq_next) != MVR_OK;
+        c->no_sync = false;
+        sum[0] += now_ms() - t0;
+      }
+      t0 = now_ms();
+      rc = wait_done(c, seq_cur);
+      const double t1 = now_ms();
+      if (rc == MVR_OK) rc = L.solve(L.self);
+      sum[1] += t1 - t0; sum[2] += now_ms() - t1;
+      if (rc != MVR_OK) {                              // nothing may stay behind a closed gate
+        if (more) { const std::vector<double> safe = last_in; write_poses(parity ^ 1, safe.data()); open_gate(seq_next); }
+        (void)hipStreamSynchronize(c->stream);
+        leave();
+        return rc;
+      }
+      ++k;
+      ++c->piped_passes;
+      if (!more) break;
+      if (next_failed || !all_rigid()) {
+        // the queued chain cannot be used (it is incomplete, or a pose left the nearly-rigid range the grid search accepts):
+        // let it run on the poses of the pass before -- valid input, results unused -- and go on the ordinary way
+        { const std::vector<double> safe = last_in; write_poses(parity ^ 1, safe.data()); }
+        open_gate(seq_next);
+        (void)wait_done(c, seq_next);
+        MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        fall_back = true;
+        break;
+      }
+      write_poses(parity ^ 1, L.poses);
+      open_gate(seq_next);
+      parity ^= 1;
+      seq_cur = seq_next;
+    }
+    leave();
+    steady = !fall_back;
+  }
+  c->pipe_steady_sig = steady ? L.sig : 0; c->pipe_steady_events = c->blocking_events;
+  if (timing_ms) for (int j = 0; j < 3; ++j) timing_ms[j] = sum[j];
+  return MVR_OK;
+}
+
+unsigned long long pass_loop_sig(Ctx *c, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src, const int *edge_tgt,
+                                 double max_dist, int reciprocal, int fma, int extra)
+{
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](unsigned long long v) { for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xFFull; h *= 1099511628211ull; } };
+  mix((unsigned long long)n_views); mix((unsigned long long)ne); mix((unsigned long long)reciprocal); mix((unsigned long long)fma); mix((unsigned long long)extra);
+  unsigned long long md; std::memcpy(&md, &max_dist, 8); mix(md);
+  for (int v = 0; v < n_views; ++v) {
+    mix((unsigned long long)posed_slots[v]); mix((unsigned long long)raw_slots[v]);
+    mix(c->slots[raw_slots[v]].set_id); mix((unsigned long long)c->slots[raw_slots[v]].n);
+  }
+  for (int e = 0; e < ne; ++e) { mix((unsigned long long)edge_src[e]); mix((unsigned long long)edge_tgt[e]); }
+  return h | 1ull;
+}
+
+}  // namespace mvr
+
+namespace {
+struct RingRun {
+  mvr_ctx *ctx; int n_views; const int *posed_slots, *raw_slots; int ne; const int *edge_src, *edge_tgt; double max_dist; int reciprocal, fma;
+  const double *origin; int lum_iterations; double *poses, *lum_pose; float *pair_T; double *pair_n, *pair_mse; int *lum_iters; double *rows;
+  std::vector<int> ss, ts; std::vector<double> pn, pm, h;
+  static int enqueue(void *p)
+  {
+    RingRun &r = *static_cast<RingRun *>(p);
+    Ctx *c = CTX(r.ctx);
+    if (int rc = mvr_cloud_transform_batch(r.ctx, r.n_views, r.posed_slots, r.raw_slots, r.poses)) return rc;
+    // the 32 doubles per edge go straight into pinned host memory (the final kernels write them over the bus: no copy
+    // to enqueue, nothing to wait for but the stream itself)
+    if (c->h_table_cap < (size_t)std::max(r.ne, 1) * 32) {
+      MVR_MAY_BLOCK(c, "the host edge table has to grow");
+      MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (c->h_table) (void)hipHostFree(c->h_table);
+      c->h_table = nullptr; c->h_table_cap = 0;
+      const size_t cap = (size_t)std::max(r.ne, 16) * 32;
+      MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), cap * sizeof(double), hipHostMallocMapped));
+      c->h_table_cap = cap;
+    }
+    double *d_table = nullptr;
+    MVR_HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&d_table), c->h_table, 0));
+    if (r.ne) { if (int rc = mvr_pair_moments2_batch(r.ctx, r.ne, r.ss.data(), r.ts.data(), r.max_dist, r.reciprocal, r.fma, nullptr, nullptr, r.origin, nullptr, d_table)) return rc; }
+    return MVR_OK;
+  }
+  static int solve(void *p)
+  {
+    RingRun &r = *static_cast<RingRun *>(p);
+    Ctx *c = CTX(r.ctx);
+    r.h.assign(c->h_table, c->h_table + (size_t)r.ne * 32);
+    if (r.rows && r.ne) std::memcpy(r.rows, r.h.data(), r.h.size() * sizeof(double));
+    const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, r.h.data(), r.origin, r.lum_iterations, r.poses, r.lum_pose, r.pair_T,
+                                      r.pair_n ? r.pair_n : r.pn.data(), r.pair_mse ? r.pair_mse : r.pm.data(), r.lum_iters);
+    return rc != MVR_OK ? set_error(c, rc, "LUM solve") : MVR_OK;
+  }
+};
+}  // namespace
+
+extern "C" {
+
+// n_steps outer passes of registrationLUM without a host language in between (the Python / C++ drivers spent a tenth of a
+// 1.2 ms step on their own bookkeeping between the calls this chains); from the third pass on, pipelined (ring_passes).
 API int mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
                      const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                      int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
                      int *lum_iters, double *rows, double *timing_ms)
 {
-  if (n_steps < 0) return MVR_E_ARG;
-  double sum[3] = {0.0, 0.0, 0.0}, t[3];
-  for (int k = 0; k < n_steps; ++k) {
-    const int rc = mvr_ring_step(ctx, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin,
-                                 lum_iterations, poses, lum_pose, pair_T, pair_n, pair_mse, lum_iters, rows, t);
-    if (rc != MVR_OK) return rc;
-    for (int j = 0; j < 3; ++j) sum[j] += t[j];
-  }
-  if (timing_ms) for (int j = 0; j < 3; ++j) timing_ms[j] = sum[j];
-  return MVR_OK;
+  if (!ctx || n_steps < 0 || n_views < 2 || ne < 0 || !posed_slots || !raw_slots || (ne && (!edge_src || !edge_tgt)) || !origin || !poses || !lum_pose)
+    return MVR_E_ARG;
+  for (int e = 0; e < ne; ++e) if (edge_src[e] < 0 || edge_src[e] >= n_views || edge_tgt[e] < 0 || edge_tgt[e] >= n_views) return MVR_E_ARG;
+  for (int v = 0; v < n_views; ++v) if (!slot_ok(posed_slots[v]) || !slot_ok(raw_slots[v])) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  RingRun r{ctx, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin, lum_iterations, poses, lum_pose, pair_T,
+            pair_n, pair_mse, lum_iters, rows, {}, {}, {}, {}, {}};
+  r.ss.resize((size_t)ne); r.ts.resize((size_t)ne); r.pn.resize((size_t)ne); r.pm.resize((size_t)ne);
+  for (int e = 0; e < ne; ++e) { r.ss[(size_t)e] = posed_slots[edge_src[e]]; r.ts[(size_t)e] = posed_slots[edge_tgt[e]]; }
+  PassLoop L;
+  L.n_views = n_views; L.posed_slots = posed_slots; L.raw_slots = raw_slots; L.poses = poses;
+  L.enqueue = &RingRun::enqueue; L.solve = &RingRun::solve; L.self = &r;
+  L.sig = pass_loop_sig(c, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, 0);
+  return ring_passes(c, n_steps, L, timing_ms);
+}
+
+// one pass: mvr_ring_run with n_steps = 1 (posing, all pairs' fused searches and sums, the host solve)
+API int mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src,
+                      const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3], int lum_iterations,
+                      double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse, int *lum_iters,
+                      double *rows, double *timing_ms)
+{
+  return mvr_ring_run(ctx, 1, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin, lum_iterations, poses,
+                      lum_pose, pair_T, pair_n, pair_mse, lum_iters, rows, timing_ms);
 }
 
 // ---- target sharding over ranks (sequential mode): forward keys out, reduced keys in ----
-API int mvr_nn_forward_keys(mvr_ctx *ctx, int ss, int ts, double max_dist, int fma, long long *dev_keys)
+static int forward_keys_impl(Ctx *c, Cloud &s, Cloud &t, double max_dist, int fma, long long *dev_keys)
 {
-  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !dev_keys) return MVR_E_ARG;
-  Ctx *c = CTX(ctx);
-  MVR_HIP_TRY(c, hipSetDevice(c->device));
-  Cloud &s = c->slots[ss], &t = c->slots[ts];
   if (s.n == 0) return MVR_OK;
   SearchPlan plan;
   if (int rc = search_forward(c, s, t, 0, s.n, max_dist, fma != 0, nullptr, &plan)) return rc;
   return launch_export_keys(c, c->keys, s.n, seg_table(t), dev_keys);
 }
+
+API int mvr_nn_forward_keys(mvr_ctx *ctx, int ss, int ts, double max_dist, int fma, long long *dev_keys)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !dev_keys) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  return forward_keys_impl(c, c->slots[ss], c->slots[ts], max_dist, fma, dev_keys);
+}
+
+static int moments2_from_keys_impl(Ctx *c, Cloud &s, Cloud &t, const long long *dev_keys, double max_dist, int reciprocal,
+                                   int fma, const double origin[3], double *dev_out);
 
 API int mvr_pair_moments2_from_keys(mvr_ctx *ctx, int ss, int ts, const long long *dev_keys, double max_dist, int reciprocal,
                                     int fma, const double origin[3], double *dev_out)
@@ -1351,7 +1650,12 @@ API int mvr_pair_moments2_from_keys(mvr_ctx *ctx, int ss, int ts, const long lon
   if (!ctx || !slot_ok(ss) || !slot_ok(ts) || !dev_keys || !origin || !dev_out) return MVR_E_ARG;
   Ctx *c = CTX(ctx);
   MVR_HIP_TRY(c, hipSetDevice(c->device));
-  Cloud &s = c->slots[ss], &t = c->slots[ts];
+  return moments2_from_keys_impl(c, c->slots[ss], c->slots[ts], dev_keys, max_dist, reciprocal, fma, origin, dev_out);
+}
+
+static int moments2_from_keys_impl(Ctx *c, Cloud &s, Cloud &t, const long long *dev_keys, double max_dist, int reciprocal,
+                                   int fma, const double origin[3], double *dev_out)
+{
   SearchPlan plan;
   if (int rc = ensure(c, c->keys, c->keys_cap, s.n)) return rc;
   if (int rc = ensure(c, c->match, c->match_cap, s.n)) return rc;
@@ -1420,6 +1724,29 @@ API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t 
   return MVR_OK;
 }
 
+// pcl::registration::DefaultConvergenceCriteria::hasConverged, evaluated after every iteration on the
+// INCREMENTAL transformation and the mean squared correspondence distance of that iteration
+namespace {
+struct Criteria {
+  double rot_thr, trans_thr, rel_mse, abs_mse = 1e-12, prev_mse = DBL_MAX;
+  int max_iterations;
+  explicit Criteria(const mvr_icp_params *p)
+      : rot_thr(1.0 - p->transformation_epsilon), trans_thr(p->transformation_epsilon), rel_mse(p->euclidean_fitness_eps), max_iterations(p->max_iterations) {}
+  bool converged(const float tr[16], double cur_mse, int iters, int *state)
+  {
+    *state = MVR_CONV_NOT;
+    if (iters >= max_iterations) { *state = MVR_CONV_ITERATIONS; return true; }
+    const double cos_angle = 0.5 * ((double)tr[0] + (double)tr[5] + (double)tr[10] - 1.0);
+    const double t2 = (double)tr[12] * (double)tr[12] + (double)tr[13] * (double)tr[13] + (double)tr[14] * (double)tr[14];
+    if (cos_angle >= rot_thr && t2 <= trans_thr) { *state = MVR_CONV_TRANSFORM; return true; }
+    if (std::fabs(cur_mse - prev_mse) < abs_mse) { *state = MVR_CONV_ABS_MSE; return true; }
+    if (std::fabs(cur_mse - prev_mse) / prev_mse < rel_mse) { *state = MVR_CONV_REL_MSE; return true; }
+    prev_mse = cur_mse;
+    return false;
+  }
+};
+}  // namespace
+
 API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params *p, float T_out[16],
                       mvr_icp_stats *st)
 {
@@ -1442,10 +1769,8 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   MVR_HIP_TRY(c, hipMemsetAsync(c->evals + kEvalRegion, 0, kEvalRegion * sizeof(uint64_t), c->stream));   // running totals of the culled kernel
   float fin[16], tr[16];
   std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
-  // DefaultConvergenceCriteria (App. A.4)
-  const double rot_thr = 1.0 - p->transformation_epsilon, trans_thr = p->transformation_epsilon;
-  const double rel_mse = p->euclidean_fitness_eps, abs_mse = 1e-12;
-  double prev_mse = DBL_MAX, cur_mse = 0.0, evals = 0.0, fwdq = 0.0;
+  Criteria crit(p);          // DefaultConvergenceCriteria (App. A.4)
+  double cur_mse = 0.0, evals = 0.0, fwdq = 0.0;
   int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
   Cloud &tgt = c->slots[ts];
   do {
@@ -1477,16 +1802,7 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     cur.stale_coords();
     mvr_mat4f_mul(tr, fin, fin);
     ++iters;
-    state = MVR_CONV_NOT; converged = 0;
-    if (iters >= p->max_iterations) { state = MVR_CONV_ITERATIONS; converged = 1; }
-    else {
-      const double cos_angle = 0.5 * ((double)tr[0] + (double)tr[5] + (double)tr[10] - 1.0);
-      const double t2 = (double)tr[12] * (double)tr[12] + (double)tr[13] * (double)tr[13] + (double)tr[14] * (double)tr[14];
-      if (cos_angle >= rot_thr && t2 <= trans_thr) { state = MVR_CONV_TRANSFORM; converged = 1; }
-      else if (std::fabs(cur_mse - prev_mse) < abs_mse) { state = MVR_CONV_ABS_MSE; converged = 1; }
-      else if (std::fabs(cur_mse - prev_mse) / prev_mse < rel_mse) { state = MVR_CONV_REL_MSE; converged = 1; }
-      else prev_mse = cur_mse;
-    }
+    converged = crit.converged(tr, cur_mse, iters, &state) ? 1 : 0;
   } while (!converged);
   // output = final * (*input), from the ORIGINAL input: alias-safe (registrator.cpp:920)
   if (os >= 0) {
@@ -1520,6 +1836,154 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     st->evals = evals; st->fwd_queries = fwdq; st->ms = now_ms() - t0;
   }
   return status;
+}
+
+// ---- sequential mode with the growing target SHARDED by points over the ranks (registrator.cpp:563-577 is
+// loop-carried and does not shard by pair).  One IterativeClosestPoint::align of the full source (every rank holds it)
+// against the distributed target, as one native loop per rank:
+//   forward NN in the rank's shard -> Ns signed keys (d2 bits << 32 | GLOBAL target index)
+//   ncclAllReduce(ncclInt64, ncclMin) of the keys on the context's stream     (ties -> lowest global index: the single-GPU rule)
+//   reciprocal check + raw second moments of the matches whose target the rank OWNS
+//   ncclAllReduce(ncclDouble, ncclSum) of the 32 sums (+ the iteration's failure count)
+//   one D2H of 40 doubles, Umeyama on the host, convergence criteria, transform of the current source
+// A rank whose local work fails still joins both collectives of the iteration, with neutral contributions and a raised
+// failure count: every rank then leaves the loop in the same iteration with an error instead of one rank leaving its
+// peers inside a collective.  Without a communicator the context is a world of one and the collectives are no-ops.
+API int mvr_seq_align_sharded(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params *p, const double origin[3], float T_out[16],
+                              mvr_icp_stats *st)
+{
+  if (!ctx || !slot_ok(ss) || !slot_ok(ts) || (os >= 0 && !slot_ok(os)) || !p || !origin || !T_out || ss == ts || os == ts) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  if (p->point_to_plane) return set_error(c, MVR_E_ARG, "the sharded align is point-to-point (the reference's estimator)");
+  if (c->comm_broken) return set_error(c, MVR_E_RCCL, "the communicator of this context was aborted");
+  const double t0 = now_ms();
+  const size_t ns = c->slots[ss].n;
+  Cloud &cur = c->slots[kScratchCur];
+  cur.n = 0;
+  if (int rc = cloud_reserve(c, cur, ns, false)) return rc;
+  if (ns) MVR_HIP_TRY(c, hipMemcpyAsync(cur.pts, c->slots[ss].pts, ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+  cur.n = ns;
+  if (c->nn_mode != 0 && ns) { if (int rc = ensure_index(c, c->slots[ss])) return rc; }
+  inherit_point_set(cur, c->slots[ss]);
+  cur.segs.clear();
+  if (int rc = ensure(c, c->seq_keys, c->seq_keys_cap, std::max<size_t>(ns, 1))) return rc;
+  if (!c->seq_row) MVR_HIP_TRY(c, hipMalloc(&c->seq_row, 40 * sizeof(double)));
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float fin[16], tr[16];
+  std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
+  Criteria crit(p);
+  double cur_mse = 0.0, fwdq = 0.0;
+  int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
+  Cloud &tgt = c->slots[ts];
+  do {
+    int local = MVR_OK;
+    if (c->inject_fail_at >= 0 && c->dist_pass == c->inject_fail_at) local = set_error(c, MVR_E_HIP, "injected failure of this rank's local work");
+    ++c->dist_pass;
+    if (local == MVR_OK) local = forward_keys_impl(c, cur, tgt, p->max_corr_dist, p->fma_dist, c->seq_keys);
+    if (local != MVR_OK && ns) (void)hipMemsetAsync(c->seq_keys, 0x7F, ns * sizeof(long long), c->stream);      // "no neighbour here" (any key above every real one)
+    if (ns) { if (int rc = comm_allreduce(c, c->seq_keys, ns, kReduceMinI64)) return rc; }
+    if (local == MVR_OK) local = moments2_from_keys_impl(c, cur, tgt, c->seq_keys, p->max_corr_dist, p->use_reciprocal, p->fma_dist, origin, c->seq_row);
+    // [32] of the row counts the ranks whose local work failed in this iteration
+    c->h_moments[48] = local == MVR_OK ? 0.0 : 1.0;
+    if (local != MVR_OK) (void)hipMemsetAsync(c->seq_row, 0, 32 * sizeof(double), c->stream);
+    MVR_HIP_TRY(c, hipMemcpyAsync(c->seq_row + 32, c->h_moments + 48, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (int rc = comm_allreduce(c, c->seq_row, 33, kReduceSumF64)) return rc;
+    MVR_HIP_TRY(c, hipMemcpyAsync(c->h_moments, c->seq_row, 33 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = stream_wait(c)) return rc;
+    const double *h = c->h_moments;
+    if (h[32] > 0.0) return local != MVR_OK ? local : set_error(c, MVR_E_RCCL, "a peer's local work failed in this iteration");
+    fwdq += (double)ns;
+    ncorr = (int)std::llround(h[0]);
+    if (h[0] < 3.0) { state = MVR_CONV_NO_CORRESPONDENCES; converged = 0; status = MVR_E_NOCORR; break; }
+    mvr_pair_moments2_t m2;
+    std::memset(&m2, 0, sizeof m2);
+    m2.n = h[0];
+    for (int k = 0; k < 3; ++k) { m2.origin[k] = origin[k]; m2.sp[k] = h[4 + k]; m2.sq[k] = h[7 + k]; }      // (the origin is a constant, not a sum over ranks)
+    for (int k = 0; k < 6; ++k) { m2.spp[k] = h[10 + k]; m2.sqq[k] = h[16 + k]; }
+    for (int k = 0; k < 9; ++k) m2.spq[k] = h[22 + k];
+    m2.sum_d2 = h[31];
+    mvr_pair_moments_t mom;
+    if (int rc = mvr_moments_from_moments2(&m2, &mom)) return set_error(c, rc, "moments of the sharded align");
+    if (int rc = mvr_umeyama_from_moments(&mom, tr, nullptr)) return set_error(c, rc, "Umeyama of the sharded align");
+    cur_mse = h[31] / h[0];                          // mean of the correspondences' (f32) squared distances, as PCL has it
+    if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
+    cur.stale_coords();
+    mvr_mat4f_mul(tr, fin, fin);
+    ++iters;
+    converged = crit.converged(tr, cur_mse, iters, &state) ? 1 : 0;
+  } while (!converged);
+  if (os >= 0) {            // output = final * (*input), from the ORIGINAL input (App. A.1)
+    if (os != ss) { c->slots[os].n = 0; if (int rc = cloud_reserve(c, c->slots[os], ns, false)) return rc; }
+    if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
+    c->slots[os].n = ns;
+    if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
+    else { c->slots[os].canonical = false; c->slots[os].pose_known = false; c->slots[os].pose_stretch = 1.0; c->slots[os].grid.reset(); }
+    c->slots[os].stale_coords();
+    c->slots[os].has_normals = false;
+  }
+  std::memcpy(T_out, fin, sizeof fin);
+  if (st) {
+    st->iterations = iters; st->converged = converged; st->state = state; st->n_corr = ncorr; st->mse = cur_mse;
+    st->evals = 0.0; st->fwd_queries = fwdq; st->ms = now_ms() - t0;
+  }
+  return status;
+}
+
+// Registrator::registrationICP (registrator.cpp:526-588) with the growing target sharded over the ranks: view order
+// 1, V-1, 2, ..., each view aligned against everything merged so far, pose_v <- T_icp * pose_v (:574), and
+// `*target += transformed_source` (:576) as "every rank appends ITS slice of the aligned scan to its shard".
+// Rank g of G owns points [n g / G, n (g + 1) / G) of every merged scan; global point numbers run scan after scan in
+// merge order.  All ranks call this with the same arguments and get the same poses and logs.
+API int mvr_seq_run_sharded(mvr_ctx *ctx, int n_views, const int *raw_slots, int target_slot, int source_slot, int out_slot,
+                            const mvr_icp_params *p, const double origin[3], int repeat, double *poses, int *align_view, float *align_T,
+                            mvr_icp_stats *align_stats, int *n_aligns)
+{
+  if (!ctx || n_views < 2 || !raw_slots || !p || !origin || !poses || repeat < 0) return MVR_E_ARG;
+  if (!slot_ok(target_slot) || !slot_ok(source_slot) || !slot_ok(out_slot) || target_slot == source_slot || target_slot == out_slot || source_slot == out_slot)
+    return MVR_E_ARG;
+  for (int v = 0; v < n_views; ++v)
+    if (!slot_ok(raw_slots[v]) || raw_slots[v] == target_slot || raw_slots[v] == source_slot || raw_slots[v] == out_slot) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const size_t G = (size_t)(c->comm ? c->comm_world : 1), g = (size_t)(c->comm ? c->comm_rank : 0);
+  std::vector<int> order;                                // registrator.cpp:530-541
+  for (int i = 1; i < n_views / 2; ++i) { order.push_back(i); order.push_back(n_views - i); }
+  if (n_views / 2 >= 1 && (order.empty() || order.back() != n_views / 2)) order.push_back(n_views / 2);
+  int done = 0;
+  if (n_aligns) *n_aligns = 0;
+  for (int r = 0; r < repeat; ++r) {
+    // target <- this rank's slice of the posed view 0
+    size_t n0 = c->slots[raw_slots[0]].n, base = 0;
+    if (int rc = mvr_cloud_transform(ctx, out_slot, raw_slots[0], poses)) return rc;
+    if (int rc = mvr_cloud_clear(ctx, target_slot)) return rc;
+    {
+      const size_t lo = n0 * g / G, hi = n0 * (g + 1) / G;
+      if (int rc = mvr_cloud_append_range(ctx, target_slot, out_slot, lo, hi - lo, base + lo)) return rc;
+    }
+    base += n0;
+    for (int v : order) {
+      if (int rc = mvr_cloud_transform(ctx, source_slot, raw_slots[v], poses + 16 * (size_t)v)) return rc;
+      float T[16];
+      mvr_icp_stats st;
+      std::memset(&st, 0, sizeof st);
+      const int rc = mvr_seq_align_sharded(ctx, source_slot, target_slot, out_slot, p, origin, T, &st);
+      if (rc != MVR_OK && rc != MVR_E_NOCORR) return rc;      // (PCL's "not enough correspondences": the driver goes on, registrator.cpp:569-574)
+      if (align_view) align_view[done] = v;
+      if (align_T) std::memcpy(align_T + 16 * (size_t)done, T, sizeof T);
+      if (align_stats) align_stats[done] = st;
+      ++done;
+      if (n_aligns) *n_aligns = done;
+      double Td[16], P[16];
+      for (int k = 0; k < 16; ++k) Td[k] = (double)T[k];
+      mvr_mat4d_mul(Td, poses + 16 * (size_t)v, P);            // pose_v <- T_icp * pose_v
+      std::memcpy(poses + 16 * (size_t)v, P, sizeof P);
+      const size_t nv = c->slots[out_slot].n, lo = nv * g / G, hi = nv * (g + 1) / G;
+      if (int rc2 = mvr_cloud_append_range(ctx, target_slot, out_slot, lo, hi - lo, base + lo)) return rc2;
+      base += nv;
+    }
+  }
+  return MVR_OK;
 }
 
 API int mvr_fitness(mvr_ctx *ctx, int is, int ts, const float T[16], double max_range, int fma, double *score)
@@ -1580,11 +2044,27 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "grid_wide_waves")) { if (value < 1 || value > 64) return MVR_E_ARG; c->grid_wide_waves = value; }
   else if (!std::strcmp(key, "grid_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->grid_lanes = value; }
   else if (!std::strcmp(key, "grid_cell_points")) { if (value < 1) return MVR_E_ARG; c->grid_cell_points = value; }
+  else if (!std::strcmp(key, "pipeline")) c->pipeline = value != 0;
+  else if (!std::strcmp(key, "wait_timeout_ms")) { if (value < 1) return MVR_E_ARG; c->wait_timeout_ms = value; }
+  else if (!std::strcmp(key, "inject_fail_pass")) { c->inject_fail_at = value; c->dist_pass = 0; }
+  else if (!std::strcmp(key, "inject_stall_pass")) { c->inject_stall_at = value; c->dist_pass = 0; }
   else if (!std::strcmp(key, "pair_fused")) c->pair_fused = value != 0;
   else if (!std::strcmp(key, "posed_refresh")) c->posed_refresh = value != 0;
   else if (!std::strcmp(key, "pair_groups")) { if (value < 1 || value > 8) return MVR_E_ARG; c->pair_groups = value; }
   else if (!std::strcmp(key, "inplace_ratio")) c->inplace_ratio = value;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
+  else return MVR_E_ARG;
+  return MVR_OK;
+}
+
+API int mvr_ctx_stat(mvr_ctx *ctx, const char *key, double *value)
+{
+  if (!ctx || !key || !value) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (!std::strcmp(key, "piped_passes")) *value = (double)c->piped_passes;
+  else if (!std::strcmp(key, "fused_passes")) *value = (double)c->fused_passes;
+  else if (!std::strcmp(key, "blocking_events")) *value = (double)c->blocking_events;
+  else if (!std::strcmp(key, "pipeline")) *value = (double)c->pipeline;
   else return MVR_E_ARG;
   return MVR_OK;
 }

@@ -116,14 +116,14 @@ __global__ void g2h_kernel(const uint32_t *__restrict__ gperm, const uint32_t *_
 
 // posed coordinates in grid order: the SAME function of the same inputs as the posed points themselves
 // (pose_point_f64 of the canonical point), so gsorted[k].xyz == pts[gperm[k]].xyz bit for bit
-struct GridPoseBatch { const float4 *graw[kBatchClouds]; float4 *out[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; };
+struct GridPoseBatch { const float4 *graw[kBatchClouds]; float4 *out[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; const Mat44d *Tp[kBatchClouds]; };
 __global__ void grid_pose_kernel(GridPoseBatch b)
 {
   const int cl = blockIdx.y;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= b.n[cl]) return;
   const float4 p = b.graw[cl][k];
-  float4 v = pose_point_f64(b.T[cl], p);
+  float4 v = pose_point_f64(b.Tp[cl] ? *b.Tp[cl] : b.T[cl], p);
   v.w = p.w;
   b.out[cl][k] = v;
 }
@@ -432,6 +432,7 @@ bool ensure_grid(Ctx *c, Cloud &canon, double reach)
   canon.grid.reset();
   auto it = c->grids.find(canon.set_id);
   if (it != c->grids.end()) { canon.grid = it->second.lock(); if (canon.grid && canon.grid->n == n) return true; canon.grid.reset(); }
+  if (may_block(c, "not in steady state: a point set has no grid yet") != MVR_OK) return false;
   // bounding box (one small round trip, once per scan): the cell edge and the grid's dimensions come from it
   float hb[6];
   if (cloud_bbox(c, canon.pts, n, hb) != MVR_OK) return false;
@@ -518,12 +519,13 @@ int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
       }
       b.graw[used] = cl->grid->graw; b.out[used] = cl->gsorted; b.n[used] = cl->n;
       std::memcpy(b.T[used].m, cl->pose, sizeof b.T[used].m);
+      b.Tp[used] = (c->pose_from_table && cl->pose_dev) ? &cl->pose_dev->T : nullptr;
       nmax = std::max(nmax, cl->n);
       cl->gcoords_valid = true;
       ++used;
     }
     if (!used) continue;
-    for (int k = used; k < kBatchClouds; ++k) { b.graw[k] = nullptr; b.out[k] = nullptr; b.n[k] = 0; }
+    for (int k = used; k < kBatchClouds; ++k) { b.graw[k] = nullptr; b.out[k] = nullptr; b.n[k] = 0; b.Tp[k] = nullptr; }
     ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)nmax * used);
     hipLaunchKernelGGL(grid_pose_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)used), dim3(256), 0, c->stream, b);
     MVR_HIP_TRY(c, hipGetLastError());
@@ -556,6 +558,7 @@ GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cl
   }
   p.nt = (uint32_t)t.n;
   p.keys = keys;
+  p.pose_dev = t.pose_dev;      // (a pass enqueued ahead of its poses: minv / stretch above are placeholders, the kernels read the device record)
   return p;
 }
 

@@ -209,9 +209,10 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
       float4 v;
       if (from) {                     // posed copy of an indexed cloud: pose its sorted copy, in order
         const float4 p = from[k];
-        v = pose_point_f64(rb.T[cloud], p);
+        const Mat44d &T = rb.Tp[cloud] ? *rb.Tp[cloud] : rb.T[cloud];
+        v = pose_point_f64(T, p);
         v.w = p.w;
-        if (rb.xsrc[cloud]) rb.xdst[cloud][k] = pose_point_f64(rb.T[cloud], rb.xsrc[cloud][k]);     // and the points in original order
+        if (rb.xsrc[cloud]) rb.xdst[cloud][k] = pose_point_f64(T, rb.xsrc[cloud][k]);     // and the points in original order
       } else {
         const uint32_t o = perm[k];
         v = pts[o];
@@ -428,6 +429,7 @@ __global__ void scatter_slot_kernel(const uint32_t *__restrict__ list, const uin
 int ensure_cub(Ctx *c, size_t bytes)
 {
   if (c->cub_cap >= bytes) return MVR_OK;
+  MVR_MAY_BLOCK(c, "hipCUB scratch has to grow");
   if (c->cub_tmp) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->cub_tmp); c->cub_tmp = nullptr; c->cub_cap = 0; }
   MVR_HIP_TRY(c, hipMalloc(&c->cub_tmp, bytes + 4096));
   c->cub_cap = bytes + 4096;
@@ -460,6 +462,7 @@ void inherit_point_set(Cloud &dst, const Cloud &src)
 int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6])
 {
   if (n == 0) return MVR_E_ARG;
+  MVR_MAY_BLOCK(c, "a bounding box is read back");
   if (int rc = ensure(c, c->partials, c->partials_cap, (size_t)1024 * 32)) return rc;
   const int bb = (int)std::min<size_t>(256, (n + 255) / 256);
   float *part = reinterpret_cast<float *>(c->partials);
@@ -508,6 +511,7 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
     cl.stale_coords();
   }
   if (!cl.order) {
+    MVR_MAY_BLOCK(c, "a point set has no ordering yet");
     // sort once per point set: bbox -> 30-bit Morton codes -> radix sort -> perm / inv
     if (c->sort_cap < n) {
       (void)hipStreamSynchronize(c->stream);
@@ -565,6 +569,7 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
     if (int rc = ensure(c, cl.sorted, cl.sorted_cap, cl.sorted_cap >= n ? n : room)) return rc;
     if (cl.sorted != sorted_before) cl.fresh_tiles = 0;          // a new buffer holds nothing
     if (cl.tiles_cap < tiles) {
+      MVR_MAY_BLOCK(c, "a cloud's box arrays have to grow");
       cl.fresh_tiles = 0;
       (void)hipStreamSynchronize(c->stream);
       if (cl.tlo) (void)hipFree(cl.tlo);
@@ -586,7 +591,7 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
 
 // from / T: optional, per cloud (see RefreshBatch)
 static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *const *from = nullptr, const double *T = nullptr,
-                         const float4 *const *xsrc = nullptr)
+                         const float4 *const *xsrc = nullptr, const Mat44d *const *Tp = nullptr)
 {
   for (int base = 0; base < count; base += kBatchClouds) {
     RefreshBatch rb;
@@ -596,6 +601,7 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
       Cloud *cl = k < m ? clouds[base + k] : nullptr;
       rb.from[k] = (cl && from) ? from[base + k] : nullptr;
       if (rb.from[k]) std::memcpy(rb.T[k].m, T + (size_t)(base + k) * 16, sizeof rb.T[k].m);
+      rb.Tp[k] = (rb.from[k] && Tp) ? Tp[base + k] : nullptr;
       rb.xsrc[k] = (rb.from[k] && xsrc) ? xsrc[base + k] : nullptr;
       rb.xdst[k] = rb.xsrc[k] ? cl->pts : nullptr;
       rb.pts[k] = cl ? cl->pts : nullptr; rb.perm[k] = cl ? cl->order->perm : nullptr; rb.n[k] = cl ? cl->n : 0;
@@ -619,7 +625,7 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
 
 int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts, char *handled)
 {
-  std::vector<Cloud *> todo; std::vector<const float4 *> from, xsrc; std::vector<double> Ts;
+  std::vector<Cloud *> todo; std::vector<const float4 *> from, xsrc; std::vector<double> Ts; std::vector<const Mat44d *> Tps;
   for (int k = 0; k < count; ++k) {
     Cloud *d = dst[k], *s = src[k];
     if (handled) handled[k] = 0;
@@ -633,9 +639,10 @@ int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src,
     if (int rc = ensure_index(c, *s)) return rc;            // the source's sorted copy: gathered once, then reused every pose
     if (!stale || d->order != s->order) continue;
     todo.push_back(d); from.push_back(s->sorted); xsrc.push_back(s->pts); Ts.insert(Ts.end(), T + (size_t)k * 16, T + (size_t)k * 16 + 16);
+    Tps.push_back((c->pose_from_table && d->pose_dev) ? &d->pose_dev->T : nullptr);      // (an address in device memory: not read here)
     if (handled) handled[k] = 1;
   }
-  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data(), with_pts ? xsrc.data() : nullptr);
+  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data(), with_pts ? xsrc.data() : nullptr, Tps.data());
 }
 
 int ensure_index(Ctx *c, Cloud &cl)

@@ -73,6 +73,15 @@ struct Seg { uint32_t local_begin, count, global_begin; };
 constexpr int kMaxSegs = 64;
 struct SegTable { uint32_t n; uint32_t lb[kMaxSegs], cnt[kMaxSegs], gb[kMaxSegs]; };
 
+struct Mat44d { double m[16]; };
+// pose-derived parameters of one posed cloud, in DEVICE memory: what the kernels of a pass that was enqueued before its
+// poses were known read instead of by-value arguments (the pipelined ring run, mvr_ctx.hip)
+struct PoseRec {
+  Mat44d T;                 // the pose (column-major 4 x 4)
+  double minv[12];          // its inverse affine map, row-major 3 x 4: posed frame -> canonical frame
+  float stretch, pad_;      // bound of how much the inverse lengthens a distance (1 for a rigid pose)
+};
+
 struct Cloud {
   float4 *pts = nullptr;
   size_t n = 0;
@@ -98,6 +107,11 @@ struct Cloud {
   std::shared_ptr<CellGrid> grid;          // the set's grid (shared)
   float4 *gsorted = nullptr; size_t gsorted_cap = 0;      // posed coordinates in grid order, w = bits(original index)
   bool gcoords_valid = false;          // gsorted matches pts
+  // pipelined ring run (mvr_ctx.hip: ring_passes): where the kernels of a pass that is enqueued BEFORE its poses are known
+  // find this posed copy's pose, inverse and stretch (device memory, filled by pose_prep_kernel once the host's solve has
+  // released the pass); null outside such a run
+  const struct PoseRec *pose_dev = nullptr;
+  bool posed_by_table = false;         // ... and the last transform of this cloud did read it (its host-side pose is filled in when the run leaves the pipe)
 };
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;      // "no neighbour" index
@@ -212,8 +226,29 @@ struct Ctx {
   int pair_fused = 1;                                 // culled mode: all pairs of a batch in one launch per stage (0: worker streams)
   int posed_refresh = 1;                              // mvr_cloud_transform_batch brings the posed copies' index up to date from the sources' sorted copies
   int pair_groups = 2;                                // fused pass: groups of pairs on concurrent streams (1: a single stream); measured on the 12-pair ring: 1.27 / 1.22 / 1.28 / 1.39 ms per step with 1 / 2 / 3 / 4
+  // ---- pipelined ring run (ring_passes, mvr_ctx.hip): pass k+1's whole launch chain is enqueued while pass k runs, behind
+  // a gate the host opens after its solve; the poses reach the kernels through a device table instead of kernel arguments
+  int pipeline = 1;                                   // 0: every pass is enqueued after the previous solve (round-2 behaviour)
+  bool no_sync = false;                               // a gated chain is being enqueued: nothing may wait for the stream or reallocate (may_block)
+  unsigned long long blocking_events = 0;             // how often something did wait / reallocate (a pass without any is in steady state)
+  bool pose_from_table = false;                       // mvr_cloud_transform_batch ignores its T values: every destination reads Cloud::pose_dev
+  double *h_pose_in = nullptr, *d_pose_in = nullptr;  // pinned, mapped: [2][views][16] poses the host writes before it opens the gate
+  PoseRec *pose_tab = nullptr; size_t pose_tab_cap = 0;      // device: [2][views]
+  uint32_t *gate = nullptr; bool gate_is_signal = false;     // host-writable word the stream waits on (hipStreamWaitValue32)
+  uint32_t *h_done = nullptr, *d_done = nullptr;      // pinned, mapped: the stream writes the pass number here when a pass's chain has drained
+  uint32_t pipe_seq = 0;                              // passes sent through the pipe so far
+  unsigned long long pipe_steady_sig = 0, pipe_steady_events = ~0ull;      // the registration whose last run ended in steady state, and blocking_events then
+  unsigned long long piped_passes = 0;                // passes of this context whose chain was enqueued ahead of their poses (diagnostics)
   // multi-GPU (mvr_world.cpp): an RCCL communicator (ncclComm_t; null = this context is a world of its own)
   void *comm = nullptr; bool comm_owned = false; int comm_rank = 0, comm_world = 1;
+  void **comm_lender = nullptr;                       // a world's communicator is lent: where the world keeps it (cleared when it is aborted here)
+  bool comm_broken = false;                           // the communicator was aborted (a peer failed or never arrived): the multi-GPU entry points refuse until a new one is set
+  int wait_timeout_ms = 60000;                        // how long a rank waits for a pass that contains a collective before it declares its peers lost
+  // failure injection (tests; mvr_ctx_tune): the dist_pass-th sharded pass / iteration since the knob was set
+  long long dist_pass = 0, inject_fail_at = -1, inject_stall_at = -1;
+  uint32_t *h_stall = nullptr, *d_stall = nullptr;    // pinned word an injected stall waits on (released by comm_abort)
+  long long *seq_keys = nullptr; size_t seq_keys_cap = 0;    // [Ns] signed keys with global target indices (sequential mode, target sharded)
+  double *seq_row = nullptr;                                 // device: 40 doubles = one row of sums + the failure count of the iteration
   double *dist_table = nullptr; size_t dist_table_cap = 0;   // [edges][32]: this rank's rows, all-reduced in place
   // instrumentation
   bool prof = false;
@@ -254,10 +289,23 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// A pass enqueued behind a host-released gate must not wait for its own stream (the host would wait for itself) nor free
+// what queued kernels use: every place that synchronises or reallocates asks here first.  The runner treats the error as
+// "this pass is not in steady state yet" and enqueues it the ordinary way.
+inline int may_block(Ctx *c, const char *what)
+{
+  Ctx *top = c->parent ? c->parent : c;
+  ++top->blocking_events;
+  if (top->no_sync) return set_error(c, MVR_E_HIP, what);
+  return MVR_OK;
+}
+#define MVR_MAY_BLOCK(ctx, what) do { if (int rc_ = ::mvr::may_block((ctx), "not in steady state: " what)) return rc_; } while (0)
+
 template <class T>
 int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
 {
   if (cap >= want) return MVR_OK;
+  MVR_MAY_BLOCK(c, "a work buffer has to grow");
   if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); p = nullptr; cap = 0; }
   size_t ncap = want + want / 4 + 64;
   MVR_HIP_TRY(c, hipMalloc(&p, ncap * sizeof(T)));
@@ -267,8 +315,8 @@ int ensure(Ctx *c, T *&p, size_t &cap, size_t want)
 
 // several clouds per launch (kernel arguments by value)
 constexpr int kBatchClouds = 16;
-struct Mat44d { double m[16]; };
-struct XformBatch { const float4 *src[kBatchClouds]; float4 *dst[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; };
+// (Tp[k], when set, overrides T[k]: the pose is read from device memory -- see PoseRec)
+struct XformBatch { const float4 *src[kBatchClouds]; float4 *dst[kBatchClouds]; unsigned long long n[kBatchClouds]; Mat44d T[kBatchClouds]; const Mat44d *Tp[kBatchClouds]; };
 // p' = T p as mvr_cloud_transform (f64 pose, f32 result): the ONE definition, shared by the transform kernels
 // and by the index refresh that poses a scan's sorted copy directly (same operations, same bits)
 __device__ __forceinline__ float4 pose_point_f64(const Mat44d &T, const float4 p)
@@ -287,7 +335,7 @@ struct RefreshBatch {
   float4 *sorted[kBatchClouds], *tlo[kBatchClouds], *thi[kBatchClouds], *cbox[kBatchClouds], *sbox[kBatchClouds];
   // optional: the sorted copy of the cloud this one is a posed copy of (same ordering) and the pose -- the refresh
   // then reads that copy in order and poses it, instead of gathering pts[] through the permutation
-  const float4 *from[kBatchClouds]; Mat44d T[kBatchClouds];
+  const float4 *from[kBatchClouds]; Mat44d T[kBatchClouds]; const Mat44d *Tp[kBatchClouds];      // (Tp[k], when set, overrides T[k])
   // optional, with `from`: the source's points in original order and where their posed copies go (the transform itself,
   // done by the same launch)
   const float4 *xsrc[kBatchClouds]; float4 *xdst[kBatchClouds];
@@ -297,7 +345,8 @@ struct RefreshBatch {
 // with_pts: also write dst->pts = T * src->pts.  handled[k] (optional) = cloud k was refreshed by this call.
 int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts = false,
                         char *handled = nullptr);
-int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T);
+int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T,
+                               const Mat44d *const *Tp = nullptr);
 int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count);     // ensure_index for many clouds, coordinates refreshed in one launch
 
 // ---- kernel launchers (mvr_nn.hip / mvr_reduce.hip / mvr_index.hip) -----------
@@ -369,13 +418,6 @@ inline void xcd_map_plan(XcdMap &map, int forced_slices, unsigned *grid_blocks)
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma);     // only the query sets on the pairs' set lists (Q = 1)
 // ---- grid search (mvr_grid.hip): exact 1-NN of seeded / bounded queries, one thread per query
-// pose-derived parameters of one posed cloud, in DEVICE-VISIBLE memory: what the kernels of a pass that was enqueued
-// before its poses were known read instead of by-value arguments (the pipelined ring run, mvr_ctx.hip)
-struct PoseRec {
-  Mat44d T;                 // the pose (column-major 4 x 4)
-  double minv[12];          // its inverse affine map, row-major 3 x 4: posed frame -> canonical frame
-  float stretch, pad_;      // bound of how much the inverse lengthens a distance (1 for a rigid pose)
-};
 struct GridPair {
   const float4 *qs = nullptr;                 // queries: a Hilbert-ordered posed cloud (w = original index)
   const uint32_t *qlist = nullptr, *qcount = nullptr;     // optional: compacted query positions + their device count (key slot = list position)
@@ -416,6 +458,22 @@ int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
 int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo xyz, hi xyz} on the host (synchronises the stream)
 bool ensure_grid(Ctx *c, Cloud &canon, double reach);      // reach: the search radius the distance map should be able to rule out (mm)
 int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
+// the pipelined pass loop shared by mvr_ring_run and mvr_ring_run_sharded (mvr_ctx.hip).  enqueue(): one pass's GPU work on
+// c->stream, ending with the edge table on its way to c->h_table; solve(): the host step on c->h_table, poses in / out.
+struct PassLoop {
+  int n_views = 0; const int *posed_slots = nullptr, *raw_slots = nullptr; double *poses = nullptr;     // poses: [views][16], in / out
+  int (*enqueue)(void *self) = nullptr; int (*solve)(void *self) = nullptr; void *self = nullptr;
+  unsigned long long sig = 0;      // identifies the registration (slots, point sets, edges, parameters): a run that ended in steady state lets the next run of the SAME registration start pipelined
+};
+unsigned long long pass_loop_sig(Ctx *c, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src, const int *edge_tgt,
+                                 double max_dist, int reciprocal, int fma, int extra);
+int ring_passes(Ctx *c, int n_steps, const PassLoop &loop, double timing_ms[3]);
+// ---- collectives of a context (mvr_world.cpp); every one of them is a no-op returning MVR_OK without a communicator
+enum { kReduceMinI64 = 0, kReduceSumF64 = 1 };
+int comm_allreduce(Ctx *c, void *dev_buf, size_t count, int kind);      // in place, on the context's stream
+int comm_poll(Ctx *c);                        // RCCL's asynchronous error state; an error aborts the communicator -> MVR_E_RCCL
+int comm_abort(Ctx *c, const char *why);      // ncclCommAbort + release of anything that could hold the stream; returns MVR_E_RCCL
+int stream_wait(Ctx *c);                      // hipStreamSynchronize; with a communicator: bounded by wait_timeout_ms and watching comm_poll, a timeout aborts
 GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cloud &t, nnkey_t *keys);
 int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
                    bool fma, nnkey_t *keys);

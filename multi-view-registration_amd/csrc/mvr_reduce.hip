@@ -195,7 +195,7 @@ __global__ void transform_f64_batch_kernel(XformBatch b)
   const int k = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n[k]) return;
-  const float4 o = pose_point_f64(b.T[k], b.src[k][i]);
+  const float4 o = pose_point_f64(b.Tp[k] ? *b.Tp[k] : b.T[k], b.src[k][i]);
   b.dst[k][i] = o;
 }
 
@@ -671,7 +671,8 @@ int launch_transform_f64(Ctx *c, const float4 *in, float4 *out, size_t n, const 
   return MVR_OK;
 }
 
-int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T)
+int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float4 *const *out, const size_t *n, const double *T,
+                               const Mat44d *const *Tp)
 {
   for (int base = 0; base < count; base += kBatchClouds) {
     XformBatch b;
@@ -681,6 +682,7 @@ int launch_transform_f64_batch(Ctx *c, int count, const float4 *const *in, float
       const bool live = k < m;
       b.src[k] = live ? in[base + k] : nullptr; b.dst[k] = live ? out[base + k] : nullptr; b.n[k] = live ? n[base + k] : 0;
       for (int j = 0; j < 16; ++j) b.T[k].m[j] = live ? T[(size_t)(base + k) * 16 + j] : 0.0;
+      b.Tp[k] = (live && Tp) ? Tp[base + k] : nullptr;
       nmax = std::max(nmax, (size_t)b.n[k]); work += 32.0 * (double)b.n[k];
     }
     if (nmax == 0) continue;

@@ -42,6 +42,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                               // (optional symbols: older libraries)
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -62,7 +64,7 @@ Rccl &rccl()
 #define MVR_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
     MVR_SYM(GetUniqueId, "ncclGetUniqueId"); MVR_SYM(CommInitRank, "ncclCommInitRank"); MVR_SYM(CommInitAll, "ncclCommInitAll");
     MVR_SYM(CommDestroy, "ncclCommDestroy"); MVR_SYM(CommCount, "ncclCommCount"); MVR_SYM(AllReduce, "ncclAllReduce");
-    MVR_SYM(GetErrorString, "ncclGetErrorString");
+    MVR_SYM(GetErrorString, "ncclGetErrorString"); MVR_SYM(CommAbort, "ncclCommAbort"); MVR_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
 #undef MVR_SYM
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
       r.error = "RCCL library lacks an expected symbol: " + r.path;
@@ -99,6 +101,89 @@ std::vector<Segment> split_queries(const std::vector<size_t> &sizes, int world, 
 }
 
 }  // namespace
+
+// ---- what the rest of the library sees of a communicator (declared in mvr_internal.h) ----------------------------------
+// Failure model.  A collective needs every rank; RCCL neither notices a peer that died nor one that left its loop early.
+// (1) A rank whose LOCAL work fails does not leave: it joins the pass's collectives with neutral contributions and a
+//     raised failure count in the reduced table, so all ranks end that pass together, each with an error.
+// (2) A rank that waits for a pass containing a collective waits at most wait_timeout_ms, polling RCCL's asynchronous error
+//     state meanwhile; on either it aborts the communicator (ncclCommAbort: the queued collective kernels exit), drains
+//     its stream and returns MVR_E_RCCL.  The context stays usable for single-GPU work; the communicator is gone.
+int comm_abort(Ctx *c, const char *why)
+{
+  Rccl &r = rccl();
+  if (c->h_stall) __atomic_store_n(c->h_stall, 1u, __ATOMIC_RELEASE);            // (an injected stall must not outlive the abort)
+  if (c->comm) {
+    if (r.lib && r.CommAbort) (void)r.CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
+    if (c->comm_lender) *c->comm_lender = nullptr;                                // a world's communicator: the world must not destroy it again
+    c->comm = nullptr; c->comm_owned = false; c->comm_lender = nullptr;
+    c->comm_broken = true;
+  }
+  return set_error(c, MVR_E_RCCL, why);
+}
+
+int comm_poll(Ctx *c)
+{
+  if (!c->comm) return MVR_OK;
+  Rccl &r = rccl();
+  if (!r.lib || !r.CommGetAsyncError) return MVR_OK;
+  ncclResult_t st = ncclSuccess;
+  if (r.CommGetAsyncError(reinterpret_cast<ncclComm_t>(c->comm), &st) != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) {
+    std::string msg = "RCCL reports an asynchronous error";
+    if (r.GetErrorString) { msg += ": "; msg += r.GetErrorString(st); }
+    return comm_abort(c, msg.c_str());
+  }
+  return MVR_OK;
+}
+
+int stream_wait(Ctx *c)
+{
+  if (!c->comm && !c->h_stall) { MVR_HIP_TRY(c, hipStreamSynchronize(c->stream)); return MVR_OK; }
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  unsigned n = 0;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return MVR_OK;
+    if (e != hipErrorNotReady) return set_error(c, MVR_E_HIP, "hipStreamQuery", e);
+    if ((++n & 0x3FFu) == 0u) {
+      if (int rc = comm_poll(c)) { (void)hipStreamSynchronize(c->stream); return rc; }
+      if (std::chrono::duration<double, std::milli>(clk::now() - t0).count() > (double)c->wait_timeout_ms) {
+        const int rc = comm_abort(c, "a pass with a collective did not finish in time: a peer failed or never arrived");
+        (void)hipStreamSynchronize(c->stream);                                    // the aborted collective and everything behind it drain now
+        return rc;
+      }
+    }
+    __builtin_ia32_pause();
+  }
+}
+
+int comm_allreduce(Ctx *c, void *dev_buf, size_t count, int kind)
+{
+  if (c->inject_stall_at >= 0 && c->dist_pass - 1 == c->inject_stall_at) {
+    // test hook: this rank's stream stalls in front of the collective, as if a peer never arrived (released by comm_abort)
+    if (!c->h_stall) {
+      MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_stall), 64, hipHostMallocMapped));
+      MVR_HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_stall), c->h_stall, 0));
+    }
+    *c->h_stall = 0u;
+    c->inject_stall_at = -1;
+    MVR_HIP_TRY(c, hipStreamWaitValue32(c->stream, c->d_stall, 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+  }
+  if (!c->comm || count == 0) return MVR_OK;
+  Rccl &r = rccl();
+  if (!r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
+  const ncclResult_t e = kind == kReduceMinI64
+      ? r.AllReduce(dev_buf, dev_buf, count, ncclInt64, ncclMin, reinterpret_cast<ncclComm_t>(c->comm), c->stream)
+      : r.AllReduce(dev_buf, dev_buf, count, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(c->comm), c->stream);
+  if (e != ncclSuccess) {
+    std::string msg = "ncclAllReduce";
+    if (r.GetErrorString) { msg += ": "; msg += r.GetErrorString(e); }
+    return comm_abort(c, msg.c_str());
+  }
+  return MVR_OK;
+}
+
 }  // namespace mvr
 
 using namespace mvr;
@@ -145,7 +230,7 @@ API int mvr_ctx_comm_init(mvr_ctx *ctx, const char id[MVR_UNIQUE_ID_BYTES], int 
   ncclComm_t comm = nullptr;
   const ncclResult_t e = r.CommInitRank(&comm, world, u, rank);
   if (e != ncclSuccess) return rccl_fail(c, "ncclCommInitRank", e);
-  c->comm = comm; c->comm_owned = true; c->comm_rank = rank; c->comm_world = world;
+  c->comm = comm; c->comm_owned = true; c->comm_rank = rank; c->comm_world = world; c->comm_lender = nullptr; c->comm_broken = false;
   return MVR_OK;
 }
 
@@ -158,7 +243,7 @@ API int mvr_ctx_comm_destroy(mvr_ctx *ctx)
     (void)hipStreamSynchronize(c->stream);
     (void)rccl().CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
   }
-  c->comm = nullptr; c->comm_owned = false; c->comm_rank = 0; c->comm_world = 1;
+  c->comm = nullptr; c->comm_owned = false; c->comm_rank = 0; c->comm_world = 1; c->comm_lender = nullptr; c->comm_broken = false;
   return MVR_OK;
 }
 
@@ -272,6 +357,52 @@ API int mvr_ring_rows_sharded(mvr_ctx *ctx, int rank, int world, int n_views, co
   return MVR_OK;
 }
 
+namespace {
+// one rank's pass of the sharded ring run, in the two halves ring_passes drives
+struct RankRun {
+  mvr_ctx *ctx; RankPlan plan; int n_views, ne; const int *edge_src, *edge_tgt; double max_dist; int reciprocal, fma; const double *origin;
+  int lum_iterations; double *poses, *lum_pose; float *pair_T; double *pair_n, *pair_mse; int *lum_iters; double *rows;
+  std::vector<double> pn, pm;
+  int local_error = MVR_OK;
+  static int enqueue(void *p)
+  {
+    RankRun &r = *static_cast<RankRun *>(p);
+    Ctx *c = CTX(r.ctx);
+    const size_t table_n = (size_t)(r.ne + 1) * 32;                 // the edge rows + one status row ([0] = ranks whose local work failed)
+    int local = MVR_OK;
+    if (c->inject_fail_at >= 0 && c->dist_pass == c->inject_fail_at) {
+      if (c->no_sync) return set_error(c, MVR_E_HIP, "not in steady state: injected failure");      // (it strikes when the pass is enqueued the ordinary way)
+      local = set_error(c, MVR_E_HIP, "injected failure of this rank's local work");
+    }
+    ++c->dist_pass;
+    if (local == MVR_OK) local = enqueue_rank_rows(r.ctx, r.plan, r.ne, r.max_dist, r.reciprocal, r.fma, r.origin, r.poses);
+    // a chain that is being queued ahead of its poses and turns out not to be in steady state is simply enqueued again the
+    // ordinary way (ring_passes): nothing of it may reach the collective.  Any OTHER failure of the local work is reported
+    // THROUGH the collective, so that the peers end this pass with an error too instead of waiting in it for ever.
+    if (local != MVR_OK && c->no_sync) return local;
+    r.local_error = local;
+    if (local != MVR_OK) MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table, 0, (size_t)r.ne * 32 * sizeof(double), c->stream));
+    c->h_moments[49] = local == MVR_OK ? 0.0 : 1.0;
+    MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table + (size_t)r.ne * 32, 0, 32 * sizeof(double), c->stream));
+    if (local != MVR_OK) MVR_HIP_TRY(c, hipMemcpyAsync(c->dist_table + (size_t)r.ne * 32, c->h_moments + 49, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (int rc = comm_allreduce(c, c->dist_table, table_n, kReduceSumF64)) return rc;
+    MVR_HIP_TRY(c, hipMemcpyAsync(c->h_table, c->dist_table, table_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return MVR_OK;
+  }
+  static int solve(void *p)
+  {
+    RankRun &r = *static_cast<RankRun *>(p);
+    Ctx *c = CTX(r.ctx);
+    if (c->h_table[(size_t)r.ne * 32] > 0.0)
+      return r.local_error != MVR_OK ? r.local_error : set_error(c, MVR_E_RCCL, "a peer's local work failed in this pass");
+    if (r.rows && r.ne) std::memcpy(r.rows, c->h_table, (size_t)r.ne * 32 * sizeof(double));
+    const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, c->h_table, r.origin, r.lum_iterations, r.poses, r.lum_pose, r.pair_T,
+                                      r.pair_n ? r.pair_n : r.pn.data(), r.pair_mse ? r.pair_mse : r.pm.data(), r.lum_iters);
+    return rc != MVR_OK ? set_error(c, rc, "LUM solve") : MVR_OK;
+  }
+};
+}  // namespace
+
 API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_slots, const int *raw_slots, int ne,
                              const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                              int lum_iterations, double *poses, double *lum_pose, float *pair_T, double *pair_n, double *pair_mse,
@@ -281,37 +412,21 @@ API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *
     return MVR_E_ARG;
   Ctx *c = CTX(ctx);
   MVR_HIP_TRY(c, hipSetDevice(c->device));
+  if (c->comm_broken) return set_error(c, MVR_E_RCCL, "the communicator of this context was aborted");
   const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
   Rccl &r = rccl();
   if (c->comm && !r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
-  RankPlan plan;
-  if (int rc = make_rank_plan(ctx, rank, world, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, &plan)) return rc;
-  if (int rc = ensure_tables(c, ne)) return rc;
-  using clk = std::chrono::steady_clock;
-  double sum[3] = {0.0, 0.0, 0.0};
-  std::vector<double> pn((size_t)ne), pm((size_t)ne);
-  for (int step = 0; step < n_steps; ++step) {
-    const auto t0 = clk::now();
-    if (int rc = enqueue_rank_rows(ctx, plan, ne, max_dist, reciprocal, fma, origin, poses)) return rc;
-    if (c->comm && ne) {
-      const ncclResult_t e = r.AllReduce(c->dist_table, c->dist_table, (size_t)ne * 32, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(c->comm), c->stream);
-      if (e != ncclSuccess) return rccl_fail(c, "ncclAllReduce", e);
-    }
-    if (ne) MVR_HIP_TRY(c, hipMemcpyAsync(c->h_table, c->dist_table, (size_t)ne * 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    const auto t1 = clk::now();
-    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const auto t2 = clk::now();
-    if (rows && ne) std::memcpy(rows, c->h_table, (size_t)ne * 32 * sizeof(double));
-    const int rc = mvr_ring_host_step(n_views, ne, edge_src, edge_tgt, c->h_table, origin, lum_iterations, poses, lum_pose, pair_T,
-                                      pair_n ? pair_n : pn.data(), pair_mse ? pair_mse : pm.data(), lum_iters);
-    const auto t3 = clk::now();
-    sum[0] += std::chrono::duration<double, std::milli>(t1 - t0).count();
-    sum[1] += std::chrono::duration<double, std::milli>(t2 - t1).count();
-    sum[2] += std::chrono::duration<double, std::milli>(t3 - t2).count();
-    if (rc != MVR_OK) return set_error(c, rc, "LUM solve");
-  }
-  if (timing_ms) for (int j = 0; j < 3; ++j) timing_ms[j] = sum[j];
-  return MVR_OK;
+  // everything that can fail for local reasons and is known up front happens BEFORE the first collective: the plan,
+  // the tables (the passes themselves report later failures through the collective, see RankRun::enqueue)
+  RankRun run{ctx, RankPlan(), n_views, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin, lum_iterations, poses, lum_pose, pair_T,
+              pair_n, pair_mse, lum_iters, rows, std::vector<double>((size_t)ne), std::vector<double>((size_t)ne), MVR_OK};
+  if (int rc = make_rank_plan(ctx, rank, world, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, &run.plan)) return rc;
+  if (int rc = ensure_tables(c, ne + 1)) return rc;
+  PassLoop L;
+  L.n_views = n_views; L.posed_slots = posed_slots; L.raw_slots = raw_slots; L.poses = poses;
+  L.enqueue = &RankRun::enqueue; L.solve = &RankRun::solve; L.self = &run;
+  L.sig = pass_loop_sig(c, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, 1 + rank + 1000 * world);
+  return ring_passes(c, n_steps, L, timing_ms);
 }
 
 // ------------------------------------------------------------------ one process, all GPUs
@@ -340,6 +455,7 @@ API int mvr_world_create(mvr_world **out, int n_dev, const int *device_ids)
   for (int k = 0; k < n_dev; ++k) {
     Ctx *c = CTX(w->ctx[(size_t)k]);
     c->comm = w->comm[(size_t)k]; c->comm_owned = false; c->comm_rank = k; c->comm_world = n_dev;
+    c->comm_lender = reinterpret_cast<void **>(&w->comm[(size_t)k]);
   }
   *out = w;
   return MVR_OK;
@@ -348,7 +464,7 @@ API int mvr_world_create(mvr_world **out, int n_dev, const int *device_ids)
 API int mvr_world_destroy(mvr_world *w)
 {
   if (!w) return MVR_E_ARG;
-  for (mvr_ctx *c : w->ctx) if (c) { (void)mvr_ctx_sync(c); CTX(c)->comm = nullptr; }
+  for (mvr_ctx *c : w->ctx) if (c) { (void)mvr_ctx_sync(c); CTX(c)->comm = nullptr; CTX(c)->comm_lender = nullptr; }
   for (ncclComm_t cm : w->comm) if (cm && rccl().lib) (void)rccl().CommDestroy(cm);
   for (mvr_ctx *c : w->ctx) if (c) (void)mvr_ctx_destroy(c);
   delete w;

@@ -16,12 +16,22 @@ and after the align every rank appends ITS slice of the transformed source to it
 Ties go to the lowest GLOBAL target index, so the correspondences are exactly those of the
 single-GPU / single-process run; the sums differ only in the order of f64 additions.
 
-The driver is written over a list of local PARTS (shards held by this process) and two
-reduction callables across processes, so the same code runs
-  * one part per process under torch.distributed (RCCL on GPUs, gloo in the CPU tests),
-  * several parts in one process (a 1-GPU "fake world" that walks the shards serially).
-A part is a backend object: HipPart (this package, mvr_hip.h entry points) on the GPU; the
-tests plug the CPU oracle in as a second backend."""
+THE PRODUCT'S HOST FOR THIS MODE IS NATIVE: mvr_seq_run_sharded / mvr_seq_align_sharded (csrc/mvr_ctx.hip, the
+collectives on the library's own RCCL communicator in csrc/mvr_world.cpp), wrapped below as
+NativeShardedSequentialICP -- one rank = one context + its communicator, torch (or any launcher) only carries
+rank 0's 128-byte unique id.
+
+ShardedSequentialICP is the same loop, statement by statement, over PLUGGABLE parts and reductions: it exists so
+that the partitioning, the tie rule and the failure protocol can be exercised where no second GPU is --
+  * several parts in one process (a 1-GPU "fake world" that walks the shards serially, tests/test_gpu_seq.py),
+  * one part per process over gloo with the CPU oracle as the part (tests/test_seq_dist.py).
+A part is a backend object: HipPart (this package, the very C entry points the native loop calls) on the GPU; the
+tests plug the CPU oracle in as a second backend.
+
+Failure protocol (the native loop's, rehearsed here): a rank whose LOCAL work fails does not leave the loop -- it
+joins the iteration's two reductions with neutral keys, a zero row and a raised failure count, so that every rank
+ends that iteration with RankFailure instead of one rank leaving its peers inside a collective; a reduction that
+itself fails (a peer died: gloo / RCCL error or timeout) surfaces as RankFailure too."""
 import numpy as np
 
 from . import (Context, IcpParams, PairMoments2, mat4d_mul, mat4f_mul, moments_from_moments2,
@@ -45,6 +55,10 @@ def view_order(n_views=12):
 def slice_bounds(n, parts):
     """equal contiguous slices of a scan of n points: part g owns [b[g], b[g+1])"""
     return [n * g // parts for g in range(parts + 1)]
+
+
+class RankFailure(RuntimeError):
+    """this rank's local work, a peer's, or a collective failed: the registration cannot go on (never a hang)"""
 
 
 class HipPart:
@@ -120,6 +134,24 @@ class HipPart:
         with self._on_stream():
             return keys.cpu().numpy()
 
+    # -- failure protocol: neutral contributions, the failure count rides in the row's origin slot (a constant, re-set
+    #    after the reduction)
+    def neutral_keys(self):
+        with self._on_stream():
+            k = self.keys[: self.ns]
+            k.fill_(INT64_MAX)
+        return k
+
+    def neutral_row(self):
+        with self._on_stream():
+            self.row.zero_()
+        return self.row
+
+    def set_status(self, row, failed):
+        with self._on_stream():
+            row[1:4] = 0.0
+            row[1] = 1.0 if failed else 0.0
+
     def row_to_host(self, row):
         with self._on_stream():
             return row.cpu().numpy()
@@ -164,6 +196,16 @@ class ShardedSequentialICP:
         g = self.g0 + k
         return self.bounds[g], self.bounds[g + 1]
 
+    @staticmethod
+    def _reduce(fn, buf):
+        """a reduction over processes; its own failure (a peer died, a timeout) is a RankFailure, not a hang"""
+        if fn is None:
+            return
+        try:
+            fn(buf)
+        except Exception as e:
+            raise RankFailure("a collective failed: a peer is gone (%s)" % (str(e).splitlines()[0] if str(e) else type(e).__name__)) from e
+
     def align(self, params: IcpParams):
         """one IterativeClosestPoint::align (App. A.1) of the posed source against the sharded target.
         Returns (final 4x4 float32, stats)."""
@@ -173,25 +215,37 @@ class ShardedSequentialICP:
         iters, conv, why, n, mse = 0, False, "NOT", 0, 0.0
         fma, rec = bool(params.fma_dist), bool(params.use_reciprocal)
         while True:
+            local_error = None
             keys = None
-            for part in self.parts:                      # forward search of every local shard
-                k = part.forward_keys(params.max_corr_dist, fma)
-                if keys is None:
-                    keys = k
-                else:
-                    p0.min_into(keys, k)
-            if self.rmin is not None:
-                self.rmin(keys)                          # MIN over ranks: ties -> lowest global index
+            try:
+                for part in self.parts:                  # forward search of every local shard
+                    k = part.forward_keys(params.max_corr_dist, fma)
+                    if keys is None:
+                        keys = k
+                    else:
+                        p0.min_into(keys, k)
+            except Exception as e:                       # local work failed: stay in the loop, contribute nothing
+                local_error, keys = e, p0.neutral_keys()
+            self._reduce(self.rmin, keys)                # MIN over ranks: ties -> lowest global index
             row = None
-            for part in self.parts:                      # every match is reduced by the part that owns its target
-                r = part.moments_from_keys(keys, params.max_corr_dist, self.origin, rec, fma)
-                if row is None:
-                    row = r
-                else:
-                    p0.add_into(row, r)
-            if self.rsum is not None:
-                self.rsum(row)
+            if local_error is None:
+                try:
+                    for part in self.parts:              # every match is reduced by the part that owns its target
+                        r = part.moments_from_keys(keys, params.max_corr_dist, self.origin, rec, fma)
+                        if row is None:
+                            row = r
+                        else:
+                            p0.add_into(row, r)
+                except Exception as e:
+                    local_error = e
+            if local_error is not None:
+                row = p0.neutral_row()
+            p0.set_status(row, local_error is not None)
+            self._reduce(self.rsum, row)
             h = p0.row_to_host(row)
+            if h[1] > 0:                                 # some rank's local work failed in this iteration: all ranks stop here
+                raise RankFailure("local work failed on this rank: %r" % (local_error,) if local_error is not None
+                                  else "a peer's local work failed in this iteration") from local_error
             n = int(round(h[0]))
             if n < 3:                                    # "Not enough correspondences found" (App. A.1)
                 conv, why = False, "NO_CORRESPONDENCES"
@@ -233,3 +287,32 @@ class ShardedSequentialICP:
                     lo, hi = self._bounds(k)
                     part.append_out(lo, hi, (a + 1) * self.N + lo)             # merged scan a+1 = global [(a+1) N, (a+2) N)
         return poses, log
+
+
+class NativeShardedSequentialICP:
+    """The product path: one rank = one library context with (optionally) its own RCCL communicator; the whole
+    registrationICP loop -- searches, ncclAllReduce(min) of the keys, sums, ncclAllReduce(sum), host solve, append of the
+    rank's slice -- is ONE native call per rank (mvr_seq_run_sharded).  Slots as HipPart."""
+    TARGET, SOURCE, OUT, RAW0 = 0, 1, 3, 8
+
+    def __init__(self, scans, device=0, stream=None, origin=(0.0, 0.0, 0.0)):
+        self.ctx = Context(device, stream=stream)
+        for v, s in enumerate(scans):
+            self.ctx.upload(self.RAW0 + v, s)
+        self.V = len(scans)
+        self.origin = np.asarray(origin, np.float64)
+
+    def comm_init(self, unique_id, rank, world):
+        """collective: every rank, with rank 0's mvr.comm_unique_id()"""
+        self.ctx.comm_init(unique_id, rank, world)
+
+    def run(self, poses, params: IcpParams, repeat=1):
+        new, log = self.ctx.seq_run_sharded([self.RAW0 + v for v in range(self.V)], self.TARGET, self.SOURCE, self.OUT, params,
+                                            self.origin, poses, repeat=repeat)
+        return [new[v] for v in range(self.V)], log
+
+    def shard_size(self):
+        return self.ctx.size(self.TARGET)
+
+    def close(self):
+        self.ctx.close()

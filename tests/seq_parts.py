@@ -76,6 +76,16 @@ class OraclePart:
     def keys_to_host(self, keys):
         return keys
 
+    def neutral_keys(self):
+        return np.full(len(self.cur), INT64_MAX, np.int64)
+
+    def neutral_row(self):
+        return np.zeros(32)
+
+    def set_status(self, row, failed):
+        row[1:4] = 0.0
+        row[1] = 1.0 if failed else 0.0
+
     def row_to_host(self, row):
         return row
 

@@ -417,3 +417,53 @@ def test_posed_index_refresh_equals_lazy_refresh(gpu, mvr):
     finally:
         gpu.tune(posed_refresh=1)
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("case", ["ring12", "ring36", "slightly_sheared", "sheared", "two_runs", "uploads_between_runs"])
+def test_pipelined_run_equals_pass_by_pass(mvr, case):
+    """mvr_ring_run enqueues pass k+1's launch chain while pass k runs (behind a gate the host's solve opens; the poses reach
+    the kernels through a device table): the SAME poses and edge tables, bit for bit, as one mvr_ring_step per pass and as
+    the run with the pipeline switched off -- on the 12- and 36-view rings, with a pose that is rigid only to 2e-4 (wider
+    balls), with one that is not nearly rigid at all (those passes must not be queued ahead), over two calls (the second
+    starts pipelined) and with a scan uploaded again between two calls (the queued chain would need a new ordering: the
+    run must notice and enqueue that pass the ordinary way)."""
+    V, N, max_d, K = (36, 3000, 8.0, 9) if case == "ring36" else (12, 12000, 4.0, 11)
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    if case == "slightly_sheared":
+        poses0[5] = poses0[5].copy(); poses0[5][0, 1] += 2e-4; poses0[7] = poses0[7].copy(); poses0[7][:3, :3] *= 1.0002      # (e = 2e-4 and 6.9e-4: inside note_pose's 1e-3)
+    if case == "sheared":
+        poses0[5] = poses0[5].copy(); poses0[5][0, 1] += 3e-3
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    posed, raw = list(range(V)), [V + v for v in range(V)]
+    runs, piped = [], []
+    for mode in ("piped", "off", "stepwise"):
+        with mvr.Context(0) as ctx:
+            ctx.tune(pipeline=int(mode != "off"))
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            P, log = [p.copy() for p in poses0], []
+            chunks = [K] if case not in ("two_runs", "uploads_between_runs") else [K - 4, 4]
+            for ci, steps in enumerate(chunks):
+                if ci == 1 and case == "uploads_between_runs":
+                    ctx.upload(V + 3, scans[3])                         # the same points, a NEW point set: no ordering, no grid
+                if mode == "stepwise":
+                    for _ in range(steps):
+                        P, info = ctx.ring_step(posed, raw, edges, P, max_d, origin)
+                else:
+                    P, info = ctx.ring_step(posed, raw, edges, P, max_d, origin, steps=steps)
+                log.append((np.asarray(P).tobytes(), info["rows"].tobytes(), tuple(info["pair_n"])))
+            # the posed clouds are what the LAST pass searched, and the slots' bookkeeping fits them: one more batch over them
+            rows = ctx.pair_moments2_batch([(a, b) for a, b in edges], max_d, origin)
+            log.append(b"".join(bytes(r) for r in rows))
+            runs.append(log)
+            piped.append(ctx.stat("piped_passes"))
+    assert runs[0] == runs[1] == runs[2], case
+    assert piped[1] == 0 and piped[2] == 0
+    if case == "sheared":
+        assert piped[0] == 0, piped                 # a pose outside the nearly-rigid range: never queued ahead
+    else:
+        assert piped[0] >= K - 7, (case, piped)     # (the first passes build orderings and grids)

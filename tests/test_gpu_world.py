@@ -116,3 +116,149 @@ def test_sharded_rows_of_all_ranks_sum_to_the_pass(mvr, scene, world):
         assert np.allclose(total[:, 4:], rinfo["rows"][:, 4:], rtol=1e-12, atol=1e-7)
         rc, new, info = mvr.ring_host_step(V, edges, total, origin, poses0)
         assert rc == 0 and np.abs(np.asarray(new) - ref).max() < 1e-9
+
+
+# ---------------------------------------------------------------- the sequential mode's native sharded host
+SEQ_V, SEQ_N, SEQ_D = 12, 4000, 6.0
+
+
+@pytest.fixture(scope="module")
+def seq_scene(mvr, orc):
+    import ref_driver
+    sp = mvr.synth_params(SEQ_V, 5)
+    scans = [mvr.synth_view(sp, v, SEQ_N) for v in range(SEQ_V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = ref_driver.init_poses(orc, SEQ_V, piv, ax)
+    return sp, scans, poses0
+
+
+@pytest.mark.parametrize("multi_iter", [False, True])
+def test_native_sequential_world_of_one(mvr, orc, seq_scene, multi_iter):
+    """mvr_seq_run_sharded (the native host of the target-sharded sequential mode: registrator.cpp:563-577 with
+    ncclAllReduce(min) of the keys and ncclAllReduce(sum) of the sums on the library's stream) in a world of ONE: with a real
+    RCCL communicator of one rank == without a communicator == the part-by-part Python rehearsal of the same loop over the
+    same C entry points, bit for bit; and all of them equal the oracle's unsharded driver (counts, iterations, poses)."""
+    import ref_driver
+    import torch
+    seq = importlib.import_module(PKG + ".seq")
+    sp, scans, poses0 = seq_scene
+    origin = np.array(sp.pivot)
+    kw = dict(max_dist=SEQ_D) if not multi_iter else dict(max_dist=SEQ_D, max_iter=3, feps=-1e300)
+    params = mvr.icp_params(**kw)
+    ref_poses, ref_log = ref_driver.sequential_icp(orc, scans, poses0, orc.make_params(**kw), fitness_last=False)
+    outs = []
+    for with_comm in (False, True):
+        drv = seq.NativeShardedSequentialICP(scans, device=0, origin=origin)
+        try:
+            if with_comm:
+                drv.comm_init(mvr.comm_unique_id(), 0, 1)
+                assert drv.ctx.comm_info() == (0, 1, 1)
+            poses, log = drv.run(poses0, params)
+            assert drv.shard_size() == SEQ_V * SEQ_N
+            outs.append((np.stack(poses), log))
+        finally:
+            drv.close()
+    part = seq.HipPart(scans, device=0, tstream=torch.cuda.Stream(device=0))
+    try:
+        py_poses, py_log = seq.ShardedSequentialICP([part], SEQ_V, SEQ_N, 1, origin=origin).run(poses0, params)
+    finally:
+        part.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], np.stack(py_poses))
+    for a, b, c in zip(outs[0][1], outs[1][1], py_log):
+        assert (a["view"], a["n_corr"], a["iterations"], a["mse"]) == (b["view"], b["n_corr"], b["iterations"], b["mse"]) == \
+               (c["view"], c["n_corr"], c["iterations"], c["mse"])
+        assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["T"], c["T"])
+    log = outs[0][1]
+    assert [e["n_corr"] for e in log] == [e["n_corr"] for e in ref_log]
+    assert [e["iterations"] for e in log] == [e["iterations"] for e in ref_log]
+    assert [e["state"].replace("NOT_CONVERGED", "NOT") for e in log] == [e["state"] for e in ref_log]
+    for v in range(SEQ_V):
+        assert np.abs(outs[0][0][v][:3, :3] - ref_poses[v][:3, :3]).max() < 1e-5, v
+        assert np.abs(outs[0][0][v][:3, 3] - ref_poses[v][:3, 3]).max() < 1e-4, v
+
+
+# ---------------------------------------------------------------- a rank's failure never leaves anybody in a collective
+@pytest.mark.parametrize("at", [0, 1, 5])
+def test_ring_local_failure_travels_through_the_collective(mvr, scene, at):
+    """A rank whose LOCAL work fails in pass `at` (injected) still joins that pass's ncclAllReduce -- with zero rows and a
+    raised failure count -- and returns its own status from that very pass; the communicator stays intact and the next run
+    on the same context reproduces the single-context loop.  (at = 5 falls into the pipelined stretch of the run.)"""
+    scans, poses0, origin = scene
+    V = len(scans)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    posed, raw = list(range(V)), [V + v for v in range(V)]
+    ref, rinfo = reference_run(mvr, scans, poses0, origin, 8)
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v])
+        ctx.comm_init(mvr.comm_unique_id(), 0, 1)
+        ctx.tune(inject_fail_pass=at)
+        with pytest.raises(mvr.MvrError) as e:
+            ctx.ring_run_sharded(posed, raw, edges, poses0, 8.0, origin, steps=8)
+        assert e.value.status == mvr.E_HIP and "injected" in str(e.value)
+        ctx.tune(inject_fail_pass=-1)
+        assert ctx.comm_info() == (0, 1, 1)
+        new, info = ctx.ring_run_sharded(posed, raw, edges, poses0, 8.0, origin, steps=8)
+        assert np.array_equal(new, ref) and np.array_equal(info["rows"], rinfo["rows"])
+
+
+@pytest.mark.parametrize("at", [0, 5])
+def test_ring_peer_that_never_arrives_is_a_timeout_not_a_hang(mvr, scene, at):
+    """The stream of this rank stalls in front of pass `at`'s collective (injected: what a peer that died looks like from
+    here).  The rank waits `wait_timeout_ms`, aborts its communicator (ncclCommAbort), drains and returns MVR_E_RCCL; the
+    multi-GPU entry points refuse until the broken communicator is dropped; the context itself is as good as new."""
+    import time
+    scans, poses0, origin = scene
+    V = len(scans)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    posed, raw = list(range(V)), [V + v for v in range(V)]
+    ref, rinfo = reference_run(mvr, scans, poses0, origin, 8)
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v])
+        ctx.comm_init(mvr.comm_unique_id(), 0, 1)
+        ctx.tune(wait_timeout_ms=400, inject_stall_pass=at)
+        t0 = time.time()
+        with pytest.raises(mvr.MvrError) as e:
+            ctx.ring_run_sharded(posed, raw, edges, poses0, 8.0, origin, steps=8)
+        assert e.value.status == mvr.E_RCCL and time.time() - t0 < 20.0
+        assert ctx.comm_info()[2] == 0                                   # the communicator is gone
+        with pytest.raises(mvr.MvrError) as e2:
+            ctx.ring_run_sharded(posed, raw, edges, poses0, 8.0, origin, steps=2)
+        assert e2.value.status == mvr.E_RCCL and "aborted" in str(e2.value)
+        ctx.comm_destroy()
+        new, info = ctx.ring_run_sharded(posed, raw, edges, poses0, 8.0, origin, steps=8)      # a world of its own again
+        assert np.array_equal(new, ref) and np.array_equal(info["rows"], rinfo["rows"])
+        ctx.comm_init(mvr.comm_unique_id(), 0, 1)                        # ... and a new communicator works
+        new, info = ctx.ring_run_sharded(posed, raw, edges, poses0, 8.0, origin, steps=8)
+        assert np.array_equal(new, ref)
+
+
+@pytest.mark.parametrize("how", ["fail", "stall"])
+def test_sequential_sharded_failures(mvr, seq_scene, how):
+    import time
+    seq = importlib.import_module(PKG + ".seq")
+    sp, scans, poses0 = seq_scene
+    params = mvr.icp_params(max_dist=SEQ_D)
+    drv = seq.NativeShardedSequentialICP(scans, device=0, origin=np.array(sp.pivot))
+    try:
+        good, glog = drv.run(poses0, params)
+        drv.comm_init(mvr.comm_unique_id(), 0, 1)
+        if how == "fail":
+            drv.ctx.tune(inject_fail_pass=3)
+        else:
+            drv.ctx.tune(wait_timeout_ms=400, inject_stall_pass=3)
+        t0 = time.time()
+        with pytest.raises(mvr.MvrError) as e:
+            drv.run(poses0, params)
+        assert time.time() - t0 < 20.0
+        assert e.value.status == (mvr.E_HIP if how == "fail" else mvr.E_RCCL)
+        drv.ctx.tune(inject_fail_pass=-1, inject_stall_pass=-1)
+        if how == "stall":
+            with pytest.raises(mvr.MvrError):
+                drv.run(poses0, params)                                  # the aborted communicator
+            drv.ctx.comm_destroy()
+        again, alog = drv.run(poses0, params)
+        assert np.array_equal(np.stack(again), np.stack(good)) and [e["n_corr"] for e in alog] == [e["n_corr"] for e in glog]
+    finally:
+        drv.close()

@@ -105,3 +105,77 @@ def test_sharded_sequential_gloo(mvr, orc, tmp_path, world):
             assert np.abs(o["poses"][v][:3, :3] - ref_poses[v][:3, :3]).max() < 1e-5
             assert np.abs(o["poses"][v][:3, 3] - ref_poses[v][:3, 3]).max() < 1e-4
     assert sum(int(o["shard"]) for o in outs) == V * N
+
+
+class _FailingPart(OraclePart):
+    """an OraclePart whose local work fails (or whose process dies) at its k-th forward search"""
+    def __init__(self, orc, scans, fail_at, how):
+        super().__init__(orc, scans)
+        self.calls, self.fail_at, self.how = 0, fail_at, how
+
+    def forward_keys(self, max_dist, fma):
+        self.calls += 1
+        if self.calls == self.fail_at:
+            if self.how == "die":
+                os._exit(0)                       # the process is simply gone: no goodbye to its peers
+            raise MemoryError("injected: this rank's local work failed")
+        return super().forward_keys(max_dist, fma)
+
+
+def _failure_worker(rank, world, port, out_dir, how):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datetime
+    import time
+    import torch
+    import torch.distributed as dist
+    import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    mvr = importlib.import_module(PKG)
+    seq = importlib.import_module(PKG + ".seq")
+    sp, scans, poses0 = scene(mvr, orc)
+    rmin = lambda k: dist.all_reduce(torch.from_numpy(k), op=dist.ReduceOp.MIN)
+    rsum = lambda r: dist.all_reduce(torch.from_numpy(r), op=dist.ReduceOp.SUM)
+    part = _FailingPart(orc, scans, 3, how) if rank == world - 1 else OraclePart(orc, scans)
+    drv = seq.ShardedSequentialICP([part], V, N, world, part0=rank, all_reduce_min=rmin, all_reduce_sum=rsum, origin=np.array(sp.pivot))
+    t0, verdict = time.time(), "finished"
+    try:
+        drv.run(poses0, mvr.icp_params(max_dist=MAX_D))
+    except seq.RankFailure as e:
+        verdict = "RankFailure: %s" % e
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%s\n%.1f\n" % (verdict, time.time() - t0))
+    os._exit(0)                                   # (no destroy_process_group: a peer may be gone)
+
+
+@pytest.mark.parametrize("how", ["raise", "die"])
+def test_a_failing_rank_ends_the_run_everywhere(mvr, orc, tmp_path, how):
+    """The failure protocol of the sharded loops, rehearsed over gloo (the native loop runs the same protocol on RCCL,
+    tests/test_gpu_world.py): a rank whose local work fails at its third align still joins that iteration's reductions
+    and EVERY rank ends it with RankFailure; a rank that dies takes its peers out of their collective with an error
+    within the group's timeout.  Nobody hangs."""
+    import multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_failure_worker, args=(r, world, port, str(tmp_path), how)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    alive = [p.is_alive() for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()                                  # exactly the processes this test started
+    assert not any(alive), "a rank hung: %s" % alive
+    texts = {}
+    for r in range(world):
+        f = os.path.join(tmp_path, "rank%d.txt" % r)
+        texts[r] = open(f).read() if os.path.exists(f) else None
+    assert texts[0] is not None and texts[0].startswith("RankFailure"), texts
+    if how == "raise":
+        assert texts[1] is not None and texts[1].startswith("RankFailure: local work failed"), texts
+        assert "peer" in texts[0]
+    else:
+        assert texts[1] is None                       # it died before it could say anything
+        assert float(texts[0].splitlines()[1]) < 60.0
