@@ -259,9 +259,10 @@ def main():
         "device": name, "n_cu": n_cu,
         "step_breakdown_ms": {"enqueue": reg.last["ms_enqueue"], "gpu_drain": reg.last["ms_drain"],
                               "host_solve": reg.last["ms_host_solve"],
-                              # nothing is queued on the GPU while the host solves and before the next pass's first
-                              # launch lands: wall time per step minus the time the host spent feeding or awaiting it
-                              "gpu_idle_ms": max(0.0, 1e3 * elapsed / args.steps - reg.last["ms_enqueue"] - reg.last["ms_drain"])},
+                              "piped_passes": ctx.stat("piped_passes"),
+                              "note": "enqueue = host time spent pushing launches (overlaps the GPU: a pass's chain is queued while the previous "
+                                      "pass runs, behind a gate); gpu_drain = host time spent waiting for a pass to finish; gpu_idle_ms (below, "
+                                      "filled from the profiled re-run) = ms_per_step minus the sum of the step's kernel durations"},
     }
     if rep_s:
         per = sorted(1e3 * t / args.steps for t in rep_s)
@@ -284,6 +285,22 @@ def main():
             return rec.get("hbm_bytes_per_launch"), "profiles/%s (PMC, %s)" % (fname, rec.get("source", "")[:120])
         except Exception:
             return None, "no profiles/%s" % fname
+
+    def hbm_roofline(kernel, launches, ms, evals, alg_bytes_per_launch, traffic, extra=None):
+        """the roof that binds a search over a few candidates per query: SURVEY 8(d)'s compulsory bytes per launch against
+        the HBM peak (intensity ~3 flop/B, far left of the 19.7 flop/B ridge); the executed-flop fraction rides along"""
+        if not launches:
+            return None
+        avg_s = ms * 1e-3 / launches
+        achieved = alg_bytes_per_launch / avg_s / 1e9
+        r = {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+             "traffic": traffic[0], "traffic_source": traffic[1],
+             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+             "launches": launches, "avg_launch_ms": ms / launches, "evals_per_launch": evals / launches, "evals_per_s": evals / (ms * 1e-3),
+             "frac_of_fp32_peak_on_executed_flops": FLOP_PER_EVAL * (evals / launches) / avg_s / 1e12 / PEAK_FP32_TFLOPS}
+        if extra:
+            r.update(extra)
+        return r
 
     def nn_roofline(kernel, launches, ms, evals, traffic, extra=None):
         if not launches:
@@ -319,6 +336,9 @@ def main():
                    grid=ctx.prof_get(mvr.K_NN_GRID), wide=ctx.prof_get(mvr.K_NN_WIDE), xf=ctx.prof_get(mvr.K_XFORM),
                    ms_per_step=1e3 * iso_elapsed / args.steps)
         rd_launches, rd_ms, rd_bytes = iso["rd"]
+        kern_ms = sum(iso[f][1] for f in ("nn", "rd", "gl", "grid", "wide", "xf")) / args.steps
+        out["step_breakdown_ms"]["kernels_sum"] = kern_ms
+        out["step_breakdown_ms"]["gpu_idle_ms"] = max(0.0, 1e3 * elapsed / args.steps - kern_ms)
     # the brute-force kernel (the plain VALU-roofline kernel) on the same pairs: one extra, untimed ring pass
     bf = None
     if world == 1 and not args.no_bruteforce_pass:
@@ -344,25 +364,28 @@ def main():
         gl_, gms, gev = iso["grid"]
         wl_, wms, wev = iso["wide"]
         cl_, cms, cev = iso["nn"]
-        q_per_launch = V * N * args.steps / gl_ * (1.0 + reg.last["n_corr"] / float(V * N))      # forward: every source; reverse: about one per accepted pair
-        alg_bytes = 32.0 * q_per_launch + 16.0 * V * N                       # per query: its point, its previous key or start bound, the key written; the posed target array once
-        avg_s = gms * 1e-3 / gl_
+        # SURVEY 8(d), compulsory bytes (12-byte points, every array once per kernel), per pair: forward search K2 =
+        # 12 Ns + 12 Nt + 8 Ns; reverse search K3 = 12 Nt' + 12 Ns + 4 Nt' + 4 Ns with Nt' = the matched targets (taken as the
+        # accepted correspondences: a lower bound).  One launch = all V pairs of a step in one direction; mean of the two.
+        Ns = Nt = float(N)
+        Ntp = reg.last["n_corr"] / float(V)
+        fwd_bytes, rev_bytes = V * (12 * Ns + 12 * Nt + 8 * Ns), V * (12 * Ntp + 12 * Ns + 4 * Ntp + 4 * Ns)
+        alg_bytes = 0.5 * (fwd_bytes + rev_bytes)
         extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; per step one forward "
                              "launch (all %d x %d source queries) and one reverse launch (the matched targets) for all scan pairs" % (args.steps, V, N),
                  "ms_per_step_one_stream_profiled": iso["ms_per_step"],
-                 "limiter": "the L1 gather path, not the ALUs: per-lane 16-byte loads of a few candidates each (rocprofv3 --pmc: TA busy 89 % of "
-                            "the launch, 14 distinct cache lines per load instruction; DESIGN.md 4.3) -- `frac` prices the executed evaluations "
-                            "against the FP32 peak as SURVEY 8(d) asks and FALLS as the search gets smarter; the step time is the figure of merit",
-                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gb_per_s": alg_bytes / avg_s / 1e9,
-                 "frac_of_hbm_peak_on_algorithmic_bytes": alg_bytes / avg_s / 1e9 / PEAK_HBM_GBS,
+                 "algorithmic_bytes": {"forward_launch": fwd_bytes, "reverse_launch": rev_bytes, "formula": "SURVEY 8(d) K2 / K3 with Nt' = accepted correspondences per pair"},
+                 "limiter": "TA: the L1 gather path (rocprofv3 --pmc: TA_TA_BUSY ~88 % of the launch, ~13 distinct cache lines per vector load; "
+                            "DESIGN.md 4.3) -- neither roof is near: HBM by the roofline model (3.4 flop/B against a 19.7 flop/B ridge), a few "
+                            "per-lane 16-byte gathers per query in practice",
                  "evals_bruteforce_equivalent_per_step": brute_equiv}
         if brute_equiv:
             tot_ms = gms + wms + cms
             extra["culling_factor"] = brute_equiv / ((gev + wev + cev) / args.steps)
             extra["bruteforce_equivalent_tflops"] = FLOP_PER_EVAL * brute_equiv / (tot_ms * 1e-3 / args.steps) / 1e12
-        out["roofline"] = nn_roofline("nn_grid_kernel (exact 1-NN of the BOUNDED queries of a fused pass over a pose-invariant cell grid, one thread "
-                                      "per query; forward and reverse launches of all scan pairs)", gl_, gms, gev,
-                                      traffic_of("nn_grid_traffic.json", "mvr_grid.hip"), extra)
+        out["roofline"] = hbm_roofline("nn_grid_kernel (exact 1-NN of the BOUNDED queries of a fused pass over a pose-invariant cell grid, one thread "
+                                       "per query; forward and reverse launches of all scan pairs)", gl_, gms, gev, alg_bytes,
+                                       traffic_of("nn_grid_traffic.json", "mvr_grid.hip"), extra)
         if wl_:
             out["roofline_stragglers"] = nn_roofline("nn_grid_tail_kernel (wide bounded queries, a wave each, and the listed 64-query sets, a block "
                                                      "each over the grid, in one launch; nn_grid_wide_kernel alone for the reverse pass)",
@@ -399,6 +422,33 @@ def main():
                     "200k points per scan (4 MB per launch); one-stream pass",
         }
     out["pcie"] = {"h2d_s": h2d, "h2d_bytes": V * N * 16}
+
+    # What a registration costs from a standing start, beside the steady state above: a FRESH context, the uploads, then K
+    # passes from the prior in one native call -- no prewarm, no seeds, the orderings and grids built on the way (the reference
+    # builds its kd-trees inside every align, registrator.cpp:569, and cpu_baseline pays for them too)
+    if world == 1:
+        cold_ctx = mvr.Context(local_rank)
+        try:
+            cold_ctx.tune(nn_mode=args.nn_mode)
+            tc0 = time.perf_counter()
+            for v in range(V):
+                cold_ctx.upload(V + v, scans[v])
+            cold_ctx.sync()
+            tc1 = time.perf_counter()
+            Kc = max(args.steps, 2)
+            _, cinfo = cold_ctx.ring_step(list(range(V)), [V + v for v in range(V)], reg.edges, [p.copy() for p in poses0], args.max_dist, origin,
+                                          fma=bool(args.fma), steps=Kc)
+            tc2 = time.perf_counter()
+            plog = cold_ctx.pass_log()
+            out["cold_registration"] = {
+                "passes": Kc, "upload_ms": 1e3 * (tc1 - tc0), "total_ms": 1e3 * (tc2 - tc1), "amortised_ms_per_pass": 1e3 * (tc2 - tc1) / Kc,
+                "ms_per_pass": [round(v, 4) for v in plog], "piped_passes": cold_ctx.stat("piped_passes"),
+                "accepted_correspondences_last_pass": float(sum(cinfo["pair_n"])),
+                "note": "fresh context -> %d uploads -> %d passes from the mis-calibrated prior in one mvr_ring_run: pass 1 builds the scans' "
+                        "Hilbert orderings and searches unseeded (culled kernel) while the cell grids are built on a side stream; from pass 2 "
+                        "on the seeded grid search; pipelined once a pass has run without allocating" % (V, Kc)}
+        finally:
+            cold_ctx.close()
 
     # BASELINE configs[2] beside the headline: the SEQUENTIAL mode (Registrator::registrationICP, registrator.cpp:526-588:
     # views 1, V-1, 2, ... each aligned to the growing merged target), device-resident, same scans -- ms per align

@@ -12,7 +12,7 @@
 //   saveRegisteredPoints :344-400, registration :719-744                    -> same names
 // The Qt/OSG/file-tree plumbing (FileSystemModel, QtConcurrent, draggers, rendering, dialogs) is out of scope:
 // `TurntableModel` is an in-memory stand-in for FileSystemModel::getPointCloud(object, view).
-// The reference's own loops replayed on the PCL-named shim (call-site compatibility): tests/cxx/reference_replay.hpp.
+// The PCL-named call surface itself is exercised, in the reference's order of calls, by tests/cxx/call_surface.hpp.
 #pragma once
 
 #include <cstdio>
@@ -179,8 +179,7 @@ struct AlignLog { int view; Matrix4f T; int n_corr; double mse; int iterations; 
 // (V x 32 doubles) across the bus, never points.  It covers the non-GUI duties of the reference's class Registrator
 // (mvr/include/registrator.h:40-59) -- which pairs are registered in which order with which parameters, and how the
 // result is composed into the views' poses -- without its PCL-shaped data flow (a host cloud rebuilt, re-uploaded and
-// re-indexed at every align).  The reference's own loops, replayed call for call on the PCL-named shim classes, are
-// test infrastructure: tests/cxx/reference_replay.hpp.
+// re-indexed at every align).  (tests/cxx/call_surface.hpp drives the PCL-named shim members in the reference's order of calls.)
 class Registrator {
  public:
   explicit Registrator(TurntableModel *model) : model_(model) {}

@@ -447,6 +447,10 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * this rank's local work fails / its stream stalls in front of the collective as if a peer never arrived; -1: off).
  * Results never depend on them. */
 int  mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value);
+/* wall milliseconds of every pass of the LAST mvr_ring_run / mvr_ring_run_sharded on this context (from the end of the
+ * previous pass's solve to the end of this one's; the first from the start of the call): what the first passes of a
+ * registration cost (orderings, grids) beside the steady state.  *n = passes logged (may exceed cap). */
+int  mvr_ctx_pass_log(mvr_ctx *ctx, double *ms, int cap, int *n);
 /* counters of the context, by name: "piped_passes" (passes of mvr_ring_run / mvr_ring_run_sharded whose launch chain was
  * enqueued ahead of their poses, see "pipeline"), "fused_passes" (fused pair batches run so far), "blocking_events"
  * (times the library waited for its stream or re-allocated a buffer: a pass without any is in steady state) */

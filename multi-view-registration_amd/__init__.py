@@ -195,6 +195,7 @@ SIGNATURES = {
     "mvr_mat4f_mul": (None, [_fp, _fp, _fp]),
     "mvr_ctx_tune": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "mvr_ctx_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "mvr_ctx_pass_log": (C.c_int, [_vp, _dp, C.c_int, C.POINTER(C.c_int)]),
     "mvr_debug_counters": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int]),
     "mvr_prof_enable": (C.c_int, [_vp, C.c_int]),
     "mvr_prof_reset": (C.c_int, [_vp]),
@@ -700,6 +701,14 @@ class Context:
         v = C.c_double()
         _chk(_lib.mvr_ctx_stat(self._h, key.encode(), C.byref(v)), self._h)
         return v.value
+
+    def pass_log(self):
+        """wall ms of every pass of the last ring run (mvr_ctx_pass_log)"""
+        n = C.c_int()
+        _chk(_lib.mvr_ctx_pass_log(self._h, None, 0, C.byref(n)), self._h)
+        ms = np.zeros(max(n.value, 1))
+        _chk(_lib.mvr_ctx_pass_log(self._h, _p(ms, C.c_double), n.value, C.byref(n)), self._h)
+        return ms[: n.value].tolist()
 
     def debug_counters(self, reset=False):
         out = (C.c_uint64 * 4)()

@@ -385,6 +385,10 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
                   c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+  if (c->side_after) (void)hipEventDestroy(c->side_after);
+  if (c->scratch_event) (void)hipEventDestroy(c->scratch_event);
+  if (c->scratch) (void)hipFree(c->scratch);
   if (c->h_stall) (void)hipHostFree(c->h_stall);
   if (c->seq_keys) (void)hipFree(c->seq_keys);
   if (c->seq_row) (void)hipFree(c->seq_row);
@@ -1139,10 +1143,15 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
       // should not pay for twelve of them (0.85 ms each at 200k points; tools/first_passes.py)
       std::sort(used.begin(), used.end());
       used.erase(std::unique(used.begin(), used.end()), used.end());
+      std::vector<Cloud *> need, canon;
       for (Cloud *cl : used) {
         if (cl->grid || !cl->pose_known || cl->n == 0) continue;
         for (Cloud &o : c->slots)
-          if (o.set_id == cl->set_id && o.canonical && o.n == cl->n) { if (ensure_grid(c, o, max_dist + 0.5)) cl->grid = o.grid; break; }
+          if (o.set_id == cl->set_id && o.canonical && o.n == cl->n) { need.push_back(cl); canon.push_back(&o); break; }
+      }
+      if (!canon.empty()) {
+        (void)ensure_grids(c, canon.data(), (int)canon.size(), max_dist + 0.5, c->stream, nullptr);      // (a set left without a grid keeps the culled kernel)
+        for (size_t k = 0; k < need.size(); ++k) if (canon[k]->grid && canon[k]->grid->n == need[k]->n) need[k]->grid = canon[k]->grid;
       }
       if (int rc = refresh_grid_coords_batch(c, used.data(), (int)used.size())) return rc;
     }
@@ -1415,9 +1424,28 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
 {
   double sum[3] = {0.0, 0.0, 0.0};
   const int V = L.n_views;
-  auto plain_pass = [&]() -> int {
+  c->pass_ms.clear();
+  double t_prev = now_ms();
+  auto pass_done = [&]() { const double t = now_ms(); c->pass_ms.push_back(t - t_prev); t_prev = t; };
+  // The scans' cell grids are needed from the second pass on.  When more passes follow in this call they are built on the
+  // context's side stream WHILE this pass's searches run (12 x 200k: 8.8 ms of the second pass in round 2), behind an
+  // event taken before the pass was enqueued; failure is not fatal -- the next pass builds what is missing.
+  auto prebuild_grids = [&]() {
+    if (!c->ring_search || c->nn_mode == 0 || !c->pair_fused || !(L.reach > 0.0) || !(L.reach * L.reach < (double)FLT_MAX)) return;
+    std::vector<Cloud *> canon;
+    for (int v = 0; v < V; ++v) { Cloud &r = c->slots[L.raw_slots[v]]; if (r.canonical && r.n && !(r.grid && r.grid->n == r.n)) canon.push_back(&r); }
+    if (canon.empty() || !c->side_after) return;
+    if (!c->side_stream && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) { c->side_stream = nullptr; return; }
+    (void)ensure_grids(c, canon.data(), (int)canon.size(), L.reach + 0.5, c->side_stream, c->side_after);
+  };
+  auto plain_pass = [&](bool more_follow) -> int {
     const double t0 = now_ms();
+    if (more_follow) {
+      if (!c->side_after && hipEventCreateWithFlags(&c->side_after, hipEventDisableTiming) != hipSuccess) c->side_after = nullptr;
+      if (c->side_after) (void)hipEventRecord(c->side_after, c->stream);
+    }
     if (int rc = L.enqueue(L.self)) return rc;
+    if (more_follow) prebuild_grids();
     const double t1 = now_ms();
     if (int rc = stream_wait(c)) return rc;
     const double t2 = now_ms();
@@ -1439,9 +1467,10 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
   while (k < n_steps) {
     if (!(steady && n_steps - k >= 2 && pipe_possible() && all_rigid() && pipe_setup(c, V) == MVR_OK)) {
       const unsigned long long ev0 = c->blocking_events;
-      if (int rc = plain_pass()) return rc;
+      if (int rc = plain_pass(n_steps - k >= 2)) return rc;
       steady = c->blocking_events == ev0 && c->fused_passes >= 2;      // (the grids exist from the second fused pass on)
       ++k;
+      pass_done();
       continue;
     }
     // ---- a pipelined stretch: passes k, k + 1, ... while nothing has to wait or grow
@@ -1508,6 +1537,7 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
       }
       ++k;
       ++c->piped_passes;
+      pass_done();
       if (!more) break;
       if (next_failed || !all_rigid()) {
         // the queued chain cannot be used (it is incomplete, or a pose left the nearly-rigid range the grid search accepts):
@@ -1611,6 +1641,7 @@ API int mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_sl
   L.n_views = n_views; L.posed_slots = posed_slots; L.raw_slots = raw_slots; L.poses = poses;
   L.enqueue = &RingRun::enqueue; L.solve = &RingRun::solve; L.self = &r;
   L.sig = pass_loop_sig(c, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, 0);
+  L.reach = max_dist;
   return ring_passes(c, n_steps, L, timing_ms);
 }
 
@@ -2054,6 +2085,15 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "inplace_ratio")) c->inplace_ratio = value;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
   else return MVR_E_ARG;
+  return MVR_OK;
+}
+
+API int mvr_ctx_pass_log(mvr_ctx *ctx, double *ms, int cap, int *n)
+{
+  if (!ctx || !n || cap < 0 || (cap && !ms)) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  *n = (int)c->pass_ms.size();
+  for (int k = 0; k < cap && k < *n; ++k) ms[k] = c->pass_ms[(size_t)k];
   return MVR_OK;
 }
 

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <iterator>
 #include <vector>
 
 #include "mvr_internal.h"
@@ -35,7 +36,8 @@ namespace mvr {
 
 CellGrid::~CellGrid()
 {
-  for (void *p : {(void *)start, (void *)gperm, (void *)graw, (void *)g2h, (void *)h2g, (void *)dt}) if (p) (void)hipFree(p);
+  if (block) (void)hipFree(block);            // (start, gperm, graw, g2h, h2g and dt are carved out of it)
+  if (ready) (void)hipEventDestroy(ready);
 }
 
 namespace {
@@ -60,41 +62,69 @@ __global__ void cell_id_kernel(const float4 *__restrict__ p, size_t n, GridGeom 
   idx[i] = (uint32_t)i;
 }
 
-// distance map, by dilation: dt = 0 on occupied cells; step k marks with k every unmarked cell that has a cell marked
-// < k among its 26 neighbours (Chebyshev distance k).  One launch per step, reading the previous step's array.
-__global__ void dt_init_kernel(const uint32_t *__restrict__ start, size_t cells, uint8_t *__restrict__ dt)
+// distance map: dt[c] = Chebyshev distance, in cells, from cell c to the nearest occupied cell, capped (255 = farther than
+// `steps`).  The Chebyshev ball is a cube, so the minimum over the occupied cells of max(|dx|, |dy|, |dz|) separates:
+//   a(c) = min over dx of |dx| with (x + dx, y, z) occupied;  b(c) = min over dy of max(|dy|, a(x, y + dy, z));
+//   dt(c) = min over dz of max(|dz|, b(x, y, z + dz))
+// -- three launches that each look at a window of 2 steps + 1 cells along one axis, instead of one dilation launch per
+// step over all 27 neighbours (round 2: up to 12 launches of 47 us per scan, half of a grid's build time).
+__global__ void dt_occupancy_kernel(const uint32_t *__restrict__ start, size_t cells, uint8_t *__restrict__ out)
 {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < cells) dt[c] = start[c + 1] > start[c] ? 0 : 255;
+  if (c < cells) out[c] = start[c + 1] > start[c] ? 0 : 255;
 }
-__global__ void dt_step_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int nx, int ny, int nz, int step)
+__global__ void dt_axis_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int nx, int ny, int nz, int axis, int steps)
 {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= (size_t)nx * ny * nz) return;
-  uint8_t v = in[c];
-  if (v == 255) {
-    const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((size_t)nx * ny));
-    bool near = false;
-    for (int dz = -1; dz <= 1 && !near; ++dz)
-      for (int dy = -1; dy <= 1 && !near; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int X = x + dx, Y = y + dy, Z = z + dz;
-          if (X < 0 || Y < 0 || Z < 0 || X >= nx || Y >= ny || Z >= nz) continue;
-          if (in[((size_t)Z * ny + Y) * nx + X] != 255) { near = true; break; }
-        }
-    if (near) v = (uint8_t)step;
+  const int x = (int)(c % nx), y = (int)((c / nx) % ny), z = (int)(c / ((size_t)nx * ny));
+  const int pos = axis == 0 ? x : axis == 1 ? y : z, len = axis == 0 ? nx : axis == 1 ? ny : nz;
+  const size_t stride = axis == 0 ? 1 : axis == 1 ? (size_t)nx : (size_t)nx * ny;
+  auto val = [&](size_t cc) -> int { return (int)in[cc]; };
+  int best = val(c);
+  for (int d = 1; d <= steps && best > d; ++d) {           // a value found at distance d cannot be beaten by anything farther than it
+    if (pos - d >= 0) best = min(best, max(d, val(c - (size_t)d * stride)));
+    if (pos + d < len) best = min(best, max(d, val(c + (size_t)d * stride)));
   }
-  out[c] = v;
+  out[c] = (uint8_t)(best > steps ? 255 : best);
 }
 
-// start[c] = first grid position whose cell id is >= c (lower bound in the sorted ids); start[cells] = n
-__global__ void cell_start_kernel(const uint32_t *__restrict__ sorted_cid, size_t n, size_t cells, uint32_t *__restrict__ start)
+// start[c] = first grid position whose cell id is >= c; start[cells] = n.  From the SORTED cell ids: the first point of a
+// run of equal ids knows its cell's start; an empty cell takes the start of the next occupied one -- a suffix minimum,
+// done as an inclusive min-scan over the reversed array.
+__global__ void cell_first_kernel(const uint32_t *__restrict__ sorted_cid, size_t n, size_t cells, uint32_t *__restrict__ start)
 {
-  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > cells) return;
-  size_t lo = 0, hi = n;
-  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (sorted_cid[mid] < (uint32_t)c) lo = mid + 1; else hi = mid; }
-  start[c] = (uint32_t)lo;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) start[cells] = (uint32_t)n;
+  if (k >= n) return;
+  const uint32_t c = sorted_cid[k];
+  if (k == 0 || sorted_cid[k - 1] != c) start[c] = (uint32_t)k;
+}
+struct MinU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; } };
+// a random-access iterator over p[len - 1], p[len - 2], ..., p[0] (hipCUB's scans take any such iterator)
+struct ReverseU32 {
+  typedef std::random_access_iterator_tag iterator_category;
+  typedef uint32_t value_type; typedef ptrdiff_t difference_type; typedef uint32_t *pointer; typedef uint32_t &reference;
+  uint32_t *last;       // &p[len - 1]
+  __host__ __device__ uint32_t &operator*() const { return *last; }
+  __host__ __device__ uint32_t &operator[](ptrdiff_t i) const { return *(last - i); }
+  __host__ __device__ ReverseU32 operator+(ptrdiff_t i) const { return ReverseU32{last - i}; }
+  __host__ __device__ ReverseU32 operator-(ptrdiff_t i) const { return ReverseU32{last + i}; }
+  __host__ __device__ ptrdiff_t operator-(const ReverseU32 &o) const { return o.last - last; }
+  __host__ __device__ ReverseU32 &operator+=(ptrdiff_t i) { last -= i; return *this; }
+  __host__ __device__ ReverseU32 &operator-=(ptrdiff_t i) { last += i; return *this; }
+  __host__ __device__ ReverseU32 &operator++() { --last; return *this; }
+  __host__ __device__ ReverseU32 operator++(int) { ReverseU32 t = *this; --last; return t; }
+  __host__ __device__ ReverseU32 &operator--() { ++last; return *this; }
+  __host__ __device__ bool operator==(const ReverseU32 &o) const { return last == o.last; }
+  __host__ __device__ bool operator!=(const ReverseU32 &o) const { return last != o.last; }
+  __host__ __device__ bool operator<(const ReverseU32 &o) const { return last > o.last; }
+};
+inline ReverseU32 thrust_like_reverse(uint32_t *p, size_t len) { return ReverseU32{p + (len ? len - 1 : 0)}; }
+// the four entries behind start[cells] (the walk reads four consecutive starts with one load): all n
+__global__ void pad_start_kernel(uint32_t *__restrict__ start, size_t cells, uint32_t n)
+{
+  if (threadIdx.x < 4) start[cells + 1 + threadIdx.x] = n;
 }
 
 __global__ void grid_gather_kernel(const float4 *__restrict__ p, const uint32_t *__restrict__ gperm, size_t n, float4 *__restrict__ graw)
@@ -423,82 +453,176 @@ __device__ __forceinline__ void nn_grid_wide_body(const GridBatch &batch, unsign
 
 }  // namespace
 
-// ---- build: once per point set, from a cloud that holds the set's canonical coordinates
-bool ensure_grid(Ctx *c, Cloud &canon, double reach)
+// ---- build: once per point set, from a cloud that holds the set's canonical coordinates.  Batched: the bounding boxes of
+// all the sets that need a grid come back in ONE round trip, every grid is one allocation (its arrays carved out of it), the
+// temporaries live in a scratch buffer of the context that only ever grows, and nothing waits for the stream afterwards --
+// a grid carries an event its first user waits for.  `on` is the stream the build is enqueued on: the context's own, or its
+// side stream so that the grids of a registration are built WHILE its first pass searches (ring_passes).
+namespace {
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+__global__ void bbox_many_partial_kernel(const float4 *const *__restrict__ pts, const unsigned long long *__restrict__ n, float *__restrict__ part)
 {
-  const size_t n = canon.n;
-  if (!canon.canonical || n == 0 || n > 0x7FFFFFFFull) return false;      // (hipCUB's sort takes an int count; the caller falls back to the culled kernel)
-  if (canon.grid && canon.grid->n == n) return true;
-  canon.grid.reset();
-  auto it = c->grids.find(canon.set_id);
-  if (it != c->grids.end()) { canon.grid = it->second.lock(); if (canon.grid && canon.grid->n == n) return true; canon.grid.reset(); }
-  if (may_block(c, "not in steady state: a point set has no grid yet") != MVR_OK) return false;
-  // bounding box (one small round trip, once per scan): the cell edge and the grid's dimensions come from it
-  float hb[6];
-  if (cloud_bbox(c, canon.pts, n, hb) != MVR_OK) return false;
-  auto g = std::make_shared<CellGrid>();
-  g->n = n;
-  double ext[3];
-  for (int k = 0; k < 3; ++k) { g->lo[k] = hb[k]; ext[k] = std::max(1e-6, (double)hb[3 + k] - (double)hb[k]); }
-  // ~grid_cell_points points per cell on a SURFACE of about the bounding box's face area (a scan is a sheet, not a
-  // volume); never more than 512 cells per axis / 32 M cells (128 MB of cell starts, of which only the cells near the
-  // surface are ever read)
-  const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
-  double h = std::sqrt((double)std::max(1, c->grid_cell_points) * area / (double)n);
-  h = std::max(h, std::max(ext[0], std::max(ext[1], ext[2])) / 512.0);
-  for (;;) {
-    double cells = 1.0;
-    for (int k = 0; k < 3; ++k) { g->dim[k] = (int)std::floor(ext[k] / h) + 1; cells *= g->dim[k]; }
-    if (cells <= 32.0e6) break;
-    h *= 1.25;
+  // blockIdx.y = cloud; 64 blocks per cloud; part[cloud][block][6]
+  const int cl = blockIdx.y;
+  const float4 *p = pts[cl];
+  const size_t cnt = (size_t)n[cl];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
+    hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
   }
-  g->h = (float)h; g->inv_h = (float)(1.0 / h);
-  const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
-  uint32_t *cid_a = nullptr, *cid_b = nullptr, *idx_a = nullptr;
-  uint8_t *dt_tmp = nullptr;
-  bool ok = hipMalloc(&g->start, (cells + 1 + 4) * 4) == hipSuccess && hipMalloc(&g->gperm, n * 4) == hipSuccess &&
-            hipMalloc(&g->graw, n * sizeof(float4)) == hipSuccess && hipMalloc(&g->g2h, n * 4) == hipSuccess && hipMalloc(&g->h2g, n * 4) == hipSuccess &&
-            hipMalloc(&g->dt, cells) == hipSuccess && hipMalloc(&dt_tmp, cells) == hipSuccess && hipMalloc(&cid_a, n * 4) == hipSuccess &&
-            hipMalloc(&cid_b, n * 4) == hipSuccess && hipMalloc(&idx_a, n * 4) == hipSuccess;
-  if (ok) {
+  __shared__ float sh[4][6];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; ++k) { sh[threadIdx.x >> 6][k] = lo[k]; sh[threadIdx.x >> 6][3 + k] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) for (int k = 0; k < 3; ++k) { sh[0][k] = fminf(sh[0][k], sh[w][k]); sh[0][3 + k] = fmaxf(sh[0][3 + k], sh[w][3 + k]); }
+    for (int k = 0; k < 6; ++k) part[((size_t)cl * gridDim.x + blockIdx.x) * 6 + k] = sh[0][k];
+  }
+}
+}  // namespace
+
+int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream_t on, hipEvent_t after)
+{
+  std::vector<Cloud *> todo;
+  for (int k = 0; k < count; ++k) {
+    Cloud *cl = canon[k];
+    if (!cl || !cl->canonical || cl->n == 0 || cl->n > 0x7FFFFFFFull) continue;      // (hipCUB's sort takes an int count; such a cloud keeps the culled kernel)
+    if (cl->grid && cl->grid->n == cl->n) continue;
+    cl->grid.reset();
+    auto it = c->grids.find(cl->set_id);
+    if (it != c->grids.end()) { cl->grid = it->second.lock(); if (cl->grid && cl->grid->n == cl->n) continue; cl->grid.reset(); }
+    if (std::find(todo.begin(), todo.end(), cl) == todo.end()) todo.push_back(cl);
+  }
+  if (todo.empty()) return MVR_OK;
+  MVR_MAY_BLOCK(c, "a point set has no grid yet");
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const bool side = on != c->stream;
+  // a side stream starts behind `after` (an event of the context's stream from BEFORE the pass it is to overlap), and any
+  // stream behind the previous user of the scratch buffer
+  if (side && after) MVR_HIP_TRY(c, hipStreamWaitEvent(on, after, 0));
+  if (c->scratch_event && c->scratch_stream != on) MVR_HIP_TRY(c, hipStreamWaitEvent(on, c->scratch_event, 0));
+  // ---- bounding boxes of all of them: one launch, one round trip
+  const int m = (int)todo.size();
+  constexpr int kBoxBlocks = 64;
+  constexpr size_t kCellsCap = 32000000;
+  std::vector<const float4 *> hp((size_t)m); std::vector<unsigned long long> hn((size_t)m);
+  size_t nmax = 0, cells_max = 0;
+  for (int k = 0; k < m; ++k) { hp[(size_t)k] = todo[(size_t)k]->pts; hn[(size_t)k] = todo[(size_t)k]->n; nmax = std::max(nmax, todo[(size_t)k]->n); }
+  const size_t head = align256((size_t)m * 8) * 2 + align256((size_t)m * kBoxBlocks * 6 * sizeof(float));
+  // (sized ONCE for the largest grid there can be: growing it later would mean freeing it under the pass this build overlaps)
+  size_t sort_bytes = 0, scan_bytes = 0;
+  {
+    uint32_t *z = nullptr;
+    MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, z, z, z, z, (int)nmax, 0, 32, on));
+    auto rit = thrust_like_reverse(z, kCellsCap + 1);
+    MVR_HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, rit, rit, MinU32(), (int)(kCellsCap + 1), on));
+  }
+  const size_t cub_bytes = std::max(sort_bytes, scan_bytes) + 256;
+  const size_t o_cid_a = 0, o_cid_b = o_cid_a + align256(nmax * 4), o_idx = o_cid_b + align256(nmax * 4), o_dtt = o_idx + align256(nmax * 4),
+               o_cub = o_dtt + align256(kCellsCap), tmp_total = o_cub + align256(cub_bytes);
+  if (int rc = ensure(c, c->scratch, c->scratch_cap, std::max(head, tmp_total))) return rc;
+  const float4 **d_pts = reinterpret_cast<const float4 **>(c->scratch);
+  unsigned long long *d_n = reinterpret_cast<unsigned long long *>(c->scratch + align256((size_t)m * 8));
+  float *d_part = reinterpret_cast<float *>(c->scratch + 2 * align256((size_t)m * 8));
+  std::vector<float> h_part((size_t)m * kBoxBlocks * 6);
+  MVR_HIP_TRY(c, hipMemcpyAsync(d_pts, hp.data(), (size_t)m * 8, hipMemcpyHostToDevice, on));
+  MVR_HIP_TRY(c, hipMemcpyAsync(d_n, hn.data(), (size_t)m * 8, hipMemcpyHostToDevice, on));
+  hipLaunchKernelGGL(bbox_many_partial_kernel, dim3(kBoxBlocks, (unsigned)m), dim3(256), 0, on, d_pts, d_n, d_part);
+  MVR_HIP_TRY(c, hipMemcpyAsync(h_part.data(), d_part, h_part.size() * sizeof(float), hipMemcpyDeviceToHost, on));
+  MVR_HIP_TRY(c, hipStreamSynchronize(on));
+  // ---- geometry and one allocation per grid
+  std::vector<std::shared_ptr<CellGrid> > gs((size_t)m);
+  for (int k = 0; k < m; ++k) {
+    const size_t n = todo[(size_t)k]->n;
+    float hb[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    for (int b = 0; b < kBoxBlocks; ++b)
+      for (int j = 0; j < 3; ++j) {
+        hb[j] = std::min(hb[j], h_part[((size_t)k * kBoxBlocks + b) * 6 + j]);
+        hb[3 + j] = std::max(hb[3 + j], h_part[((size_t)k * kBoxBlocks + b) * 6 + 3 + j]);
+      }
+    auto g = std::make_shared<CellGrid>();
+    g->n = n;
+    double ext[3];
+    for (int j = 0; j < 3; ++j) { g->lo[j] = hb[j]; ext[j] = std::max(1e-6, (double)hb[3 + j] - (double)hb[j]); }
+    // ~grid_cell_points points per cell on a SURFACE of about the bounding box's face area (a scan is a sheet, not a
+    // volume); never more than 512 cells per axis / 32 M cells (128 MB of cell starts, of which only the cells near the
+    // surface are ever read)
+    const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+    double h = std::sqrt((double)std::max(1, c->grid_cell_points) * area / (double)n);
+    h = std::max(h, std::max(ext[0], std::max(ext[1], ext[2])) / 512.0);
+    for (;;) {
+      double cells = 1.0;
+      for (int j = 0; j < 3; ++j) { g->dim[j] = (int)std::floor(ext[j] / h) + 1; cells *= g->dim[j]; }
+      if (cells <= 32.0e6) break;
+      h *= 1.25;
+    }
+    g->h = (float)h; g->inv_h = (float)(1.0 / h);
+    const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
+    cells_max = std::max(cells_max, cells);
+    const size_t o_start = 0, o_gperm = o_start + align256((cells + 1 + 4) * 4), o_graw = o_gperm + align256(n * 4), o_g2h = o_graw + align256(n * sizeof(float4)),
+                 o_h2g = o_g2h + align256(n * 4), o_dt = o_h2g + align256(n * 4), total = o_dt + align256(cells);
+    if (hipMalloc(&g->block, total) != hipSuccess) { (void)hipGetLastError(); return set_error(c, MVR_E_NOMEM, "grid build: out of device memory"); }
+    g->start = reinterpret_cast<uint32_t *>(g->block + o_start); g->gperm = reinterpret_cast<uint32_t *>(g->block + o_gperm);
+    g->graw = reinterpret_cast<float4 *>(g->block + o_graw); g->g2h = reinterpret_cast<uint32_t *>(g->block + o_g2h);
+    g->h2g = reinterpret_cast<uint32_t *>(g->block + o_h2g); g->dt = reinterpret_cast<uint8_t *>(g->block + o_dt);
+    int steps = (int)std::ceil(std::max(0.0, reach) / h) + 2;       // enough to rule out `reach` (dt - 1 cell edges > reach + a cell), at most kGridDtMax
+    g->dt_steps = std::min(kGridDtMax, std::max(2, steps));
+    gs[(size_t)k] = g;
+  }
+  // ---- temporaries: cell ids (two buffers for the sort), indices, the distance map's second buffer, hipCUB's scratch
+  (void)cells_max;
+  uint32_t *cid_a = reinterpret_cast<uint32_t *>(c->scratch + o_cid_a), *cid_b = reinterpret_cast<uint32_t *>(c->scratch + o_cid_b),
+           *idx_a = reinterpret_cast<uint32_t *>(c->scratch + o_idx);
+  uint8_t *dt_tmp = reinterpret_cast<uint8_t *>(c->scratch + o_dtt);
+  void *cub = c->scratch + o_cub;
+  for (int k = 0; k < m; ++k) {
+    Cloud &cl = *todo[(size_t)k];
+    CellGrid &g = *gs[(size_t)k];
+    const size_t n = g.n, cells = (size_t)g.dim[0] * g.dim[1] * g.dim[2];
     GridGeom gg;
-    for (int k = 0; k < 3; ++k) { gg.lo[k] = g->lo[k]; gg.dim[k] = g->dim[k]; }
-    gg.inv_h = g->inv_h;
+    for (int j = 0; j < 3; ++j) { gg.lo[j] = g.lo[j]; gg.dim[j] = g.dim[j]; }
+    gg.inv_h = g.inv_h;
     const unsigned nb = (unsigned)((n + 255) / 256), cb = (unsigned)((cells + 255) / 256);
-    hipLaunchKernelGGL(cell_id_kernel, dim3(nb), dim3(256), 0, c->stream, canon.pts, n, gg, cid_a, idx_a);
+    hipLaunchKernelGGL(cell_id_kernel, dim3(nb), dim3(256), 0, on, cl.pts, n, gg, cid_a, idx_a);
     int bits = 1;
     while (((size_t)1 << bits) < cells) ++bits;
-    size_t bytes = 0;
-    ok = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, cid_a, cid_b, idx_a, g->gperm, (int)n, 0, bits, c->stream) == hipSuccess;
-    void *tmp = nullptr;
-    if (ok) ok = hipMalloc(&tmp, bytes + 256) == hipSuccess;
-    if (ok) ok = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, cid_a, cid_b, idx_a, g->gperm, (int)n, 0, bits, c->stream) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(cell_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, c->stream, cid_b, n, cells, g->start);
-      hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, c->stream, canon.pts, g->gperm, n, g->graw);
-      // distance map: as many dilation steps as ruling out `reach` takes (dt - 1 cell edges > reach + a cell), at most
-      // kGridDtMax; ping-pong (an even count: the result ends in g->dt).  Half of a grid's build time is these steps.
-      static_assert(kGridDtMax % 2 == 0, "ping-pong ends in dt");
-      int steps = (int)std::ceil(std::max(0.0, reach) / h) + 2;
-      steps = std::min(kGridDtMax, std::max(2, steps + (steps & 1)));
-      g->dt_steps = steps;
-      hipLaunchKernelGGL(dt_init_kernel, dim3(cb), dim3(256), 0, c->stream, g->start, cells, g->dt);
-      for (int step = 1; step <= steps; ++step) {
-        uint8_t *in = (step & 1) ? g->dt : dt_tmp, *out = (step & 1) ? dt_tmp : g->dt;
-        hipLaunchKernelGGL(dt_step_kernel, dim3(cb), dim3(256), 0, c->stream, in, out, g->dim[0], g->dim[1], g->dim[2], step);
-      }
-      ok = hipGetLastError() == hipSuccess;
+    size_t b1 = cub_bytes;
+    MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(cub, b1, cid_a, cid_b, idx_a, g.gperm, (int)n, 0, bits, on));
+    MVR_HIP_TRY(c, hipMemsetAsync(g.start, 0xFF, (cells + 1 + 4) * 4, on));
+    hipLaunchKernelGGL(cell_first_kernel, dim3(nb), dim3(256), 0, on, cid_b, n, cells, g.start);
+    auto rit = thrust_like_reverse(g.start, cells + 1);
+    size_t b2 = cub_bytes;
+    MVR_HIP_TRY(c, hipcub::DeviceScan::InclusiveScan(cub, b2, rit, rit, MinU32(), (int)(cells + 1), on));
+    hipLaunchKernelGGL(pad_start_kernel, dim3(1), dim3(64), 0, on, g.start, cells, (uint32_t)n);
+    hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, on, cl.pts, g.gperm, n, g.graw);
+    hipLaunchKernelGGL(dt_occupancy_kernel, dim3(cb), dim3(256), 0, on, g.start, cells, dt_tmp);
+    hipLaunchKernelGGL(dt_axis_kernel, dim3(cb), dim3(256), 0, on, dt_tmp, g.dt, g.dim[0], g.dim[1], g.dim[2], 0, g.dt_steps);
+    hipLaunchKernelGGL(dt_axis_kernel, dim3(cb), dim3(256), 0, on, g.dt, dt_tmp, g.dim[0], g.dim[1], g.dim[2], 1, g.dt_steps);
+    hipLaunchKernelGGL(dt_axis_kernel, dim3(cb), dim3(256), 0, on, dt_tmp, g.dt, g.dim[0], g.dim[1], g.dim[2], 2, g.dt_steps);
+    MVR_HIP_TRY(c, hipGetLastError());
+    if (side) {               // whoever uses the grid first on another stream waits for this
+      MVR_HIP_TRY(c, hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
+      MVR_HIP_TRY(c, hipEventRecord(g.ready, on));
     }
-    (void)hipStreamSynchronize(c->stream);
-    if (tmp) (void)hipFree(tmp);
+    cl.grid = gs[(size_t)k];
+    c->grids[cl.set_id] = gs[(size_t)k];
   }
-  if (dt_tmp) (void)hipFree(dt_tmp);
-  for (uint32_t *p : {cid_a, cid_b, idx_a}) if (p) (void)hipFree(p);
-  if (!ok) return false;
-  canon.grid = g;
   for (auto i2 = c->grids.begin(); i2 != c->grids.end();) i2 = i2->second.expired() ? c->grids.erase(i2) : std::next(i2);
-  c->grids[canon.set_id] = g;
-  return true;
+  if (!c->scratch_event) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->scratch_event, hipEventDisableTiming));
+  MVR_HIP_TRY(c, hipEventRecord(c->scratch_event, on));
+  c->scratch_stream = on;
+  return MVR_OK;
+}
+
+bool ensure_grid(Ctx *c, Cloud &canon, double reach)
+{
+  Cloud *one = &canon;
+  if (ensure_grids(c, &one, 1, reach, c->stream, nullptr) != MVR_OK) return false;
+  return canon.grid != nullptr && canon.grid->n == canon.n;
 }
 
 // posed copies: coordinates in grid order (and the grid-position -> Hilbert-position map, once per ordering)
@@ -513,6 +637,10 @@ int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
       Cloud *cl = posed[base + k];
       if (!cl || !cl->grid || !cl->pose_known || cl->gcoords_valid || cl->n == 0 || cl->grid->n != cl->n) continue;
       if (int rc = ensure(c, cl->gsorted, cl->gsorted_cap, cl->n)) return rc;
+      if (cl->grid->ready && !cl->grid->ready_waited) {      // built on the side stream: this is its first use on the main one
+        MVR_HIP_TRY(c, hipStreamWaitEvent(c->stream, cl->grid->ready, 0));
+        cl->grid->ready_waited = true;
+      }
       if (cl->order && cl->grid->built_for != cl->order.get()) {
         hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h, cl->grid->h2g);
         cl->grid->built_for = cl->order.get();

@@ -55,6 +55,9 @@ struct CellGrid {
   float4 *graw = nullptr;                // [n] canonical coordinates in grid order, w = bits(original index)
   uint32_t *g2h = nullptr;               // [n] grid position -> position in the set's Hilbert ordering (what the fused pass's keys carry)
   uint32_t *h2g = nullptr;               // [n] its inverse: where a seed (a Hilbert position) sits in grid order -- the seed's coordinates then come from the array the walk reads anyway
+  char *block = nullptr;                 // the ONE device allocation the arrays below are carved out of
+  hipEvent_t ready = nullptr;            // set when the grid was built on the context's side stream: recorded behind its last build kernel
+  bool ready_waited = false;             // ... and the context's main stream has been made to wait for it
   uint8_t *dt = nullptr;                 // [cells] Chebyshev distance, in cells, to the nearest occupied cell (0 = occupied, 255 = farther than dt_steps): "is there any point near here at all" in ONE byte
   int dt_steps = 0;                      // dilation steps dt was built with: 255 means "farther than dt_steps cells"
   const Order *built_for = nullptr;      // the ordering g2h refers to
@@ -177,6 +180,10 @@ struct Ctx {
   // index-build scratch
   uint32_t *codes_a = nullptr, *codes_b = nullptr, *idx_a = nullptr; size_t sort_cap = 0;
   void *cub_tmp = nullptr; size_t cub_cap = 0;
+  char *scratch = nullptr; size_t scratch_cap = 0;    // temporaries of the grid builds (grows, never shrinks)
+  hipStream_t side_stream = nullptr;                  // set-up work that may overlap a pass (grid builds)
+  hipEvent_t side_after = nullptr;                    // recorded on the main stream before the pass the side stream's work overlaps
+  hipEvent_t scratch_event = nullptr; hipStream_t scratch_stream = nullptr;      // the last user of `scratch`
   float *bbox = nullptr;                              // device: 8 floats (lo xyz, hi xyz)
   // launch configuration (mvr_ctx_tune)
   int nn_q = 8, nn_sub = 32, nn_blocks_per_cu = 2;
@@ -238,6 +245,7 @@ struct Ctx {
   uint32_t *h_done = nullptr, *d_done = nullptr;      // pinned, mapped: the stream writes the pass number here when a pass's chain has drained
   uint32_t pipe_seq = 0;                              // passes sent through the pipe so far
   unsigned long long pipe_steady_sig = 0, pipe_steady_events = ~0ull;      // the registration whose last run ended in steady state, and blocking_events then
+  std::vector<double> pass_ms;                        // wall time of every pass of the last ring run (end of the previous solve -> end of this one)
   unsigned long long piped_passes = 0;                // passes of this context whose chain was enqueued ahead of their poses (diagnostics)
   // multi-GPU (mvr_world.cpp): an RCCL communicator (ncclComm_t; null = this context is a world of its own)
   void *comm = nullptr; bool comm_owned = false; int comm_rank = 0, comm_world = 1;
@@ -456,13 +464,15 @@ int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
 // the set's grid (built from `canon`, a cloud holding the set's canonical coordinates) and the posed copy's grid-ordered
 // coordinates; false = not available (the caller uses the culled kernel)
 int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo xyz, hi xyz} on the host (synchronises the stream)
-bool ensure_grid(Ctx *c, Cloud &canon, double reach);      // reach: the search radius the distance map should be able to rule out (mm)
+bool ensure_grid(Ctx *c, Cloud &canon, double reach);
+int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream_t on, hipEvent_t after);      // the same for many sets at once, enqueued on `on` (no wait afterwards)      // reach: the search radius the distance map should be able to rule out (mm)
 int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
 // the pipelined pass loop shared by mvr_ring_run and mvr_ring_run_sharded (mvr_ctx.hip).  enqueue(): one pass's GPU work on
 // c->stream, ending with the edge table on its way to c->h_table; solve(): the host step on c->h_table, poses in / out.
 struct PassLoop {
   int n_views = 0; const int *posed_slots = nullptr, *raw_slots = nullptr; double *poses = nullptr;     // poses: [views][16], in / out
   int (*enqueue)(void *self) = nullptr; int (*solve)(void *self) = nullptr; void *self = nullptr;
+  double reach = 0.0;              // the search radius of the passes (mm): with it the loop builds the scans' grids while the first pass searches
   unsigned long long sig = 0;      // identifies the registration (slots, point sets, edges, parameters): a run that ended in steady state lets the next run of the SAME registration start pipelined
 };
 unsigned long long pass_loop_sig(Ctx *c, int n_views, const int *posed_slots, const int *raw_slots, int ne, const int *edge_src, const int *edge_tgt,

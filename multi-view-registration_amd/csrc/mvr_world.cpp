@@ -363,7 +363,7 @@ struct RankRun {
   mvr_ctx *ctx; RankPlan plan; int n_views, ne; const int *edge_src, *edge_tgt; double max_dist; int reciprocal, fma; const double *origin;
   int lum_iterations; double *poses, *lum_pose; float *pair_T; double *pair_n, *pair_mse; int *lum_iters; double *rows;
   std::vector<double> pn, pm;
-  int local_error = MVR_OK;
+  int rank = 0, world = 1;
   static int enqueue(void *p)
   {
     RankRun &r = *static_cast<RankRun *>(p);
@@ -380,11 +380,16 @@ struct RankRun {
     // ordinary way (ring_passes): nothing of it may reach the collective.  Any OTHER failure of the local work is reported
     // THROUGH the collective, so that the peers end this pass with an error too instead of waiting in it for ever.
     if (local != MVR_OK && c->no_sync) return local;
-    r.local_error = local;
-    if (local != MVR_OK) MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table, 0, (size_t)r.ne * 32 * sizeof(double), c->stream));
-    c->h_moments[49] = local == MVR_OK ? 0.0 : 1.0;
+    // the status row: [0] = ranks that failed, [1 + rank] = this rank's (negated) status -- so that after the reduction a rank
+    // knows whether the failure was its own without any host-side memory of the pass (passes are enqueued ahead of their solves)
     MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table + (size_t)r.ne * 32, 0, 32 * sizeof(double), c->stream));
-    if (local != MVR_OK) MVR_HIP_TRY(c, hipMemcpyAsync(c->dist_table + (size_t)r.ne * 32, c->h_moments + 49, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (local != MVR_OK) {
+      MVR_HIP_TRY(c, hipMemsetAsync(c->dist_table, 0, (size_t)r.ne * 32 * sizeof(double), c->stream));
+      double *flag = c->h_moments + 48;      // (pinned; only ever written in this branch, which is never taken while a chain is queued ahead)
+      flag[0] = 1.0; flag[1] = (double)(-local);
+      MVR_HIP_TRY(c, hipMemcpyAsync(c->dist_table + (size_t)r.ne * 32, flag, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      MVR_HIP_TRY(c, hipMemcpyAsync(c->dist_table + (size_t)r.ne * 32 + 1 + (size_t)(r.rank % 31), flag + 1, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     if (int rc = comm_allreduce(c, c->dist_table, table_n, kReduceSumF64)) return rc;
     MVR_HIP_TRY(c, hipMemcpyAsync(c->h_table, c->dist_table, table_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return MVR_OK;
@@ -393,8 +398,11 @@ struct RankRun {
   {
     RankRun &r = *static_cast<RankRun *>(p);
     Ctx *c = CTX(r.ctx);
-    if (c->h_table[(size_t)r.ne * 32] > 0.0)
-      return r.local_error != MVR_OK ? r.local_error : set_error(c, MVR_E_RCCL, "a peer's local work failed in this pass");
+    if (c->h_table[(size_t)r.ne * 32] > 0.0) {
+      const double mine = c->h_table[(size_t)r.ne * 32 + 1 + (size_t)(r.rank % 31)];
+      if (mine > 0.0 && r.world <= 31) return set_error(c, -(int)mine, "this rank's local work failed in this pass (reported to its peers through the pass's all-reduce)");
+      return set_error(c, MVR_E_RCCL, "a peer's local work failed in this pass");
+    }
     if (r.rows && r.ne) std::memcpy(r.rows, c->h_table, (size_t)r.ne * 32 * sizeof(double));
     const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, c->h_table, r.origin, r.lum_iterations, r.poses, r.lum_pose, r.pair_T,
                                       r.pair_n ? r.pair_n : r.pn.data(), r.pair_mse ? r.pair_mse : r.pm.data(), r.lum_iters);
@@ -419,13 +427,14 @@ API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *
   // everything that can fail for local reasons and is known up front happens BEFORE the first collective: the plan,
   // the tables (the passes themselves report later failures through the collective, see RankRun::enqueue)
   RankRun run{ctx, RankPlan(), n_views, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin, lum_iterations, poses, lum_pose, pair_T,
-              pair_n, pair_mse, lum_iters, rows, std::vector<double>((size_t)ne), std::vector<double>((size_t)ne), MVR_OK};
+              pair_n, pair_mse, lum_iters, rows, std::vector<double>((size_t)ne), std::vector<double>((size_t)ne), rank, world};
   if (int rc = make_rank_plan(ctx, rank, world, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, &run.plan)) return rc;
   if (int rc = ensure_tables(c, ne + 1)) return rc;
   PassLoop L;
   L.n_views = n_views; L.posed_slots = posed_slots; L.raw_slots = raw_slots; L.poses = poses;
   L.enqueue = &RankRun::enqueue; L.solve = &RankRun::solve; L.self = &run;
   L.sig = pass_loop_sig(c, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, 1 + rank + 1000 * world);
+  L.reach = max_dist;
   return ring_passes(c, n_steps, L, timing_ms);
 }
 

@@ -4,7 +4,7 @@
 // to compare with the oracle-based restatement of the same driver loops.
 //
 // usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
-//   mode: seq | lum | auto | err | api          the reference's loops on the PCL-named shim (reference_replay.hpp)
+//   mode: seq | lum | auto | err | api          the PCL-named call surface, in the reference's order of calls (call_surface.hpp)
 //         seqdev | lumdev | errdev | register      the product's device-resident drivers (mvr/registrator.hpp)
 //         world                                    the single-process multi-GPU host (mvr_world_*), here with one GPU
 //         denoise
@@ -17,10 +17,10 @@
 #include <unistd.h>
 
 #define MVR_ALIAS_PCL
-#include "reference_replay.hpp"
+#include "call_surface.hpp"
 
 using namespace mvr;
-using mvr_replay::ReplayRegistrator;
+using surface::CallSurface;
 
 static void print_pose(const RowMatrixd &m, bool last)
 {
@@ -56,7 +56,7 @@ int main(int argc, char **argv)
       model.views[v].points.resize(N);
       if (mvr_synth_view(&sp, v, N, model.views[v].points.points[0].data, nullptr) != MVR_OK) return 3;
     }
-    ReplayRegistrator reg(&model);       // is-a mvr::Registrator: the device-resident drivers are reachable through it too
+    CallSurface reg(&model);             // is-a mvr::Registrator: the device-resident drivers are reachable through it too
     double piv[3], ax[3];
     mvr_synth_prior(&sp, piv, ax);
     reg.setPivotPoint(piv[0], piv[1], piv[2]);
@@ -64,9 +64,11 @@ int main(int argc, char **argv)
 
     std::printf("{\"mode\":\"%s\",", mode.c_str());
     if (mode == "seq") {
-      reg.registrationICP(1000, max_d, 0, repeat);
+      surface::IcpKnobs k;                       // the sequential mode's settings: registrator.cpp:551-560
+      k.max_distance = max_d; k.max_iterations = 1000; k.transformation_epsilon = 0.000001; k.fitness_epsilon = 64;
+      reg.growingTargetSweeps(k, repeat);
     } else if (mode == "lum") {
-      reg.registrationLUM(10, 16 * repeat, max_d, 0);
+      reg.ringRelaxation(repeat, max_d);
       std::printf("\"lum_ncorr\":[");
       for (size_t i = 0; i < reg.lum_ncorr.size(); ++i) std::printf("%d%s", reg.lum_ncorr[i], i + 1 < reg.lum_ncorr.size() ? "," : "");
       std::printf("],");
@@ -146,13 +148,15 @@ int main(int argc, char **argv)
       for (size_t i = 0; i < pc.points.size(); ++i) { sx += pc.points.points[i].x; sy += pc.points.points[i].y; sz += pc.points.points[i].z; }
       std::printf("\"noise\":%zu,\"kept\":%zu,\"sum\":[%.17g,%.17g,%.17g],", noise, pc.points.size(), sx, sy, sz);
     } else if (mode == "auto") {
-      reg.automaticRegistration(0, 1000, repeat, max_d, 50.0);
+      surface::IcpKnobs k;                       // the incremental mode: no transformation epsilon (registrator.cpp:901-904), fitness epsilon 50
+      k.max_distance = max_d; k.max_iterations = 1000; k.with_transformation_epsilon = false; k.fitness_epsilon = 50.0;
+      reg.addViewsOneByOne(k, repeat);
     } else if (mode == "err") {
-      auto pairs = reg.computeError(0, max_d);
+      auto pairs = reg.ringResiduals(max_d);
       std::printf("\"pairs\":[");
       for (size_t i = 0; i < pairs.size(); ++i) {
-        double s = 0; for (const Correspondence &c : *pairs[i].second) s += c.distance;
-        std::printf("[%d,%d,%zu,%.17g]%s", pairs[i].first.first, pairs[i].first.second, pairs[i].second->size(), s, i + 1 < pairs.size() ? "," : "");
+        double s = 0; for (const Correspondence &c : *pairs[i].pairs) s += c.distance;
+        std::printf("[%d,%d,%zu,%.17g]%s", pairs[i].a, pairs[i].b, pairs[i].pairs->size(), s, i + 1 < pairs.size() ? "," : "");
       }
       std::printf("],");
     } else if (mode == "api") {
@@ -202,7 +206,7 @@ int main(int argc, char **argv)
     std::printf("],");
     if (mode == "seq" || mode == "auto" || mode == "lum" || mode == "lumdev" || mode == "seqdev") {
       for (int v = 0; v < V; ++v) model.views[v].setRegisterState(true);
-      if (mode == "lumdev" || mode == "seqdev") reg.mvr::Registrator::refineAxis(0); else reg.refineAxis(0);
+      reg.refineAxis(0);                          // the product's (mvr_refine_axis)
       std::printf("\"refined_pivot\":[%.9g,%.9g,%.9g],\"refined_axis\":[%.9g,%.9g,%.9g],", reg.getPivotPoint()[0], reg.getPivotPoint()[1],
                   reg.getPivotPoint()[2], reg.getAxisNormal()[0], reg.getAxisNormal()[1], reg.getAxisNormal()[2]);
     }

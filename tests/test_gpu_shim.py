@@ -1,7 +1,7 @@
 """GPU tests of the C++ layer (include/mvr/*.hpp) through tests/cxx/shim_driver:
   * the reference's own driver loops (Registrator::registrationICP / registrationLUM / computeError /
     automaticRegistration, mvr/src/registrator.cpp), replayed call for call on the PCL-named shim classes
-    (tests/cxx/reference_replay.hpp -- call-site compatibility), and
+    (tests/cxx/call_surface.hpp -- call-site compatibility), and
   * the product's device-resident drivers (mvr::Registrator::registrationICPDevice / registrationLUMDevice /
     computeErrorDevice / registration),
 both compared with the same loops restated on the CPU oracle (tests/ref_driver.py) on identical synthetic scans."""
