@@ -1400,9 +1400,10 @@ int pipe_setup(Ctx *c, int n_views)
 struct Spin { double t0 = now_ms(); unsigned n = 0; };
 // the host's wait for "pass seq has drained": a spin on pinned memory (a wake-up from hipStreamSynchronize costs tens of
 // microseconds), with a look at the stream every few thousand rounds so that a failed launch ends the wait, and a bound
-int wait_done(Ctx *c, uint32_t seq)
+int wait_done(Ctx *c, uint32_t seq, bool *timed_out = nullptr)
 {
   Spin sp;
+  if (timed_out) *timed_out = false;
   for (;;) {
     if ((int32_t)(__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) - seq) >= 0) return MVR_OK;
     __builtin_ia32_pause();
@@ -1411,9 +1412,12 @@ int wait_done(Ctx *c, uint32_t seq)
       if (e != hipSuccess && e != hipErrorNotReady) return set_error(c, MVR_E_HIP, "a pass of the pipelined ring run failed on the device", e);
       if (e == hipSuccess && (int32_t)(__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) - seq) >= 0) return MVR_OK;
       if (int rc = comm_poll(c)) return rc;                 // (a peer's failure surfaces here: the communicator is aborted, the pass will not finish)
-      if (now_ms() - sp.t0 > (double)c->wait_timeout_ms)
-        return c->comm ? comm_abort(c, "a pass did not finish in time: a peer failed or never arrived")
-                       : set_error(c, MVR_E_HIP, "a pass of the pipelined ring run did not finish in time");
+      if (now_ms() - sp.t0 > (double)c->wait_timeout_ms) {
+        // (with a communicator the caller aborts it -- after it has opened the gate of the chain queued behind this pass:
+        // ncclCommAbort waits for the stream, and the stream would wait for the gate)
+        if (timed_out) *timed_out = true;
+        return set_error(c, c->comm ? MVR_E_RCCL : MVR_E_HIP, "a pass of the pipelined ring run did not finish in time");
+      }
     }
   }
 }
@@ -1427,6 +1431,14 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
   c->pass_ms.clear();
   double t_prev = now_ms();
   auto pass_done = [&]() { const double t = now_ms(); c->pass_ms.push_back(t - t_prev); t_prev = t; };
+  auto pipe_possible = [&]() {
+    if (!c->pipeline || c->nn_mode == 0 || !c->pair_fused || c->grid_debug || V < 2) return false;
+    for (int v = 0; v < V; ++v) {
+      if (L.posed_slots[v] == L.raw_slots[v] || c->slots[L.raw_slots[v]].has_normals) return false;
+      for (int u = 0; u < v; ++u) if (L.posed_slots[u] == L.posed_slots[v]) return false;
+    }
+    return true;
+  };
   // The scans' cell grids are needed from the second pass on.  When more passes follow in this call they are built on the
   // context's side stream WHILE this pass's searches run (12 x 200k: 8.8 ms of the second pass in round 2), behind an
   // event taken before the pass was enqueued; failure is not fatal -- the next pass builds what is missing.
@@ -1444,8 +1456,14 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
       if (!c->side_after && hipEventCreateWithFlags(&c->side_after, hipEventDisableTiming) != hipSuccess) c->side_after = nullptr;
       if (c->side_after) (void)hipEventRecord(c->side_after, c->stream);
     }
+    // set-up that overlaps the pass: the grids on the side stream, the pipe's few allocations -- the GPU is busy with this
+    // pass meanwhile.  NOT behind a pass that contains a collective: streams share hardware queues, and a collective that
+    // a lost peer keeps from finishing would hold the side stream's packets behind it -- the host would wait for the side
+    // stream instead of reaching the bounded wait that ends such a pass (found with the injected stall of the tests).
+    const bool setup_first = c->comm != nullptr || c->inject_stall_at >= 0;
+    if (more_follow && setup_first) { prebuild_grids(); if (pipe_possible()) (void)pipe_setup(c, V); }
     if (int rc = L.enqueue(L.self)) return rc;
-    if (more_follow) prebuild_grids();
+    if (more_follow && !setup_first) { prebuild_grids(); if (pipe_possible()) (void)pipe_setup(c, V); }
     const double t1 = now_ms();
     if (int rc = stream_wait(c)) return rc;
     const double t2 = now_ms();
@@ -1454,14 +1472,6 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
     return rc;
   };
   auto all_rigid = [&]() { for (int v = 0; v < V; ++v) if (!pose_nearly_rigid(L.poses + 16 * (size_t)v)) return false; return true; };
-  auto pipe_possible = [&]() {
-    if (!c->pipeline || c->nn_mode == 0 || !c->pair_fused || c->grid_debug || V < 2) return false;
-    for (int v = 0; v < V; ++v) {
-      if (L.posed_slots[v] == L.raw_slots[v] || c->slots[L.raw_slots[v]].has_normals) return false;
-      for (int u = 0; u < v; ++u) if (L.posed_slots[u] == L.posed_slots[v]) return false;
-    }
-    return true;
-  };
   bool steady = L.sig != 0 && c->pipe_steady_sig == L.sig && c->pipe_steady_events == c->blocking_events;
   int k = 0;
   while (k < n_steps) {
@@ -1525,12 +1535,18 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
         sum[0] += now_ms() - t0;
       }
       t0 = now_ms();
-      rc = wait_done(c, seq_cur);
+      bool timed_out = false;
+      rc = wait_done(c, seq_cur, &timed_out);
       const double t1 = now_ms();
       if (rc == MVR_OK) rc = L.solve(L.self);
       sum[1] += t1 - t0; sum[2] += now_ms() - t1;
       if (rc != MVR_OK) {                              // nothing may stay behind a closed gate
         if (more) { const std::vector<double> safe = last_in; write_poses(parity ^ 1, safe.data()); open_gate(seq_next); }
+        if (timed_out) {                               // (releases an injected stall too)
+          const bool had_comm = c->comm != nullptr;
+          const int r2 = comm_abort(c, "a pass did not finish in time: a peer failed or never arrived");
+          if (had_comm) rc = r2; else (void)set_error(c, rc, "a pass of the pipelined ring run did not finish in time");
+        }
         (void)hipStreamSynchronize(c->stream);
         leave();
         return rc;

@@ -20,7 +20,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -109,12 +113,33 @@ std::vector<Segment> split_queries(const std::vector<size_t> &sizes, int world, 
 // (2) A rank that waits for a pass containing a collective waits at most wait_timeout_ms, polling RCCL's asynchronous error
 //     state meanwhile; on either it aborts the communicator (ncclCommAbort: the queued collective kernels exit), drains
 //     its stream and returns MVR_E_RCCL.  The context stays usable for single-GPU work; the communicator is gone.
+static bool trace_comm() { static const bool on = std::getenv("MVR_TRACE_COMM") != nullptr; return on; }
+#define MVR_TRACE(...) do { if (trace_comm()) { std::fprintf(stderr, "[mvr comm] " __VA_ARGS__); std::fprintf(stderr, "\n"); std::fflush(stderr); } } while (0)
+
 int comm_abort(Ctx *c, const char *why)
 {
+  MVR_TRACE("abort: %s (comm %p, stall word %p)", why, c->comm, (void *)c->h_stall);
   Rccl &r = rccl();
   if (c->h_stall) __atomic_store_n(c->h_stall, 1u, __ATOMIC_RELEASE);            // (an injected stall must not outlive the abort)
   if (c->comm) {
-    if (r.lib && r.CommAbort) (void)r.CommAbort(reinterpret_cast<ncclComm_t>(c->comm));
+    if (r.lib && r.CommAbort) {
+      // ncclCommAbort itself must not become the hang it is there to end: it runs on a helper thread that is given five
+      // seconds; a call that has not come back by then is left behind (the communicator is unusable either way)
+      struct Box { std::mutex m; std::condition_variable cv; bool done = false; };
+      auto box = std::make_shared<Box>();
+      const ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm);
+      const int device = c->device;
+      auto fn = r.CommAbort;
+      std::thread([box, comm, device, fn] {
+        (void)hipSetDevice(device);
+        (void)fn(comm);
+        { std::lock_guard<std::mutex> g(box->m); box->done = true; }
+        box->cv.notify_all();
+      }).detach();
+      std::unique_lock<std::mutex> lk(box->m);
+      const bool back = box->cv.wait_for(lk, std::chrono::seconds(5), [&] { return box->done; });
+      MVR_TRACE("ncclCommAbort %s", back ? "returned" : "did NOT return within 5 s (left behind)");
+    }
     if (c->comm_lender) *c->comm_lender = nullptr;                                // a world's communicator: the world must not destroy it again
     c->comm = nullptr; c->comm_owned = false; c->comm_lender = nullptr;
     c->comm_broken = true;
@@ -142,6 +167,7 @@ int stream_wait(Ctx *c)
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   unsigned n = 0;
+  MVR_TRACE("stream_wait: bounded, %d ms", c->wait_timeout_ms);
   for (;;) {
     const hipError_t e = hipStreamQuery(c->stream);
     if (e == hipSuccess) return MVR_OK;
@@ -150,7 +176,9 @@ int stream_wait(Ctx *c)
       if (int rc = comm_poll(c)) { (void)hipStreamSynchronize(c->stream); return rc; }
       if (std::chrono::duration<double, std::milli>(clk::now() - t0).count() > (double)c->wait_timeout_ms) {
         const int rc = comm_abort(c, "a pass with a collective did not finish in time: a peer failed or never arrived");
+        MVR_TRACE("draining the stream");
         (void)hipStreamSynchronize(c->stream);                                    // the aborted collective and everything behind it drain now
+        MVR_TRACE("drained");
         return rc;
       }
     }
@@ -160,17 +188,23 @@ int stream_wait(Ctx *c)
 
 int comm_allreduce(Ctx *c, void *dev_buf, size_t count, int kind)
 {
-  if (c->inject_stall_at >= 0 && c->dist_pass - 1 == c->inject_stall_at) {
-    // test hook: this rank's stream stalls in front of the collective, as if a peer never arrived (released by comm_abort)
+  const bool stall = c->inject_stall_at >= 0 && c->dist_pass - 1 == c->inject_stall_at && kind == kReduceSumF64;      // (the LAST collective of a pass / iteration)
+  auto stall_stream = [&]() -> int {
+    // test hook: the pass this collective belongs to never finishes on this rank -- what a peer that died inside the
+    // collective looks like from here (the word is released by comm_abort).  The wait is queued BEHIND the collective:
+    // RCCL's enqueue may itself synchronise with the stream and must not meet a stream that cannot move.
     if (!c->h_stall) {
       MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_stall), 64, hipHostMallocMapped));
       MVR_HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_stall), c->h_stall, 0));
     }
     *c->h_stall = 0u;
     c->inject_stall_at = -1;
+    MVR_TRACE("injecting a stall behind the collective");
     MVR_HIP_TRY(c, hipStreamWaitValue32(c->stream, c->d_stall, 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
-  }
-  if (!c->comm || count == 0) return MVR_OK;
+    MVR_TRACE("stall queued");
+    return MVR_OK;
+  };
+  if (!c->comm || count == 0) return stall ? stall_stream() : MVR_OK;
   Rccl &r = rccl();
   if (!r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
   const ncclResult_t e = kind == kReduceMinI64
@@ -181,7 +215,7 @@ int comm_allreduce(Ctx *c, void *dev_buf, size_t count, int kind)
     if (r.GetErrorString) { msg += ": "; msg += r.GetErrorString(e); }
     return comm_abort(c, msg.c_str());
   }
-  return MVR_OK;
+  return stall ? stall_stream() : MVR_OK;
 }
 
 }  // namespace mvr

@@ -178,6 +178,7 @@ def test_native_sequential_world_of_one(mvr, orc, seq_scene, multi_iter):
 
 
 # ---------------------------------------------------------------- a rank's failure never leaves anybody in a collective
+@pytest.mark.timeout(120)
 @pytest.mark.parametrize("at", [0, 1, 5])
 def test_ring_local_failure_travels_through_the_collective(mvr, scene, at):
     """A rank whose LOCAL work fails in pass `at` (injected) still joins that pass's ncclAllReduce -- with zero rows and a
@@ -202,6 +203,7 @@ def test_ring_local_failure_travels_through_the_collective(mvr, scene, at):
         assert np.array_equal(new, ref) and np.array_equal(info["rows"], rinfo["rows"])
 
 
+@pytest.mark.timeout(90)
 @pytest.mark.parametrize("at", [0, 5])
 def test_ring_peer_that_never_arrives_is_a_timeout_not_a_hang(mvr, scene, at):
     """The stream of this rank stalls in front of pass `at`'s collective (injected: what a peer that died looks like from
@@ -234,6 +236,7 @@ def test_ring_peer_that_never_arrives_is_a_timeout_not_a_hang(mvr, scene, at):
         assert np.array_equal(new, ref)
 
 
+@pytest.mark.timeout(120)
 @pytest.mark.parametrize("how", ["fail", "stall"])
 def test_sequential_sharded_failures(mvr, seq_scene, how):
     import time
