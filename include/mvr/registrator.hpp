@@ -7,6 +7,7 @@
 //   Registrator::getRotationMatrix :331-342, load/save (axis.txt) :258-308   -> Registrator (same formats)
 //   registrationICP :517-588        -> Registrator::registrationICPDevice   (target grows in a device slot)
 //   registrationLUM :611-664        -> Registrator::registrationLUMDevice   (all passes in one native call)
+//   automaticRegistration :746-842, :877-990, :1008-1030 -> Registrator::automaticRegistrationDevice (in-place aligns, model grown in a slot)
 //   computeError :466-515           -> Registrator::computeErrorDevice      (per-pair count + residual)
 //   refineAxis :402-455             -> Registrator::refineAxis              (mvr_refine_axis)
 //   saveRegisteredPoints :344-400, registration :719-744                    -> same names
@@ -265,6 +266,54 @@ class Registrator {
         pc.setMatrix(pc.getMatrix() * RowMatrixd(PclMatrixCaster<RowMatrixd>(entry.T)));      // pose <- T_icp o pose
         d.check(mvr_cloud_append(d.ctx(), target.s, moved.s), "mvr_cloud_append");
       }
+    }
+  }
+
+  // ---- incremental registration (what automaticRegistration computes, registrator.cpp:746-842 with
+  // automaticRegistrationICP :877-990 and refineTransformation :1008-1030; intent per SURVEY App. C.1 -- the original
+  // indexes its view list out of bounds from the second view on and re-registers the earlier views cumulatively):
+  // the views are added one at a time; a new view gets its turntable prior, is posed from its resident raw scan, then
+  // advanced IN PLACE by `repeat_times` aligns against everything merged so far (the reference's `icp_.align(*source_)`
+  // whose output aliases its input, :920 / :1012 / :1024: every repeat continues from the last, pose <- T_j o pose), and
+  // is appended to the model where it stands.  The transformation epsilon is never set in this mode (it stays PCL's 0,
+  // App. C.3); the fitness epsilon is the caller's (the dialog's default is 50).  Per repeat one 4x4 crosses the bus.
+  // The logged fitness is the TRUE residual of the advanced source against the model (mvr_fitness with the identity),
+  // not the reference's double-transformed number (App. C.2).
+  void automaticRegistrationDevice(int object, int max_iterations, int repeat_times, double max_distance, double euclidean_fitness_epsilon,
+                                   bool log_fitness = false)
+  {
+    const int V = model_->numViews();
+    if (V < 2) return;
+    Device &d = Device::instance();
+    ensureResident(object);
+    size_t total = 0;
+    for (int v = 0; v < V; ++v) total += model_->getPointCloud(object, v).size();
+    mvr_icp_params p = mvr_icp_params();
+    p.use_reciprocal = 1; p.max_corr_dist = max_distance; p.max_iterations = max_iterations;
+    p.transformation_epsilon = 0.0; p.euclidean_fitness_eps = euclidean_fitness_epsilon;          // registrator.cpp:901-904
+    SlotGuard model, moving;
+    d.check(mvr_cloud_transform(d.ctx(), model.s, raw_[0], model_->getPointCloud(object, 0).getMatrix().asColumnMajorColumnVector()), "mvr_cloud_transform");
+    d.check(mvr_cloud_reserve(d.ctx(), model.s, total), "mvr_cloud_reserve");
+    const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int v = 1; v < V; ++v) {
+      ScanCloud &pc = model_->getPointCloud(object, v);
+      pc.initRotation(*this);
+      pc.setRegisterState(true);
+      d.check(mvr_cloud_transform(d.ctx(), moving.s, raw_[(size_t)v], pc.getMatrix().asColumnMajorColumnVector()), "mvr_cloud_transform");
+      for (int j = 0; j < repeat_times; ++j) {
+        float T[16];
+        mvr_icp_stats st = mvr_icp_stats();
+        const int rc = mvr_icp_align(d.ctx(), moving.s, model.s, moving.s, &p, T, &st);            // out == in: the source advances in place
+        if (rc != MVR_OK && rc != MVR_E_NOCORR) d.check(rc, "mvr_icp_align");
+        AlignLog entry{pc.getView(), Matrix4f(T), st.n_corr, st.mse, st.iterations, 0.0, false};
+        if (log_fitness) {
+          d.check(mvr_fitness(d.ctx(), moving.s, model.s, identity, DBL_MAX, 0, &entry.fitness), "mvr_fitness");
+          entry.has_fitness = true;
+        }
+        log.push_back(entry);
+        pc.setMatrix(pc.getMatrix() * RowMatrixd(PclMatrixCaster<RowMatrixd>(entry.T)));
+      }
+      d.check(mvr_cloud_append(d.ctx(), model.s, moving.s), "mvr_cloud_append");
     }
   }
 

@@ -24,6 +24,17 @@ int set_error(Ctx *c, int status, const char *what, hipError_t e)
   return status;
 }
 
+void host_mark(const char *what)
+{
+  static const bool on = std::getenv("MVR_TRACE_HOST") != nullptr;
+  if (!on) return;
+  using namespace std::chrono;
+  static double last = 0.0;
+  const double t = duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+  std::fprintf(stderr, "[mvr host] %8.3f ms  %s\n", last == 0.0 ? 0.0 : t - last, what);
+  last = t;
+}
+
 static hipEvent_t take_event(Ctx *c)
 {
   if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
@@ -137,7 +148,7 @@ void cloud_free(Cloud &cl)
 // coordinates and T is a rigid motion (what the grid search needs to walk the set's pose-invariant grid)
 void note_pose(Cloud &dst, const Cloud &src, bool src_canonical, const double T[16])
 {
-  dst.canonical = false; dst.pose_known = false;
+  dst.canonical = false; dst.pose_known = false; dst.fin_known = false; dst.parts.clear();
   if (!src_canonical || &dst == &src) return;
   if (T[3] != 0.0 || T[7] != 0.0 || T[11] != 0.0 || T[15] != 1.0) return;
   // NEARLY rigid: the poses of a registration are products with PCL-style float 4x4s (lum.getTransformation is an
@@ -330,6 +341,10 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_CULL_W")) c->cull_w = std::atoi(m);     // waves per query set: 1, 2, 4 (default)
   if (const char *m = std::getenv("MVR_CULL_SLICES")) c->cull_slices = std::atoi(m);   // XCD dealing of a pair's query sets: 1, 2, 4, 8 (0 = auto)
   if (const char *m = std::getenv("MVR_SEED_FORWARD")) c->seed_forward = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_PARTS_LANES")) c->parts_lanes = std::atoi(m);
+  if (const char *m = std::getenv("MVR_PARTS_MAX_ROWS")) c->parts_max_rows = std::max(1, std::atoi(m));
+  if (const char *m = std::getenv("MVR_GRID_DEBUG")) c->grid_debug = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_SEQ_SEARCH")) c->seq_search = std::max(0, std::min(2, std::atoi(m)));    // align against a target made of posed scans: 1 = through the scans' grids, 0 = culled kernel
   if (const char *m = std::getenv("MVR_RING_SEARCH")) c->ring_search = std::atoi(m);   // fused pass: 1 = grid search for bounded queries, 0 = culled kernel only
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
@@ -352,7 +367,8 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (hipMalloc(&c->count, 64) != hipSuccess || hipMalloc(&c->evals, (2 * kEvalRegion + kTraceRec * kTraceBlocks) * sizeof(uint64_t)) != hipSuccess ||
       hipMalloc(&c->bbox, 64) != hipSuccess || hipMalloc(&c->moments, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&c->h_moments, 64 * sizeof(double)) != hipSuccess ||
-      hipHostMalloc(&c->h_counts, kProfCounts * sizeof(uint64_t)) != hipSuccess) {
+      hipHostMalloc(&c->h_counts, kProfCounts * sizeof(uint64_t)) != hipSuccess ||
+      hipHostMalloc(&c->h_evals, kEvalRegion * sizeof(uint64_t)) != hipSuccess) {
     mvr_ctx_destroy(reinterpret_cast<mvr_ctx *>(c));
     return MVR_E_HIP;
   }
@@ -385,6 +401,8 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
                   c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  if (c->d_parts) (void)hipFree(c->d_parts);
+  if (c->h_parts) (void)hipHostFree(c->h_parts);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   if (c->side_after) (void)hipEventDestroy(c->side_after);
   if (c->scratch_event) (void)hipEventDestroy(c->scratch_event);
@@ -399,6 +417,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   if (c->h_moments) (void)hipHostFree(c->h_moments);
   if (c->h_table) (void)hipHostFree(c->h_table);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
+  if (c->h_evals) (void)hipHostFree(c->h_evals);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return MVR_OK;
@@ -584,6 +603,9 @@ API int mvr_cloud_copy(mvr_ctx *ctx, int dst, int src)
   d.n = s.n;
   inherit_point_set(d, s);
   d.canonical = s.canonical; d.pose_known = s.pose_known; d.pose_stretch = s.pose_stretch; std::memcpy(d.pose, s.pose, sizeof d.pose); d.grid = s.grid;
+  d.fin_known = s.fin_known; std::memcpy(d.fin, s.fin, sizeof d.fin);
+  d.parts = s.parts;
+  for (GridPart &gp : d.parts) gp.gs_filled = false;          // (the grid-ordered coordinates are not copied: written again at the first search)
   d.segs = s.segs;
   d.has_normals = false;
   if (s.has_normals && s.n) {
@@ -601,6 +623,25 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   Cloud &d = c->slots[dst];
   const size_t add = c->slots[src].n;         // read before a self-append grows it
+  // What the grown cloud is made of, when both sides are posed copies of scans (the sequential mode's model: view 0 posed,
+  // then one aligned view after the other): recorded so that mvr_icp_align can search it through the scans' grids.
+  auto provenance = [](const Cloud &x, size_t base, GridPart *gp) {
+    if (!(x.pose_known || x.fin_known) || x.n == 0 || !x.segs.empty()) return false;
+    gp->set_id = x.set_id; gp->n = x.n; gp->base = base; gp->kind = x.fin_known ? 2 : 1;
+    std::memcpy(gp->pose, x.pose, sizeof gp->pose); std::memcpy(gp->fin, x.fin, sizeof gp->fin);
+    gp->grid = x.grid; gp->gs_filled = false;
+    return true;
+  };
+  std::vector<GridPart> parts_after;
+  {
+    bool ok = dst != src && d.segs.empty() && add > 0;
+    if (ok) {
+      if (!d.parts.empty()) parts_after = d.parts;
+      else if (d.n > 0) { GridPart p0; ok = provenance(d, 0, &p0); if (ok) parts_after.push_back(p0); }
+    }
+    GridPart pn;
+    if (ok && provenance(c->slots[src], d.n, &pn)) parts_after.push_back(pn); else parts_after.clear();
+  }
   if (!d.segs.empty()) {                       // a shard: the appended points continue its global numbering
     uint32_t gend = 0;
     for (const Seg &sg : d.segs) gend = std::max(gend, sg.global_begin + sg.count);
@@ -617,8 +658,12 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
     if (dst != src && d.segs.empty() && extend_point_set(c, d, d.n, s)) {
       // a different point set all the same: what it is now DEFINES it (as new_point_set says for the other branch); a pose
       // or a grid of the set it grew from is not its own
-      d.canonical = true; d.pose_known = false; d.pose_stretch = 1.0; d.grid.reset(); d.gcoords_valid = false;
+      // (for a cloud made of parts gcoords_valid says "the parts' gs_filled flags can be trusted": the stretches of
+      // gsorted[] already written stay valid here -- those points did not move)
+      const bool keep_gs = d.gcoords_valid && !parts_after.empty() && !d.parts.empty();
+      d.forget_pose(); d.canonical = true; d.gcoords_valid = keep_gs;
     } else new_point_set(c, d);
+    if (!parts_after.empty()) d.parts.swap(parts_after);
     // normals survive only if both parts carry them
     const bool keep = s.has_normals && (d.has_normals || d.n == 0);
     if (keep) {
@@ -650,7 +695,7 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   c->slots[dst].n = n;
   const bool src_canon = c->slots[src].canonical;
   if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
-  else { c->slots[dst].canonical = false; c->slots[dst].pose_known = false; c->slots[dst].grid.reset(); }      // moved in place: no longer the upload coordinates
+  else c->slots[dst].forget_pose();      // moved in place: no longer the upload coordinates
   c->slots[dst].stale_coords();
   note_pose(c->slots[dst], c->slots[src], src_canon && dst != src, T);
   if (c->slots[src].has_normals && n) {
@@ -697,7 +742,7 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     c->slots[dst[k]].n = n[k];
     const bool src_canon = c->slots[src[k]].canonical;
     if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
-    else { c->slots[dst[k]].canonical = false; c->slots[dst[k]].pose_known = false; c->slots[dst[k]].grid.reset(); }
+    else c->slots[dst[k]].forget_pose();
     c->slots[dst[k]].stale_coords();
     if (c->pose_from_table && c->slots[dst[k]].pose_dev && dst[k] != src[k]) {
       // a pass enqueued ahead of its poses: the kernels read pose, inverse and stretch from the destination's device
@@ -752,7 +797,7 @@ API int mvr_cloud_transform_f32(mvr_ctx *ctx, int dst, int src, const float T[16
   if (int rc = launch_transform_f32(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
   c->slots[dst].n = n;
   if (dst != src) { inherit_point_set(c->slots[dst], c->slots[src]); c->slots[dst].segs = c->slots[src].segs; }
-  else { c->slots[dst].canonical = false; c->slots[dst].pose_known = false; c->slots[dst].grid.reset(); }
+  else c->slots[dst].forget_pose();
   c->slots[dst].stale_coords();
   if (c->slots[src].has_normals && n) {
     if (int rc = ensure(c, c->slots[dst].nrm, c->slots[dst].nrm_cap, n)) return rc;
@@ -1136,6 +1181,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     std::vector<Cloud *> used;
     for (int k = 0; k < n_pairs; ++k) { used.push_back(&c->slots[src[k]]); used.push_back(&c->slots[dst[k]]); }
     if (int rc = ensure_index_batch(c, used.data(), (int)used.size())) return rc;      // one refresh launch for all views
+    host_mark("  batch: indices");
     if (c->pair_fused && c->ring_search && c->fused_passes > 0 && max_dist * max_dist < (double)FLT_MAX) {
       // the grid search's side: every posed copy finds its set's grid (built once, from the cloud that holds the set's
       // canonical coordinates) and refreshes its coordinates in grid order -- one launch for all views.  Not in the
@@ -1157,6 +1203,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     }
   }
   if (c->nn_mode != 0 && c->pair_fused) {
+    host_mark("  batch: grid coordinates");
     ++c->fused_passes;
     // Optionally in G groups of pairs, group 0 on the caller's stream and the others on worker streams: a group's
     // glue kernels and the tail of its searches then overlap the other groups' searches.
@@ -1201,6 +1248,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
       c->cull_w = saved_w;
       if (status != MVR_OK) return status;
     }
+    host_mark("  batch: searches and sums enqueued");
     if (out) {
       std::vector<double> h((size_t)n_pairs * 32);
       MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1452,6 +1500,7 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
   };
   auto plain_pass = [&](bool more_follow) -> int {
     const double t0 = now_ms();
+    host_mark("pass: begin");
     if (more_follow) {
       if (!c->side_after && hipEventCreateWithFlags(&c->side_after, hipEventDisableTiming) != hipSuccess) c->side_after = nullptr;
       if (c->side_after) (void)hipEventRecord(c->side_after, c->stream);
@@ -1463,9 +1512,11 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
     const bool setup_first = c->comm != nullptr || c->inject_stall_at >= 0;
     if (more_follow && setup_first) { prebuild_grids(); if (pipe_possible()) (void)pipe_setup(c, V); }
     if (int rc = L.enqueue(L.self)) return rc;
-    if (more_follow && !setup_first) { prebuild_grids(); if (pipe_possible()) (void)pipe_setup(c, V); }
+    host_mark("pass: chain enqueued");
+    if (more_follow && !setup_first) { prebuild_grids(); host_mark("pass: grids enqueued on the side stream"); if (pipe_possible()) (void)pipe_setup(c, V); host_mark("pass: pipe set up"); }
     const double t1 = now_ms();
     if (int rc = stream_wait(c)) return rc;
+    host_mark("pass: drained");
     const double t2 = now_ms();
     const int rc = L.solve(L.self);
     sum[0] += t1 - t0; sum[1] += t2 - t1; sum[2] += now_ms() - t2;
@@ -1605,6 +1656,7 @@ struct RingRun {
     RingRun &r = *static_cast<RingRun *>(p);
     Ctx *c = CTX(r.ctx);
     if (int rc = mvr_cloud_transform_batch(r.ctx, r.n_views, r.posed_slots, r.raw_slots, r.poses)) return rc;
+    host_mark("  posed (orderings, sorted copies)");
     // the 32 doubles per edge go straight into pinned host memory (the final kernels write them over the bus: no copy
     // to enqueue, nothing to wait for but the stream itself)
     if (c->h_table_cap < (size_t)std::max(r.ne, 1) * 32) {
@@ -1771,6 +1823,183 @@ API int mvr_pair_moments2_from_corr(mvr_ctx *ctx, int ss, int ts, const int32_t 
   return MVR_OK;
 }
 
+// ---- mvr_icp_align against a target MADE OF POSED SCANS (the growing model of the sequential mode) --------------------
+// Everything the part-by-part search needs, or false when the align has to take the culled kernel: every part's scan and
+// the source's scan must be resident in canonical form (their grids are found or built here, batched), the target's
+// grid-ordered coordinates are written for the parts that do not have them yet, the current source gets the pose and the
+// grid of the posed source it is a copy of, and the part table goes to the device.
+// the current source of an align is an exact copy of a posed scan: give it that scan's pose, grid and grid-ordered
+// coordinates, so that the REVERSE searches (matched targets looking for their nearest source point, each with the bound
+// its forward match gives) can walk the source's grid instead of the culled kernel's box hierarchy
+static bool prepare_source_grid(Ctx *c, const Cloud &posed_src, Cloud &cur, double max_dist)
+{
+  if (!c->seq_search || c->nn_mode == 0 || !posed_src.pose_known || posed_src.fin_known || posed_src.n == 0 || posed_src.n != cur.n) return false;
+  if (!(max_dist * max_dist < (double)FLT_MAX)) return false;
+  Cloud *src_canon = nullptr;
+  for (Cloud &o : c->slots) if (o.set_id == posed_src.set_id && o.canonical && o.n == posed_src.n) { src_canon = &o; break; }
+  if (!src_canon) return false;
+  if (ensure_grids(c, &src_canon, 1, max_dist + 0.5, c->stream, nullptr) != MVR_OK || !src_canon->grid || src_canon->grid->n != src_canon->n) return false;
+  cur.pose_known = true; cur.pose_stretch = posed_src.pose_stretch; std::memcpy(cur.pose, posed_src.pose, sizeof cur.pose);
+  cur.grid = src_canon->grid; cur.gcoords_valid = false;
+  Cloud *one = &cur;
+  return refresh_grid_coords_batch(c, &one, 1) == MVR_OK && cur.gcoords_valid;
+}
+
+static bool prepare_parts_search(Ctx *c, const Cloud &posed_src, Cloud &cur, Cloud &tgt, double max_dist)
+{
+  if (c->seq_search < 2 || c->nn_mode == 0 || !posed_src.pose_known || posed_src.fin_known || posed_src.n == 0) return false;
+  if (!(max_dist * max_dist < (double)FLT_MAX)) return false;
+  if (tgt.parts.empty() && (tgt.pose_known || tgt.fin_known) && tgt.segs.empty() && tgt.n > 0) {
+    // a single posed scan (the model before its first append: view 0 under its pose) is a composite of one part
+    GridPart gp;
+    gp.set_id = tgt.set_id; gp.n = tgt.n; gp.base = 0; gp.kind = tgt.fin_known ? 2 : 1;
+    std::memcpy(gp.pose, tgt.pose, sizeof gp.pose); std::memcpy(gp.fin, tgt.fin, sizeof gp.fin);
+    gp.grid = nullptr; gp.gs_filled = false;
+    tgt.parts.push_back(gp);
+    tgt.gcoords_valid = false;              // (a posed scan's gsorted[] carries original indices without a base: same thing for base 0, but written by another kernel)
+  }
+  if (tgt.parts.empty()) return false;
+  size_t total = 0;
+  for (const GridPart &gp : tgt.parts) { if (gp.base != total || gp.n == 0 || (gp.kind != 1 && gp.kind != 2)) return false; total += gp.n; }
+  if (total != tgt.n || tgt.n > 0xFFFFFFF0ull) return false;
+  auto canon_of = [&](unsigned long long set_id, size_t n) -> Cloud * {
+    for (Cloud &o : c->slots) if (o.set_id == set_id && o.canonical && o.n == n) return &o;
+    return nullptr;
+  };
+  std::vector<Cloud *> canon;
+  for (const GridPart &gp : tgt.parts) { Cloud *o = canon_of(gp.set_id, gp.n); if (!o) return false; canon.push_back(o); }
+  Cloud *src_canon = canon_of(posed_src.set_id, posed_src.n);
+  if (!src_canon) return false;
+  canon.push_back(src_canon);
+  if (ensure_grids(c, canon.data(), (int)canon.size(), max_dist + 0.5, c->stream, nullptr) != MVR_OK) return false;
+  for (Cloud *o : canon) if (!o->grid || o->grid->n != o->n) return false;
+  // the target's coordinates in grid order, part after part
+  const float4 *before = tgt.gsorted;
+  if (ensure(c, tgt.gsorted, tgt.gsorted_cap, std::max(tgt.cap, tgt.n)) != MVR_OK) return false;
+  if (tgt.gsorted != before || !tgt.gcoords_valid) for (GridPart &gp : tgt.parts) gp.gs_filled = false;
+  for (size_t k = 0; k < tgt.parts.size(); ++k) {
+    GridPart &gp = tgt.parts[k];
+    gp.grid = canon[k]->grid;
+    if (gp.grid->ready && !gp.grid->ready_waited) { if (hipStreamWaitEvent(c->stream, gp.grid->ready, 0) != hipSuccess) return false; gp.grid->ready_waited = true; }
+    if (!gp.gs_filled && fill_part_coords(c, tgt, gp) != MVR_OK) return false;
+  }
+  tgt.gcoords_valid = true;
+  // the current source: an exact copy of the posed source, so its pose and its scan's grid
+  cur.pose_known = true; cur.pose_stretch = posed_src.pose_stretch; std::memcpy(cur.pose, posed_src.pose, sizeof cur.pose);
+  cur.grid = src_canon->grid; cur.gcoords_valid = false;
+  Cloud *one = &cur;
+  if (refresh_grid_coords_batch(c, &one, 1) != MVR_OK || !cur.gcoords_valid) return false;
+  // the part table
+  const size_t K = tgt.parts.size();
+  if (c->parts_cap < K) {
+    if (may_block(c, "not in steady state: the part table has to grow") != MVR_OK) return false;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_parts) (void)hipFree(c->d_parts);
+    if (c->h_parts) (void)hipHostFree(c->h_parts);
+    c->d_parts = nullptr; c->h_parts = nullptr; c->parts_cap = 0;
+    const size_t cap = std::max<size_t>(64, 2 * K);
+    if (hipMalloc(&c->d_parts, cap * sizeof(PartDesc)) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->h_parts), cap * sizeof(PartDesc)) != hipSuccess) return false;
+    c->parts_cap = cap;
+  }
+  for (size_t k = 0; k < K; ++k) {
+    const GridPart &gp = tgt.parts[k];
+    const CellGrid &g = *gp.grid;
+    PartDesc &d = c->h_parts[k];
+    d.gts = tgt.gsorted + gp.base; d.start = g.start; d.dt = g.dt;
+    for (int j = 0; j < 3; ++j) { d.lo[j] = g.lo[j]; d.dim[j] = g.dim[j]; }
+    d.inv_h = g.inv_h; d.h = g.h; d.dt_max = g.dt_steps; d.base = (uint32_t)gp.base; d.n = (uint32_t)gp.n;
+    // canonical -> posed: the f64 pose, then (kind 2) the align's f32 matrix
+    double M[16];
+    std::memcpy(M, gp.pose, sizeof M);
+    if (gp.kind == 2) { double F[16]; for (int j = 0; j < 16; ++j) F[j] = (double)gp.fin[j]; mvr_mat4d_mul(F, gp.pose, M); }
+    if (M[3] != 0.0 || M[7] != 0.0 || M[11] != 0.0 || M[15] != 1.0) return false;
+    double e2 = 0.0;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        const double dd = M[4 * a] * M[4 * b] + M[4 * a + 1] * M[4 * b + 1] + M[4 * a + 2] * M[4 * b + 2], x = dd - (a == b ? 1.0 : 0.0);
+        e2 += x * x;
+      }
+    const double e = std::sqrt(e2);
+    if (!(e <= 1e-3)) return false;                        // (note_pose's bar: beyond it a ball is no ball any more)
+    d.stretch = std::nextafterf((float)((1.0 / std::sqrt(1.0 - e)) * (1.0 + 1e-6)), INFINITY);
+    const double A[3][3] = {{M[0], M[4], M[8]}, {M[1], M[5], M[9]}, {M[2], M[6], M[10]}};
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    const double id = 1.0 / det;
+    const double I[3][3] = {{(A[1][1] * A[2][2] - A[1][2] * A[2][1]) * id, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id},
+                            {(A[1][2] * A[2][0] - A[1][0] * A[2][2]) * id, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id},
+                            {(A[1][0] * A[2][1] - A[1][1] * A[2][0]) * id, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id}};
+    for (int r = 0; r < 3; ++r) {
+      for (int j = 0; j < 3; ++j) d.minv[4 * r + j] = I[r][j];
+      d.minv[4 * r + 3] = -(I[r][0] * M[12] + I[r][1] * M[13] + I[r][2] * M[14]);
+    }
+  }
+  if (hipMemcpyAsync(c->d_parts, c->h_parts, K * sizeof(PartDesc), hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
+  return true;
+}
+
+// the search of one iteration through the parts: forward = nn_parts_kernel (+ the culled kernel for the queries it
+// flags), reverse = the grid walk over the CURRENT SOURCE's grid for the matched targets, compacted by the kernels of
+// the fused pass (no hipCUB).  Leaves keys / slot / rkeys as run_search does.
+static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, bool reciprocal, bool fma, SearchPlan *plan, bool parts_forward)
+{
+  const size_t ns = cur.n, nt = tgt.n;
+  const double max2 = max_dist * max_dist;
+  const float cap2 = cap_from_max2(max2);
+  *plan = SearchPlan();
+  if (int rc = ensure(c, c->keys, c->keys_cap, ns)) return rc;
+  if (int rc = ensure(c, c->match, c->match_cap, ns)) return rc;
+  if (int rc = ensure(c, c->rkeys, c->rkeys_cap, std::max(ns, std::min(ns, nt)))) return rc;
+  if (int rc = ensure(c, c->bheavy, c->bheavy_cap, ns)) return rc;
+  if (int rc = ensure_index(c, cur)) return rc;
+  if (int rc = ensure_index(c, tgt)) return rc;
+  plan->qperm = cur.order->perm; plan->tinv = tgt.order->inv;
+  if (!parts_forward) {
+    // forward: the culled kernel over the target's composite index (keys are written by exactly one wave per query)
+    if (int rc = launch_nn_cull(c, cur, 0, ns, nullptr, tgt, cap2, fma, c->keys)) return rc;
+  } else {
+  if (int rc = launch_nn_parts(c, cur, (int)tgt.parts.size(), cap2, fma, c->keys, c->bheavy)) return rc;
+  if (c->grid_debug) {           // diagnostics: how many queries the parts could not answer
+    std::vector<uint8_t> hv(ns);
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MVR_HIP_TRY(c, hipMemcpy(hv.data(), c->bheavy, ns, hipMemcpyDeviceToHost));
+    size_t f = 0, sets = 0;
+    for (size_t i = 0; i < ns; i += 64) { size_t g = 0; for (size_t j = i; j < std::min(ns, i + 64); ++j) g += hv[j]; f += g; sets += g != 0; }
+    std::fprintf(stderr, "[parts] %zu parts, %zu queries: %zu left to the culled kernel in %zu of %zu sets\n", tgt.parts.size(), ns, f, sets, (ns + 63) / 64);
+  }
+  {   // the flagged queries: the culled kernel over the composite index, keys by SORTED position into rkeys[], then merged
+    CullPair p = make_cull_pair(cur, 0, ns, c->bheavy, tgt, c->rkeys);
+    if (int rc = launch_nn_cull_batch(c, &p, 1, cap2, fma)) return rc;
+    if (int rc = launch_merge_flagged_keys(c, cur.sorted, c->bheavy, c->rkeys, ns, c->keys)) return rc;
+  }
+  }
+  if (!reciprocal || nt == 0) return MVR_OK;
+  // reverse: the distinct matched targets, each starting from the distance of the source that matched it
+  if (int rc = ensure(c, c->bound, c->bound_cap, nt)) return rc;
+  if (int rc = launch_seed_bounds(c, c->keys, plan->qperm, 0, ns, max2, plan->tinv, nt, c->bound)) return rc;
+  const size_t nl = std::min(ns, nt), chunks = (nt + 255) / 256;
+  if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
+  if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
+  if (int rc = ensure(c, c->bchunks, c->bchunks_cap, chunks + 8)) return rc;
+  if (int rc = ensure(c, c->bwide, c->bwide_cap, nl)) return rc;
+  if (!c->bwide_count) {
+    MVR_MAY_BLOCK(c, "the wide-query counters are not allocated yet");
+    MVR_HIP_TRY(c, hipMalloc(&c->bwide_count, 3 * kWideCounters * sizeof(uint32_t)));
+    MVR_HIP_TRY(c, hipMemsetAsync(c->bwide_count, 0, 3 * kWideCounters * sizeof(uint32_t), c->stream));
+  }
+  GlueBatch gb;
+  gb.max2 = max2; gb.reciprocal = 1; gb.origin[0] = gb.origin[1] = gb.origin[2] = 0.0;
+  GluePair &g = gb.p[0];
+  g.bound = c->bound; g.list = c->list; g.slot = c->slot; g.chunks = c->bchunks; g.qcount = c->count; g.nt = nt;
+  if (int rc = launch_compact_flags_batch(c, gb, 1)) return rc;
+  plan->slot = c->slot; plan->count = c->count;
+  GridPair rev = make_grid_pair(tgt, 0, nl, cur, c->rkeys);
+  rev.qlist = c->list; rev.qcount = c->count; rev.qbound = c->bound;
+  rev.wide_list = c->bwide; rev.wide_count = c->bwide_count + kWideCounters - 1;      // (a counter the fused pass does not use)
+  MVR_HIP_TRY(c, hipMemsetAsync(rev.wide_count, 0, sizeof(uint32_t), c->stream));
+  if (int rc = launch_nn_grid_batch(c, &rev, 1, cap2, fma)) return rc;
+  return launch_nn_grid_wide_batch(c, &rev, 1, cap2, fma);
+}
+
 // pcl::registration::DefaultConvergenceCriteria::hasConverged, evaluated after every iteration on the
 // INCREMENTAL transformation and the mean squared correspondence distance of that iteration
 namespace {
@@ -1820,20 +2049,29 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   double cur_mse = 0.0, evals = 0.0, fwdq = 0.0;
   int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
   Cloud &tgt = c->slots[ts];
+  // a target made of posed scans (the sequential mode's model) is searched through the scans' grids -- in the first
+  // iteration, while the current source still IS the posed source (later iterations, which the reference's settings never
+  // reach, take the culled kernel: the moved source's coordinates are no longer a known pose of its scan)
+  // (seq_search 2: forward through the parts as well; measured on the 12 x 200k sweep it does NOT pay -- DESIGN.md 4.5 -- so
+  // the default, 1, keeps the culled kernel for the forward search and takes the grid for the reverse one)
+  const bool parts_ok = ns > 0 && tgt.n > 0 && ts != ss && prepare_parts_search(c, c->slots[ss], cur, tgt, p->max_corr_dist);
+  const bool rev_grid_ok = parts_ok || (ns > 0 && tgt.n > 0 && ts != ss && p->use_reciprocal && tgt.n <= 0xFFFFFFF0ull &&
+                                        prepare_source_grid(c, c->slots[ss], cur, p->max_corr_dist));
   do {
     double ev = 0.0;
     SearchPlan plan;
+    if (rev_grid_ok && iters == 0) { if (int rc = run_search_parts(c, cur, tgt, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &plan, parts_ok)) return rc; }
+    else
     if (int rc = run_search(c, cur, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev, &plan)) return rc;
     if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, plan.slot, plan.count, plan.qperm, plan.tinv, 0, ns,
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
-    if (p->point_to_plane) {
-      if (int rc = launch_p2plane(c, cur.pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc;
-      if (int rc = read_moments(c, 64)) return rc;
-    } else {
-      if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
-      if (int rc = read_moments(c, 18)) return rc;
-    }
+    if (p->point_to_plane) { if (int rc = launch_p2plane(c, cur.pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc; }
+    else if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
+    // the search kernels' running evaluation totals ride along with the moments (the statistic needs no wait of its own)
+    if (st && c->nn_mode != 0)
+      MVR_HIP_TRY(c, hipMemcpyAsync(c->h_evals, c->evals + kEvalRegion, kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = read_moments(c, p->point_to_plane ? 64 : 18)) return rc;
     const double *h = c->h_moments;
     fwdq += (double)ns;
     evals += (c->nn_mode != 0) ? 0.0 : ev + h[17] * (double)ns;   // forward Ns*Nt + reverse Nt'*Ns (brute force)
@@ -1845,23 +2083,34 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
       umeyama_from_moments(h + 1, h + 4, h + 8, tr, nullptr);
     }
     cur_mse = h[7];
-    if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
-    cur.stale_coords();
     mvr_mat4f_mul(tr, fin, fin);
     ++iters;
     converged = crit.converged(tr, cur_mse, iters, &state) ? 1 : 0;
+    if (!converged) {          // (the moved source is only needed by another iteration: the output is final * the ORIGINAL input)
+      if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
+      cur.stale_coords();
+      cur.pose_known = false; cur.grid.reset();
+    }
   } while (!converged);
   // output = final * (*input), from the ORIGINAL input: alias-safe (registrator.cpp:920)
   if (os >= 0) {
     if (os != ss) { c->slots[os].n = 0; if (int rc = cloud_reserve(c, c->slots[os], ns, false)) return rc; }
     if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
     c->slots[os].n = ns;
-    if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
-    else {
+    if (os != ss) {
+      inherit_point_set(c->slots[os], c->slots[ss]);
+      // the output is the f32 matrix `fin` applied to a cloud with a known f64 pose: a posed copy still, by known arithmetic
+      // (what the sequential mode appends to its model, registrator.cpp:576 -- see GridPart)
+      const Cloud &in = c->slots[ss];
+      if (in.pose_known && !in.fin_known) {
+        Cloud &o = c->slots[os];
+        o.fin_known = true; std::memcpy(o.fin, fin, sizeof fin); std::memcpy(o.pose, in.pose, sizeof o.pose); o.pose_stretch = in.pose_stretch; o.grid = in.grid;
+      }
+    } else {
       // the aliased align(*source_) of registrator.cpp:920: the slot's points moved in place by a FLOAT matrix -- they are
       // neither the set's upload coordinates nor a known f64 pose of them any more, and a grid built in the old frame
       // must not be walked with them (the other in-place paths: mvr_cloud_transform, _f32, _batch)
-      c->slots[os].canonical = false; c->slots[os].pose_known = false; c->slots[os].pose_stretch = 1.0; c->slots[os].grid.reset();
+      c->slots[os].forget_pose();
     }
     c->slots[os].stale_coords();
     if (c->slots[ss].has_normals && ns) {      // ICP::transformCloud rotates the source normals too
@@ -1872,11 +2121,8 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   }
   std::memcpy(T_out, fin, sizeof fin);
   if (st && c->nn_mode != 0) {
-    std::vector<uint64_t> h(kEvalRegion);
-    MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), c->evals + kEvalRegion, kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
     evals = 0.0;
-    for (int k = 0; k < kEvalShards; ++k) evals += (double)h[(size_t)k * kEvalStride];
+    for (int k = 0; k < kEvalShards; ++k) evals += (double)c->h_evals[(size_t)k * kEvalStride];
   }
   if (st) {
     st->iterations = iters; st->converged = converged; st->state = state; st->n_corr = ncorr; st->mse = cur_mse;
@@ -1965,7 +2211,7 @@ API int mvr_seq_align_sharded(mvr_ctx *ctx, int ss, int ts, int os, const mvr_ic
     if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;
     c->slots[os].n = ns;
     if (os != ss) inherit_point_set(c->slots[os], c->slots[ss]);
-    else { c->slots[os].canonical = false; c->slots[os].pose_known = false; c->slots[os].pose_stretch = 1.0; c->slots[os].grid.reset(); }
+    else c->slots[os].forget_pose();
     c->slots[os].stale_coords();
     c->slots[os].has_normals = false;
   }
@@ -2080,6 +2326,9 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "seed_forward")) c->seed_forward = value != 0;
   else if (!std::strcmp(key, "fused_mark")) { if (value < 0 || value > 2) return MVR_E_ARG; c->fused_mark = value; }
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
+  else if (!std::strcmp(key, "seq_search")) { if (value < 0 || value > 2) return MVR_E_ARG; c->seq_search = value; }
+  else if (!std::strcmp(key, "parts_lanes")) { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->parts_lanes = value; }
+  else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
   else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;
   else if (!std::strcmp(key, "grid_debug")) c->grid_debug = value != 0;

@@ -534,6 +534,7 @@ int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream
   hipLaunchKernelGGL(bbox_many_partial_kernel, dim3(kBoxBlocks, (unsigned)m), dim3(256), 0, on, d_pts, d_n, d_part);
   MVR_HIP_TRY(c, hipMemcpyAsync(h_part.data(), d_part, h_part.size() * sizeof(float), hipMemcpyDeviceToHost, on));
   MVR_HIP_TRY(c, hipStreamSynchronize(on));
+  host_mark("    grids: bounding boxes back");
   // ---- geometry and one allocation per grid
   std::vector<std::shared_ptr<CellGrid> > gs((size_t)m);
   for (int k = 0; k < m; ++k) {
@@ -573,6 +574,7 @@ int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream
     g->dt_steps = std::min(kGridDtMax, std::max(2, steps));
     gs[(size_t)k] = g;
   }
+  host_mark("    grids: allocated");
   // ---- temporaries: cell ids (two buffers for the sort), indices, the distance map's second buffer, hipCUB's scratch
   (void)cells_max;
   uint32_t *cid_a = reinterpret_cast<uint32_t *>(c->scratch + o_cid_a), *cid_b = reinterpret_cast<uint32_t *>(c->scratch + o_cid_b),
@@ -612,6 +614,7 @@ int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream
     c->grids[cl.set_id] = gs[(size_t)k];
   }
   for (auto i2 = c->grids.begin(); i2 != c->grids.end();) i2 = i2->second.expired() ? c->grids.erase(i2) : std::next(i2);
+  host_mark("    grids: builds enqueued");
   if (!c->scratch_event) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->scratch_event, hipEventDisableTiming));
   MVR_HIP_TRY(c, hipEventRecord(c->scratch_event, on));
   c->scratch_stream = on;
@@ -923,6 +926,243 @@ int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     else hipLaunchKernelGGL((nn_grid_tail_kernel<false>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals, wide_blocks);
     MVR_HIP_TRY(c, hipGetLastError());
   }
+  return MVR_OK;
+}
+
+// ---- a COMPOSITE target, searched part by part: the growing model of the sequential mode (registrator.cpp:563-577) is a
+// concatenation of posed scans that never move once appended; each keeps its raw scan's pose-invariant grid (GridPart).
+// One thread per source query walks the parts one after the other with a RUNNING bound: the first part that has points
+// next to the query gives a bound a few tenths of a millimetre wide (a probe of the 27 cells around the query), and every
+// later part is either ruled out by one byte of its distance map or walked over a handful of cells.  The reference's
+// kd-tree over the whole merged cloud (rebuilt at every align, registrator.cpp:569) becomes K small address computations.
+// Candidates are evaluated on the posed coordinates with the float formula of every other search; the minimum is over
+// (d2, COMPOSITE original index), so the result equals a search of the merged cloud bit for bit.  A query whose ball
+// cannot be bounded here (no point next to it in any part, yet possibly one within the cap) is flagged for the culled
+// kernel, which searches the composite index for it.
+namespace {
+
+// G lanes share a query: lane `sub` takes parts sub, sub + G, ...  (One lane per query is a chain of some forty dependent
+// loads at 200k queries -- 3 waves per SIMD, nothing to hide the latency behind: 442 us at ten parts.)  Two phases:
+//   A  every lane looks at its parts' distance-map byte; the first of its parts that has points NEXT to the query (d <= 1)
+//      is probed -- the 27 cells around the query -- and the group's best find becomes the bound of ALL its lanes;
+//   B  every lane walks the ball of that bound in each of its parts that the distance map does not rule out.
+// A query without any part next to it has no bound: if some part may still hold a point within the cap it is flagged for
+// the culled kernel (the rim of the coverage: few, and clustered), else it has no neighbour.
+template <bool FMA, int G>
+__global__ void __launch_bounds__(256) nn_parts_kernel(const float4 *__restrict__ qs, uint32_t nq, const PartDesc *__restrict__ parts, int n_parts,
+                                                       float cap2, int max_rows, nnkey_t *__restrict__ keys, uint8_t *__restrict__ heavy,
+                                                       unsigned long long *__restrict__ evals)
+{
+  const uint32_t pos = (blockIdx.x * 256u + threadIdx.x) / G;
+  const int sub = (int)(threadIdx.x % G);
+  unsigned long long n_eval = 0;
+  const bool live = pos < nq;
+  const float4 q = live ? qs[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const double qx = q.x, qy = q.y, qz = q.z;
+  const float qn1 = fabsf(q.x) + fabsf(q.y) + fabsf(q.z);
+  float bd = cap2;                   // nothing beyond it is wanted; AT it, it is (inclusive)
+  uint32_t bi = kNone;
+  bool in_reach = false, too_wide = false;
+  auto map_into = [&](const PartDesc &a, float &rx, float &ry, float &rz, float &slack) {
+    rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
+    ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
+    rz = (float)(((a.minv[8] * qx + a.minv[9] * qy) + a.minv[10] * qz) + a.minv[11]);
+    slack = 2.0e-6f * (fabsf(rx) + fabsf(ry) + fabsf(rz));            // (see grid_ball)
+  };
+  auto walk = [&](const PartDesc &a, int x0, int x1, int y0, int y1, int z0, int z1) {
+    // rows of cells in y-major order; the next row's range is requested while this row's points are evaluated
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    uint32_t row = (uint32_t)((z0 * a.dim[1] + y0) * a.dim[0]);
+    const uint32_t row_step = (uint32_t)a.dim[0], z_step = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
+    uint32_t s = a.start[row + (uint32_t)x0], e = a.start[row + (uint32_t)x1 + 1u];
+    int yy = 0;
+    for (int it = 0; it < nrows; ++it) {
+        uint32_t s2 = 0, e2 = 0;
+        if (it + 1 < nrows) {
+          row += row_step;
+          if (++yy == ny) { yy = 0; row += z_step; }
+          s2 = a.start[row + (uint32_t)x0]; e2 = a.start[row + (uint32_t)x1 + 1u];
+        }
+        n_eval += e - s;
+        for (uint32_t i = s; i < e; i += 4) {
+          const uint32_t last = e - 1u;
+          const uint32_t i1 = min(i + 1u, last), i2 = min(i + 2u, last), i3 = min(i + 3u, last);
+          const float4 t0 = a.gts[i], t1 = a.gts[i1], t2 = a.gts[i2], t3 = a.gts[i3];
+          const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
+          const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
+          const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
+          if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; }
+          if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; }
+          if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; }
+          if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; }
+        }
+        s = s2; e = e2;
+    }
+  };
+  auto share = [&]() {             // the group's smallest (d2, index)
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+      const float od = __shfl_xor(bd, o, 64);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o, 64);
+      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+  };
+  // ---- A: a bound.  Every lane reads its parts' distance-map bytes; ONE part of the group that has points next to the
+  // query (d = 0 before d = 1) is probed -- the 27 cells around the query -- by the lane that owns it; should that probe
+  // find nothing within the cap, the next candidate is tried.
+  uint32_t cand_mask = 0;            // bit j: this lane's j-th part (k = sub + j G) has d <= 1; bit 16 + j: d == 0
+  if (live) {
+    int j = 0;
+    for (int k = sub; k < n_parts; k += G, ++j) {
+      const PartDesc &a = parts[k];
+      float rx, ry, rz, slack;
+      map_into(a, rx, ry, rz, slack);
+      const float rad = (sqrtf(cap2) * 1.00001f + (1.0e-3f + 4.0e-6f * qn1)) * a.stretch + slack;
+      const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
+      const uint32_t d = a.dt[((size_t)cz * a.dim[1] + cy) * a.dim[0] + cx];
+      // the query's (clamped) cell is d cells from the nearest occupied one: every point of this part is at least
+      // (d - 1) cell edges away along some axis
+      if ((d == 255u ? (float)a.dt_max : (float)d - 1.f) * a.h > rad) continue;
+      in_reach = true;                                   // this part may hold a point within the cap
+      if (d <= 1u && j < 16) cand_mask |= (1u << j) | (d == 0u ? (1u << (16 + j)) : 0u);
+    }
+  }
+  for (int round = 0; round < 2 * 16 * G; ++round) {       // (ends as soon as a probe succeeds or the candidates run out)
+    // the group's next candidate: the occupied-cell ones first, lowest lane, lowest part
+    const uint32_t mine = (cand_mask >> 16) ? 2u : (cand_mask & 0xFFFFu) ? 1u : 0u;
+    uint32_t best_rank = mine, owner = (uint32_t)sub;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+      const uint32_t orank = (uint32_t)__shfl_xor((int)best_rank, o, 64), oown = (uint32_t)__shfl_xor((int)owner, o, 64);
+      if (orank > best_rank || (orank == best_rank && oown < owner)) { best_rank = orank; owner = oown; }
+    }
+    if (best_rank == 0u) break;                            // (uniform over the group)
+    if ((uint32_t)sub == owner) {
+      const uint32_t pick = (cand_mask >> 16) ? (cand_mask >> 16) : (cand_mask & 0xFFFFu);
+      const int j = __ffs((int)pick) - 1;
+      cand_mask &= ~((1u << j) | (1u << (16 + j)));
+      const PartDesc &a = parts[sub + j * G];
+      float rx, ry, rz, slack;
+      map_into(a, rx, ry, rz, slack);
+      const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
+      walk(a, max(cx - 1, 0), min(cx + 1, a.dim[0] - 1), max(cy - 1, 0), min(cy + 1, a.dim[1] - 1), max(cz - 1, 0), min(cz + 1, a.dim[2] - 1));
+    }
+    share();
+    if (bi != kNone) break;                                // (uniform: shared)
+  }
+  const bool have = bi != kNone;     // (uniform over the group)
+  // ---- B: the exact ball of the bound, in every part that can reach into it
+  if (live && have) {
+    for (int k = sub; k < n_parts; k += G) {
+      const PartDesc &a = parts[k];
+      float rx, ry, rz, slack;
+      map_into(a, rx, ry, rz, slack);
+      const float rad = (sqrtf(bd) * 1.00001f + (1.0e-3f + 4.0e-6f * qn1)) * a.stretch + slack;
+      const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
+      const uint32_t d = a.dt[((size_t)cz * a.dim[1] + cy) * a.dim[0] + cx];
+      if ((d == 255u ? (float)a.dt_max : (float)d - 1.f) * a.h > rad) continue;
+      const int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+      const int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+      const int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+      if ((y1 - y0 + 1) * (z1 - z0 + 1) > max_rows) { too_wide = true; continue; }
+      walk(a, x0, x1, y0, y1, z0, z1);
+    }
+    share();
+  }
+  // a lane's verdict on its own parts -> the group's
+  unsigned flag = (too_wide || (!have && in_reach)) ? 1u : 0u;
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) flag |= (unsigned)__shfl_xor((int)flag, o, 64);
+  if (live && sub == 0) {
+    const bool found = bi != kNone && bd <= cap2;
+    keys[__float_as_uint(q.w)] = found ? (((nnkey_t)__float_as_uint(bd) << 32) | bi) : kKeyInit;
+    heavy[pos] = flag ? 1 : 0;
+  }
+  if (evals) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o, 64);
+    if ((threadIdx.x & 63) == 0 && n_eval) {
+      unsigned long long *sh = evals + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kEvalShards - 1)) * kEvalStride;
+      atomicAdd(sh, n_eval);
+      atomicAdd(sh + kEvalRegion, n_eval);
+    }
+  }
+}
+
+// a part's coordinates in its grid's order, by the arithmetic that made its points: f32(pose * canonical) as
+// transform_f64_kernel, then (kind 2) the f32 matrix as transform_f32_kernel -- the same operations on the same inputs, so
+// out[k].xyz == pts[base + gperm[k]].xyz bit for bit; w = bits(base + original index)
+struct Mat34fp { float m[12]; };
+__global__ void parts_coords_kernel(const float4 *__restrict__ graw, float4 *__restrict__ out, size_t n, Mat44d T, Mat34fp F, int kind, uint32_t base)
+{
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float4 p = graw[k];
+  float4 v = pose_point_f64(T, p);
+  if (kind == 2) {
+    float4 o;
+    o.x = ((F.m[0] * v.x + F.m[1] * v.y) + F.m[2] * v.z) + F.m[3];
+    o.y = ((F.m[4] * v.x + F.m[5] * v.y) + F.m[6] * v.z) + F.m[7];
+    o.z = ((F.m[8] * v.x + F.m[9] * v.y) + F.m[10] * v.z) + F.m[11];
+    v = o;
+  }
+  v.w = __uint_as_float(base + __float_as_uint(p.w));
+  out[k] = v;
+}
+
+}  // namespace
+
+namespace {
+__global__ void merge_flagged_keys_kernel(const float4 *__restrict__ sorted, const uint8_t *__restrict__ flags, const nnkey_t *__restrict__ by_pos, size_t n,
+                                          nnkey_t *__restrict__ keys)
+{
+  const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos < n && flags[pos]) keys[__float_as_uint(sorted[pos].w)] = by_pos[pos];
+}
+}  // namespace
+
+int launch_merge_flagged_keys(Ctx *c, const float4 *sorted, const uint8_t *flags, const nnkey_t *by_pos, size_t n, nnkey_t *keys)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(merge_flagged_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sorted, flags, by_pos, n, keys);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int fill_part_coords(Ctx *c, Cloud &target, GridPart &part)
+{
+  if (!part.grid || part.grid->n != part.n || !target.gsorted || part.base + part.n > target.gsorted_cap) return set_error(c, MVR_E_ARG, "fill_part_coords");
+  Mat44d T; Mat34fp F;
+  std::memcpy(T.m, part.pose, sizeof T.m);
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) F.m[4 * r + k] = part.fin[r + 4 * k];
+  ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)part.n);
+  hipLaunchKernelGGL(parts_coords_kernel, dim3((unsigned)((part.n + 255) / 256)), dim3(256), 0, c->stream, part.grid->graw, target.gsorted + part.base, part.n, T, F,
+                     part.kind, (uint32_t)part.base);
+  MVR_HIP_TRY(c, hipGetLastError());
+  part.gs_filled = true;
+  return MVR_OK;
+}
+
+int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnkey_t *keys, uint8_t *heavy)
+{
+  if (q.n == 0 || count <= 0) return MVR_OK;
+  const bool per_launch = c->prof && !c->prof_totals;
+  if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
+  ProfScope ps(c, MVR_K_NN_GRID, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
+  // lanes per query (they share out the parts): as many as there are parts, up to eight
+  int lanes = count <= 1 ? 1 : count <= 2 ? 2 : count <= 4 ? 4 : 8;
+  if (c->parts_lanes == 1 || c->parts_lanes == 2 || c->parts_lanes == 4 || c->parts_lanes == 8) lanes = c->parts_lanes;
+  const unsigned blocks = (unsigned)((q.n * (size_t)lanes + 255) / 256);
+  const int max_rows = c->parts_max_rows;      // a ball that still spans more rows of cells than this goes to the culled kernel
+#define MVR_PARTS_LAUNCH(F, GG) hipLaunchKernelGGL((nn_parts_kernel<F, GG>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q.n, c->d_parts, count, cap2, max_rows, keys, heavy, c->evals)
+  switch (lanes) {
+    case 1: if (fma) MVR_PARTS_LAUNCH(true, 1); else MVR_PARTS_LAUNCH(false, 1); break;
+    case 2: if (fma) MVR_PARTS_LAUNCH(true, 2); else MVR_PARTS_LAUNCH(false, 2); break;
+    case 4: if (fma) MVR_PARTS_LAUNCH(true, 4); else MVR_PARTS_LAUNCH(false, 4); break;
+    default: if (fma) MVR_PARTS_LAUNCH(true, 8); else MVR_PARTS_LAUNCH(false, 8); break;
+  }
+#undef MVR_PARTS_LAUNCH
+  MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
 

@@ -85,6 +85,19 @@ struct PoseRec {
   float stretch, pad_;      // bound of how much the inverse lengthens a distance (1 for a rigid pose)
 };
 
+// One merged scan inside a cloud that is a CONCATENATION of posed copies of scans -- the growing target of the sequential
+// mode (`*target += transformed_source`, registrator.cpp:576).  Its points never move once appended, so the raw scan's
+// pose-invariant cell grid serves it: the part records which point set it is a copy of and by which arithmetic its
+// coordinates were made (kind 1: p = f32(pose * canonical) as mvr_cloud_transform; kind 2: that, then the f32 matrix of an
+// align's result as mvr_icp_align's output) -- enough to write its coordinates in GRID order bit for bit and to map a
+// query into the scan's canonical frame.
+struct GridPart {
+  unsigned long long set_id = 0; size_t n = 0, base = 0; int kind = 0;
+  double pose[16]; float fin[16];
+  std::shared_ptr<CellGrid> grid;      // found (or built) when the part is first searched
+  bool gs_filled = false;              // its stretch of the cloud's gsorted[] is written
+};
+
 struct Cloud {
   float4 *pts = nullptr;
   size_t n = 0;
@@ -114,6 +127,11 @@ struct Cloud {
   // find this posed copy's pose, inverse and stretch (device memory, filled by pose_prep_kernel once the host's solve has
   // released the pass); null outside such a run
   const struct PoseRec *pose_dev = nullptr;
+  // ... or a known f64 pose FOLLOWED by a known f32 matrix (the output cloud of an align whose source had a known pose):
+  // pts = xform_f32(fin, f32(pose * canonical)); the sequential mode's merged scans are made this way
+  bool fin_known = false; float fin[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::vector<GridPart> parts;         // non-empty: this cloud is exactly the concatenation of these posed scans (see GridPart)
+  void forget_pose() { canonical = false; pose_known = false; fin_known = false; pose_stretch = 1.0; grid.reset(); parts.clear(); }
   bool posed_by_table = false;         // ... and the last transform of this cloud did read it (its host-side pose is filled in when the run leaves the pipe)
 };
 
@@ -162,6 +180,8 @@ struct Ctx {
   std::map<uint64_t, std::weak_ptr<Order> > orders;   // set_id -> ordering (shared between posed copies)
   std::map<uint64_t, std::weak_ptr<CellGrid> > grids;     // set_id -> uniform grid (shared between posed copies)
   int grid_light_rows = 12;                           // grid search (default = kGridLightRows): rows of cells a thread walks itself; wider balls leave for a wave of their own or for the culled kernel
+  int seq_search = 1;                                 // mvr_icp_align of a posed scan: 1 (default) = the REVERSE searches walk the source scan's cell grid (compaction by the fused pass's kernels, no hipCUB), the forward search stays with the culled kernel; 2 = the forward search too, through the grids of the posed scans the target is made of (nn_parts_kernel: exact, measured slower -- DESIGN.md 4.5); 0 = the culled kernel for both
+  int parts_lanes = 0, parts_max_rows = 25;           // nn_parts_kernel: lanes per query (1, 2, 4, 8; 0 = by the number of parts) and the widest ball (rows of cells) a lane walks itself
   int ring_search = 1;                                // fused pass: 1 = seeded searches walk the uniform grid (thread per query), 0 = always the culled kernel
   std::shared_ptr<OrderPool> order_pool = std::make_shared<OrderPool>();
   // per-pair work buffers (grown on demand)
@@ -180,6 +200,7 @@ struct Ctx {
   // index-build scratch
   uint32_t *codes_a = nullptr, *codes_b = nullptr, *idx_a = nullptr; size_t sort_cap = 0;
   void *cub_tmp = nullptr; size_t cub_cap = 0;
+  struct PartDesc *d_parts = nullptr, *h_parts = nullptr; size_t parts_cap = 0;      // the part table of a composite target: device copy and pinned staging
   char *scratch = nullptr; size_t scratch_cap = 0;    // temporaries of the grid builds (grows, never shrinks)
   hipStream_t side_stream = nullptr;                  // set-up work that may overlap a pass (grid builds)
   hipEvent_t side_after = nullptr;                    // recorded on the main stream before the pass the side stream's work overlaps
@@ -265,6 +286,7 @@ struct Ctx {
   std::vector<hipEvent_t> event_pool;                 // timing events are recycled, not re-created per launch
   std::vector<ProfRec> recs;
   uint64_t *h_counts = nullptr;                       // pinned: device counters copied per profiled launch
+  uint64_t *h_evals = nullptr;                        // pinned [kEvalRegion]: the culled / grid kernels' running totals, copied with every iteration's moments (mvr_icp_align's `evals` statistic without a wait of its own)
   size_t h_counts_used = 0;
   uint64_t prof_launches[MVR_K_COUNT] = {0};
   double prof_ms[MVR_K_COUNT] = {0};
@@ -275,6 +297,8 @@ constexpr int kScratchCur = MVR_MAX_SLOTS;       // ICP's input_transformed
 constexpr int kScratchTmp = MVR_MAX_SLOTS + 1;   // fitness temporary
 
 int set_error(Ctx *c, int status, const char *what, hipError_t e = hipSuccess);
+// host-side stopwatch for the set-up phases (MVR_TRACE_HOST=1): prints the milliseconds since the previous mark to stderr
+void host_mark(const char *what);
 
 #define MVR_HIP_TRY(ctx, expr)                                               \
   do {                                                                       \
@@ -485,6 +509,20 @@ int comm_poll(Ctx *c);                        // RCCL's asynchronous error state
 int comm_abort(Ctx *c, const char *why);      // ncclCommAbort + release of anything that could hold the stream; returns MVR_E_RCCL
 int stream_wait(Ctx *c);                      // hipStreamSynchronize; with a communicator: bounded by wait_timeout_ms and watching comm_poll, a timeout aborts
 GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cloud &t, nnkey_t *keys);
+// ---- a composite target searched part by part (mvr_grid.hip: nn_parts_kernel)
+struct PartDesc {
+  const float4 *gts; const uint32_t *start; const uint8_t *dt;
+  float lo[3], inv_h, h, stretch; int dim[3], dt_max;
+  double minv[12];
+  uint32_t base, n;
+};
+// forward search of the queries q.sorted[0, nq) in the `count` parts described at c->d_parts: keys[original query index] =
+// (d2 bits, COMPOSITE original target index), kKeyInit = nothing within cap2; heavy[sorted position] = 1 for the queries
+// that were NOT answered here (an unbounded ball too wide to walk): the culled kernel takes those
+int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnkey_t *keys, uint8_t *heavy);
+int fill_part_coords(Ctx *c, Cloud &target, GridPart &part);
+// keys[original index of sorted[pos]] = by_pos[pos] for the flagged positions (the culled kernel answers flagged queries by sorted position)
+int launch_merge_flagged_keys(Ctx *c, const float4 *sorted, const uint8_t *flags, const nnkey_t *by_pos, size_t n, nnkey_t *keys);      // target.gsorted[part.base ...] <- the part's coordinates in its grid's order
 int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, float cap2,
                    bool fma, nnkey_t *keys);
 // one scan pair of a batched global pass (mvr_pair_moments2_batch, culled mode): everything the glue and the

@@ -5,7 +5,7 @@
 //
 // usage: shim_driver <mode> <views> <points> <max_dist> <repeat> <config_id>
 //   mode: seq | lum | auto | err | api          the PCL-named call surface, in the reference's order of calls (call_surface.hpp)
-//         seqdev | lumdev | errdev | register      the product's device-resident drivers (mvr/registrator.hpp)
+//         seqdev | lumdev | autodev | errdev | register   the product's device-resident drivers (mvr/registrator.hpp)
 //         world                                    the single-process multi-GPU host (mvr_world_*), here with one GPU
 //         denoise
 #include <cstdio>
@@ -74,6 +74,8 @@ int main(int argc, char **argv)
       std::printf("],");
     } else if (mode == "seqdev") {
       reg.registrationICPDevice(1000, max_d, 0, repeat);
+    } else if (mode == "autodev") {
+      reg.automaticRegistrationDevice(0, 1000, repeat, max_d, 50.0, true);
     } else if (mode == "errdev") {
       auto pairs = reg.computeErrorDevice(0, max_d);
       std::printf("\"pairs\":[");
@@ -204,7 +206,7 @@ int main(int argc, char **argv)
       std::printf("}%s", i + 1 < reg.log.size() ? "," : "");
     }
     std::printf("],");
-    if (mode == "seq" || mode == "auto" || mode == "lum" || mode == "lumdev" || mode == "seqdev") {
+    if (mode == "seq" || mode == "auto" || mode == "autodev" || mode == "lum" || mode == "lumdev" || mode == "seqdev") {
       for (int v = 0; v < V; ++v) model.views[v].setRegisterState(true);
       reg.refineAxis(0);                          // the product's (mvr_refine_axis)
       std::printf("\"refined_pivot\":[%.9g,%.9g,%.9g],\"refined_axis\":[%.9g,%.9g,%.9g],", reg.getPivotPoint()[0], reg.getPivotPoint()[1],

@@ -143,3 +143,72 @@ def test_slot_state_after_in_place_changes_between_passes(mvr, how):
             runs.append(b"".join(bytes(r) for r in rows) + b"".join(bytes(r) for r in rows2))
             assert sum(r.n for r in rows) > 1000
     assert runs[0] == runs[1], how
+
+
+def _sequential(mvr, ctx, scans, poses0, params, repeat, V, hook=None):
+    """the sequential driver (registrator.cpp:526-588) over the C-ABI: view 0 posed, then 1, V-1, 2, ... each aligned to
+    the growing model and appended"""
+    RAW, TARGET, SOURCE, OUT = 16, 0, 1, 2
+    order = []
+    for i in range(1, V // 2):
+        order += [i, V - i]
+    order.append(V // 2)
+    poses, log = [p.copy() for p in poses0], []
+    for r in range(repeat):
+        ctx.transform(TARGET, RAW + 0, poses[0])
+        ctx.reserve(TARGET, sum(len(s) for s in scans))
+        for k, v in enumerate(order):
+            ctx.transform(SOURCE, RAW + v, poses[v])
+            T, st, rc = ctx.icp_align(SOURCE, TARGET, OUT, params)
+            poses[v] = mvr.mat4d_mul(T.astype(np.float64), poses[v])
+            if hook:
+                hook(ctx, r, k)
+            ctx.append(TARGET, OUT)
+            log.append((v, st["n_corr"], st["iterations"], st["state"], st["mse"], T.tobytes()))
+    return poses, log, ctx.download(TARGET)
+
+
+@pytest.mark.parametrize("case", ["reference_settings", "two_sweeps", "three_iterations", "ragged_sizes", "wide_radius"])
+def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, case):
+    """mvr_icp_align of a posed scan against the growing model of the sequential mode: the reverse searches walk the
+    source scan's cell grid (seq_search 1, the default) and, with seq_search 2, the forward search goes through the merged
+    scans' pose-invariant grids as well (nn_parts_kernel): the same transformations, counts, residuals and merged cloud,
+    bit for bit, as the culled kernel both ways (seq_search 0) -- with the reference's settings, over two sweeps (the grids are reused, the model is rebuilt),
+    with aligns that iterate (only their first iteration can use the parts), with scans of different sizes and with a
+    radius so wide that most queries go to the fallback.  The first align's correspondences equal the oracle's."""
+    V, N, max_d = 8, 9000, 4.0
+    sp = mvr.synth_params(V, 3)
+    sizes = [N] * V if case != "ragged_sizes" else [N - 613 * v for v in range(V)]
+    scans = [mvr.synth_view(sp, v, sizes[v]) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    kw = dict(max_dist=max_d, max_iter=1000)
+    if case == "three_iterations":
+        kw = dict(max_dist=max_d, max_iter=3, teps=0.0, feps=-1e300)
+    if case == "wide_radius":
+        kw = dict(max_dist=40.0, max_iter=1000)
+    params = mvr.icp_params(**kw)
+    runs = []
+    for mode in (0, 1, 2):           # culled both ways; reverse over the source's grid (default); forward through the parts as well
+        with mvr.Context(0) as ctx:
+            ctx.tune(seq_search=mode)
+            for v in range(V):
+                ctx.upload(16 + v, scans[v])
+            ctx.prof_reset(); ctx.prof_enable(1)
+            poses, log, merged = _sequential(mvr, ctx, scans, poses0, params, 2 if case == "two_sweeps" else 1, V)
+            ctx.prof_enable(False)
+            assert (ctx.prof_get(mvr.K_NN_GRID)[0] > 0) == (mode >= 1), (case, mode)
+            runs.append((np.asarray(poses).tobytes(), log, merged.tobytes()))
+    for r in runs[1:]:
+        assert runs[0][1] == r[1], case
+        assert runs[0][0] == r[0] and runs[0][2] == r[2], case
+    # ... and against the oracle: the first align's correspondences, one by one
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(16 + v, scans[v])
+        ctx.transform(0, 16, poses0[0]); ctx.transform(1, 17, poses0[1])
+        T, st, rc = ctx.icp_align(1, 0, 2, params)
+    a, b = orc.transform_f64(poses0[1], scans[1]), orc.transform_f64(poses0[0], scans[0])
+    cc = orc.correspondences(a, b, kw["max_dist"], kdtree=True)
+    if case != "three_iterations":
+        assert st["n_corr"] == len(cc), (case, st["n_corr"], len(cc))

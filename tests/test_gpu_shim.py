@@ -161,6 +161,33 @@ def test_automatic_registration_driver(driver, mvr, orc):
     assert_poses(out["poses"], poses)
 
 
+def test_automatic_registration_device_resident(driver, mvr, orc):
+    """Registrator::automaticRegistrationDevice (scans resident, the model grown in a device slot, every repeat an in-place
+    align: one 4x4 back) == the same restatement: counts per repeat, final poses, and the logged TRUE residual equals the
+    oracle's fitness of the advanced source against the model."""
+    V, N, max_d, repeat = 12, 3000, 8.0, 3
+    out, _ = run(driver, "autodev", V, N, max_d, repeat, 6)
+    sp, scans, poses0 = scene(mvr, orc, V, N, 6)
+    poses = [p.copy() for p in poses0]
+    target = orc.transform_f64(poses[0], scans[0])
+    params = orc.make_params(max_dist=max_d, max_iter=1000, teps=0.0, feps=50.0)
+    k = 0
+    for v in range(1, V):
+        source = orc.transform_f64(poses[v], scans[v])
+        for _ in range(repeat):
+            source, T, st, rc = orc.icp_align(source, target, params)
+            poses[v] = orc.mat4d_mul(T.astype(np.float64), poses[v])
+            g = out["log"][k]; k += 1
+            assert g["view"] == v and g["n_corr"] == st["n_corr"] and g["iterations"] == st["iterations"]
+            Tg = np.array(g["T"]).reshape(4, 4)
+            assert np.abs(Tg[:3, :3] - T[:3, :3]).max() <= ROT_TOL and np.abs(Tg[:3, 3] - T[:3, 3]).max() <= TRANS_TOL
+            if v in (1, V - 1):
+                assert abs(g["fitness"] - orc.fitness(source, target, np.eye(4, dtype=np.float32))) < 1e-6 * max(1.0, g["fitness"])
+        target = np.concatenate([target, source])
+    assert k == len(out["log"]) == (V - 1) * repeat
+    assert_poses(out["poses"], poses)
+
+
 def test_pcl_named_api_surface(driver):
     out, err = run(driver, "api", 12, 3000, 8.0, 1, 3)
     assert out["iters"] == 7 and out["converged"] == 1
