@@ -469,7 +469,26 @@ API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *
   L.enqueue = &RankRun::enqueue; L.solve = &RankRun::solve; L.self = &run;
   L.sig = pass_loop_sig(c, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, 1 + rank + 1000 * world);
   L.reach = max_dist;
-  return ring_passes(c, n_steps, L, timing_ms);
+  if (int rc = ring_passes(c, n_steps, L, timing_ms)) return rc;
+  // Every rank solved the SAME all-reduced table and so holds the same poses -- if RCCL handed every rank the same bits (one
+  // reduction order per element, whatever the algorithm).  That assumption is checked, once per call, not taken on trust:
+  // a hash of the poses and its complement are MIN-reduced; all ranks agree exactly when min(h) == ~min(~h).
+  if (c->comm && n_steps > 0) {
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(poses);
+    for (size_t i = 0; i < (size_t)n_views * 16 * sizeof(double); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    h >>= 1;                                              // (non-negative as a signed 64-bit value: ncclInt64 / ncclMin)
+    if (int rc = ensure(c, c->seq_keys, c->seq_keys_cap, 2)) return rc;
+    long long *hk = reinterpret_cast<long long *>(c->h_moments + 50);
+    hk[0] = (long long)h; hk[1] = (long long)(0x7FFFFFFFFFFFFFFFull - h);
+    MVR_HIP_TRY(c, hipMemcpyAsync(c->seq_keys, hk, 2 * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    if (int rc = comm_allreduce(c, c->seq_keys, 2, kReduceMinI64)) return rc;
+    MVR_HIP_TRY(c, hipMemcpyAsync(hk, c->seq_keys, 2 * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = stream_wait(c)) return rc;
+    if ((unsigned long long)hk[0] != 0x7FFFFFFFFFFFFFFFull - (unsigned long long)hk[1])
+      return set_error(c, MVR_E_RCCL, "the ranks disagree on the poses: the all-reduce did not hand every rank the same bits");
+  }
+  return MVR_OK;
 }
 
 // ------------------------------------------------------------------ one process, all GPUs

@@ -27,10 +27,10 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def pair_fixture():
-    """BASELINE config 1 shape (2 scans, pairwise point-to-point ICP), 8192 pts."""
+    """BASELINE config 1: 2 synthetic turntable scans, 10 000 points each, pairwise point-to-point ICP."""
     sp = mvr.synth_params(12, 1)
-    tgt = mvr.synth_view(sp, 0, 8192)
-    raw = mvr.synth_view(sp, 1, 8192)
+    tgt = mvr.synth_view(sp, 0, 10000)
+    raw = mvr.synth_view(sp, 1, 10000)
     piv, ax = mvr.synth_prior(sp)
     prior = mvr.axis_rotation(piv, ax, mvr.turntable_angle(1, 12))
     src = orc.transform_f64(prior, raw)
@@ -50,7 +50,7 @@ def pair_fixture():
     o5, T5, st5, rc = orc.icp_align(src, tgt, p5)
     out["align5_T"], out["align5_stats"] = T5, np.array([st5["iterations"], st5["n_corr"], st5["mse"]])
     out["fitness1"] = np.array([orc.fitness(src, tgt, T)])
-    np.savez_compressed(os.path.join(OUT, "pair_2x8192.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "pair_2x10000.npz"), **out)
     print("pair: n_corr", st["n_corr"], "mse", st["mse"], "-> 5 it mse", st5["mse"])
 
 

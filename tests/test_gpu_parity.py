@@ -144,7 +144,7 @@ def test_nn_empty_inputs(gpu):
 
 
 def test_golden_pair(gpu, mvr):
-    g = load_golden("pair_2x8192.npz")
+    g = load_golden("pair_2x10000.npz")
     gpu.upload(0, g["tgt"]); gpu.upload(1, g["raw"])
     gpu.transform(1, 1, g["prior"])
     assert np.array_equal(bits(gpu.download(1)), bits(g["src"]))

@@ -265,3 +265,46 @@ def test_sequential_sharded_failures(mvr, seq_scene, how):
         assert np.array_equal(np.stack(again), np.stack(good)) and [e["n_corr"] for e in alog] == [e["n_corr"] for e in glog]
     finally:
         drv.close()
+
+
+# ---------------------------------------------------------------- more than one GPU (skipped on the one-GPU test box)
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.timeout(300)
+def test_world_of_two_devices(mvr, scene):
+    """mvr_world_create(2): one process, two GPUs, ncclCommInitAll; every rank runs its half of the queries, the edge table is
+    all-reduced over xGMI, the ranks end with bit-identical poses (mvr_world_ring_run checks it, and so does the pose hash
+    inside mvr_ring_run_sharded) that agree with the single-context run to rounding (the sums are added in another order)."""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    scans, poses0, origin = scene
+    V = len(scans)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    ref, rinfo = reference_run(mvr, scans, poses0, origin, 6)
+    with mvr.World(2) as w:
+        for v in range(V):
+            w.upload(V + v, scans[v])
+        new, info = w.ring_run(list(range(V)), [V + v for v in range(V)], edges, poses0, 8.0, origin, steps=6)
+        assert w.ctx(0).comm_info() == (0, 2, 2) and w.ctx(1).comm_info() == (1, 2, 2)
+    assert info["pair_n"] == rinfo["pair_n"]
+    assert np.abs(np.asarray(new) - ref).max() < 1e-9
+
+
+@pytest.mark.timeout(600)
+def test_bench_with_two_ranks(mvr):
+    """`python bench.py --gpus 2` end to end: two processes, library-owned RCCL communicator, one JSON line with ranks = 2"""
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--points", "20000", "--no-cpu-baseline",
+                        "--no-bruteforce-pass", "--repeats", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
