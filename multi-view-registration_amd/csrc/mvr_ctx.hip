@@ -775,7 +775,11 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
       which.push_back(k);
     }
     std::vector<char> handled(d.size(), 0);
-    if (!d.empty()) { if (int rc = refresh_posed_batch(c, (int)d.size(), d.data(), s.data(), Ts.data(), pass == 0, handled.data())) return rc; }
+    // (a pass queued ahead of its poses leaves the points in original order out: 77 MB of the step's 230 MB of posing
+    // traffic that no kernel of a fused pass reads -- ring_passes writes them once at the end of the stretch)
+    const bool skip_pts = pass == 0 && c->pose_from_table && c->skip_posed_pts;
+    if (!d.empty()) { if (int rc = refresh_posed_batch(c, (int)d.size(), d.data(), s.data(), Ts.data(), pass == 0 && !skip_pts, handled.data())) return rc; }
+    if (skip_pts) for (size_t i = 0; i < which.size(); ++i) if (handled[i]) c->slots[dst[which[i]]].pts_stale = true;
     if (pass == 0) {
       for (size_t i = 0; i < which.size(); ++i) if (handled[i]) { done[which[i]] = 1; n[which[i]] = 0; }    // posed by the refresh launch
       std::vector<const Mat44d *> Tp((size_t)count, nullptr);
@@ -1556,7 +1560,8 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
       return rc;
     };
     auto leave = [&]() {      // back to by-value poses; the host's pose bookkeeping catches up with what the last chain computed
-      c->pose_from_table = false; c->no_sync = false;
+      c->pose_from_table = false; c->no_sync = false; c->skip_posed_pts = false;
+      std::vector<const float4 *> in; std::vector<float4 *> out; std::vector<size_t> nn; std::vector<double> Ts;
       for (int v = 0; v < V; ++v) {
         Cloud &d = c->slots[L.posed_slots[v]];
         d.pose_dev = nullptr;
@@ -1564,9 +1569,15 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
         const bool was_known = d.pose_known;
         d.posed_by_table = false;
         note_pose(d, c->slots[L.raw_slots[v]], was_known, last_in.data() + 16 * (size_t)v);
+        if (d.pts_stale) {                               // the points in original order, left out while the passes were queued ahead
+          in.push_back(c->slots[L.raw_slots[v]].pts); out.push_back(d.pts); nn.push_back(d.n);
+          Ts.insert(Ts.end(), last_in.begin() + 16 * (size_t)v, last_in.begin() + 16 * (size_t)v + 16);
+          d.pts_stale = false;
+        }
       }
+      if (!in.empty()) (void)launch_transform_f64_batch(c, (int)in.size(), in.data(), out.data(), nn.data(), Ts.data());
     };
-    c->pose_from_table = true;
+    c->pose_from_table = true; c->skip_posed_pts = true;
     write_poses(parity, L.poses);
     uint32_t seq_cur = 0, seq_next = 0;
     double t0 = now_ms();

@@ -132,6 +132,7 @@ struct Cloud {
   bool fin_known = false; float fin[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::vector<GridPart> parts;         // non-empty: this cloud is exactly the concatenation of these posed scans (see GridPart)
   void forget_pose() { canonical = false; pose_known = false; fin_known = false; pose_stretch = 1.0; grid.reset(); parts.clear(); }
+  bool pts_stale = false;              // pts[] were left out by the last (pipelined) pose of this cloud: sorted[] / gsorted[] are current, pts[] are written when the run leaves the pipe
   bool posed_by_table = false;         // ... and the last transform of this cloud did read it (its host-side pose is filled in when the run leaves the pipe)
 };
 
@@ -259,6 +260,7 @@ struct Ctx {
   int pipeline = 1;                                   // 0: every pass is enqueued after the previous solve (round-2 behaviour)
   bool no_sync = false;                               // a gated chain is being enqueued: nothing may wait for the stream or reallocate (may_block)
   unsigned long long blocking_events = 0;             // how often something did wait / reallocate (a pass without any is in steady state)
+  bool skip_posed_pts = false;                        // ... and the posed copies' points in ORIGINAL order are not written (nothing in a fused pass reads them: ring_passes writes them once, when the stretch of queued passes ends)
   bool pose_from_table = false;                       // mvr_cloud_transform_batch ignores its T values: every destination reads Cloud::pose_dev
   double *h_pose_in = nullptr, *d_pose_in = nullptr;  // pinned, mapped: [2][views][16] poses the host writes before it opens the gate
   PoseRec *pose_tab = nullptr; size_t pose_tab_cap = 0;      // device: [2][views]

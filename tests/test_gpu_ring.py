@@ -459,6 +459,7 @@ def test_pipelined_run_equals_pass_by_pass(mvr, case):
             # the posed clouds are what the LAST pass searched, and the slots' bookkeeping fits them: one more batch over them
             rows = ctx.pair_moments2_batch([(a, b) for a, b in edges], max_d, origin)
             log.append(b"".join(bytes(r) for r in rows))
+            log.append(ctx.download(3).tobytes() + ctx.download(V - 1).tobytes())      # (the queued passes leave the posed points in original order out: written when the run ends)
             runs.append(log)
             piped.append(ctx.stat("piped_passes"))
     assert runs[0] == runs[1] == runs[2], case

@@ -8,7 +8,8 @@ import csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
 GRID = len(sys.argv) > 2 and sys.argv[2] == "grid"        # the grid-search launches (nn_grid_kernel) instead of the culled ones
-V, N, STEPS, WARM = 12, 200000, 10, (25 if GRID else 2)
+_probe = json.loads([l for l in open(os.path.join(d, "FETCH_SIZE.log")) if l.startswith("{")][-1])      # the probe says what it ran
+V, N, STEPS, WARM = _probe["views"], _probe["n"], _probe["steps"], _probe["warm"]
 NAME = "nn_grid_kernel" if GRID else "nn_cull_kernel"
 
 
@@ -19,6 +20,11 @@ def per_dispatch(counter):
             if NAME in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 rows[int(r["Dispatch_Id"])] = rows.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     vals = [rows[k] for k in sorted(rows)]
+    if V > 12:
+        # more pairs than one fused launch holds: several launches per direction and step -- only per-STEP sums are meaningful
+        per_step = len(vals) // (STEPS + max(WARM, 1) - (1 if GRID else 0))
+        tail = vals[-per_step * STEPS:]
+        return [sum(tail[i * per_step:(i + 1) * per_step]) / 2.0 for i in range(STEPS) for _ in (0, 1)]      # (spread evenly over a "forward" and a "reverse" slot)
     if GRID:
         return vals[-2 * STEPS:]              # the first pass of all takes the culled kernel; the timed steps are the last ones
     return vals[2 * max(WARM, 1):]            # forward + reverse per step; the warm-up steps come first
@@ -41,7 +47,16 @@ if GRID:
     # (16 B per point, grid order) -- the candidates a query evaluates are that same target array, re-read through the caches
     alg_fwd = V * (32 * N + 16 * N)
     alg_rev = V * (32 * m + 4 * m + 16 * N)
+# SURVEY 8(d)'s compulsory bytes (12-byte points, every array once per kernel): K2 = 12 Ns + 12 Nt + 8 Ns, K3 = 12 Nt' + 12 Ns + 4 Nt' + 4 Ns
+s8d_fwd, s8d_rev = V * (12 * N + 12 * N + 8 * N), V * (12 * m + 12 * N + 4 * m + 4 * N)
 out = {
+    "survey_8d_bytes_forward": s8d_fwd, "survey_8d_bytes_reverse": s8d_rev, "survey_8d_bytes_per_launch": 0.5 * (s8d_fwd + s8d_rev),
+    "ratio_to_survey_8d": 0.5 * (fwd + rev) / (0.5 * (s8d_fwd + s8d_rev)),
+    "fetch_uncorrected_bytes_per_launch": 0.5 * ((ff + fr) * 1024 + (wf + wr) * 1024),
+    "calibration_note": "the x2 of the guide holds for wide coalesced reads; tools/exp_fetch.hip (profiles/r03_*_exp_fetch.txt) measures what this counter "
+                        "reports for one-line-per-lane gathers, the walk's dominant access: the truth lies between the uncorrected and the doubled figure",
+    "per_step_note": ("more than 12 pairs: the launches of a step are summed and halved -- forward / reverse figures are the per-step mean of both" if V > 12 else None),
+    "hbm_bytes_per_step": fwd + rev,
     "kernel": ("nn_grid_kernel<false,1> (exact grid walk of the bounded queries, fused launch over the %d scan pairs of a ring step)" if GRID else
                "nn_cull_kernel<false,1,1> (exact culled NN, fused launch over the %d scan pairs of a ring step)") % V,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/step_probe.py %d %d %d %d, MVR_PAIR_GROUPS=1 "
