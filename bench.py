@@ -370,11 +370,13 @@ def main():
         Ns = Nt = float(N)
         Ntp = reg.last["n_corr"] / float(V)
         fwd_bytes, rev_bytes = V * (12 * Ns + 12 * Nt + 8 * Ns), V * (12 * Ntp + 12 * Ns + 4 * Ntp + 4 * Ns)
-        alg_bytes = 0.5 * (fwd_bytes + rev_bytes)
+        launches_per_step = gl_ / float(args.steps)          # 2 while one fused launch holds all pairs (V <= 12), more beyond
+        alg_bytes = (fwd_bytes + rev_bytes) / launches_per_step
         extra = {"measured": "%d steps right after the timed region, HIP events and evaluation counters per launch; per step one forward "
                              "launch (all %d x %d source queries) and one reverse launch (the matched targets) for all scan pairs" % (args.steps, V, N),
                  "ms_per_step_one_stream_profiled": iso["ms_per_step"],
-                 "algorithmic_bytes": {"forward_launch": fwd_bytes, "reverse_launch": rev_bytes, "formula": "SURVEY 8(d) K2 / K3 with Nt' = accepted correspondences per pair"},
+                 "algorithmic_bytes": {"forward_per_step": fwd_bytes, "reverse_per_step": rev_bytes, "launches_per_step": launches_per_step,
+                                       "formula": "SURVEY 8(d) K2 / K3 with Nt' = accepted correspondences per pair; per launch = (forward + reverse) / launches per step"},
                  "limiter": "TA: the L1 gather path (rocprofv3 --pmc: TA_TA_BUSY ~88 % of the launch, ~13 distinct cache lines per vector load; "
                             "DESIGN.md 4.3) -- neither roof is near: HBM by the roofline model (3.4 flop/B against a 19.7 flop/B ridge), a few "
                             "per-lane 16-byte gathers per query in practice",

@@ -1215,7 +1215,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     // measured on 2 / 3 / 4 / 6 pairs of 200k: equal or up to 4 % slower)
     // (a pass enqueued ahead of its poses runs its pairs as ONE group: the groups measure the same since the grid search --
     // 0.508 / 0.506 / 0.504 ms with 1 / 2 / 3 -- and one stream needs no fork / join events between queued passes)
-    const int G = (n_pairs >= 4 * c->pair_groups && !c->pose_from_table) ? c->pair_groups : 1;
+    const int G = (n_pairs >= 4 * c->pair_groups && !c->pose_from_table && !c->single_group) ? c->pair_groups : 1;
     c->last_batch.assign((size_t)n_pairs, BatchPairRec());
     if (G == 1) {
       if (int rc = pair_batch_fused(c, c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
@@ -1446,6 +1446,13 @@ int pipe_setup(Ctx *c, int n_views)
     if (hipMalloc(&c->pose_tab, 2 * cap * sizeof(PoseRec)) != hipSuccess) { c->pose_tab = nullptr; return MVR_E_HIP; }
     c->pose_tab_cap = cap;
   }
+  if (!c->pipe_ops_warm) {
+    // the runtime sets the two stream operations up lazily, per stream, at their first use (milliseconds): have that happen
+    // now, behind whatever the stream is busy with, not in the first pass that is queued ahead
+    (void)hipStreamWriteValue32(c->stream, c->d_done, *c->h_done, 0);
+    (void)hipStreamWaitValue32(c->stream, c->gate, 0u, hipStreamWaitValueGte, 0xFFFFFFFFu);        // (any value is >= 0: never blocks)
+    c->pipe_ops_warm = true;
+  }
   return MVR_OK;
 }
 
@@ -1528,6 +1535,11 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
   };
   auto all_rigid = [&]() { for (int v = 0; v < V; ++v) if (!pose_nearly_rigid(L.poses + 16 * (size_t)v)) return false; return true; };
   bool steady = L.sig != 0 && c->pipe_steady_sig == L.sig && c->pipe_steady_events == c->blocking_events;
+  // one group of pairs from the first pass on when passes may be queued ahead later: the queued chain runs its pairs as one
+  // group, and a change of the grouping in mid-run would re-size the work buffers and orphan the seeds in them (measured: the
+  // first queued pass of a registration then cost 2.5 ms instead of 0.43)
+  struct GroupGuard { Ctx *c; bool saved; ~GroupGuard() { c->single_group = saved; } } group_guard{c, c->single_group};
+  if (pipe_possible() && n_steps >= 2) c->single_group = true;
   int k = 0;
   while (k < n_steps) {
     if (!(steady && n_steps - k >= 2 && pipe_possible() && all_rigid() && pipe_setup(c, V) == MVR_OK)) {

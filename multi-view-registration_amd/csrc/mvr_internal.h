@@ -260,12 +260,14 @@ struct Ctx {
   int pipeline = 1;                                   // 0: every pass is enqueued after the previous solve (round-2 behaviour)
   bool no_sync = false;                               // a gated chain is being enqueued: nothing may wait for the stream or reallocate (may_block)
   unsigned long long blocking_events = 0;             // how often something did wait / reallocate (a pass without any is in steady state)
+  bool single_group = false;                          // the fused pass runs its pairs as ONE group for the whole ring run: a run that may queue passes ahead must not change the layout of its work buffers (and of the seeds in them) when it starts to
   bool skip_posed_pts = false;                        // ... and the posed copies' points in ORIGINAL order are not written (nothing in a fused pass reads them: ring_passes writes them once, when the stretch of queued passes ends)
   bool pose_from_table = false;                       // mvr_cloud_transform_batch ignores its T values: every destination reads Cloud::pose_dev
   double *h_pose_in = nullptr, *d_pose_in = nullptr;  // pinned, mapped: [2][views][16] poses the host writes before it opens the gate
   PoseRec *pose_tab = nullptr; size_t pose_tab_cap = 0;      // device: [2][views]
   uint32_t *gate = nullptr; bool gate_is_signal = false;     // host-writable word the stream waits on (hipStreamWaitValue32)
   uint32_t *h_done = nullptr, *d_done = nullptr;      // pinned, mapped: the stream writes the pass number here when a pass's chain has drained
+  bool pipe_ops_warm = false;                         // the stream's wait-value / write-value operations have been used once
   uint32_t pipe_seq = 0;                              // passes sent through the pipe so far
   unsigned long long pipe_steady_sig = 0, pipe_steady_events = ~0ull;      // the registration whose last run ended in steady state, and blocking_events then
   std::vector<double> pass_ms;                        // wall time of every pass of the last ring run (end of the previous solve -> end of this one)
