@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--nn-mode", type=int, default=1, help="1: exact culled search (default); 0: exact brute force")
     ap.add_argument("--no-bruteforce-pass", action="store_true",
                     help="skip the extra untimed brute-force ring pass that feeds roofline_bruteforce")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip cold_registration and secondary_sequential (they launch the same kernels on other shapes: a rocprofv3 --stats "
+                         "average over the run then covers the ring step's launches only)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed K-step window is repeated this many times after the headline one: min/median/max as extra keys")
     args = ap.parse_args()
@@ -428,7 +431,7 @@ def main():
     # What a registration costs from a standing start, beside the steady state above: a FRESH context, the uploads, then K
     # passes from the prior in one native call -- no prewarm, no seeds, the orderings and grids built on the way (the reference
     # builds its kd-trees inside every align, registrator.cpp:569, and cpu_baseline pays for them too)
-    if world == 1:
+    if world == 1 and not args.no_secondary:
         cold_ctx = mvr.Context(local_rank)
         try:
             cold_ctx.tune(nn_mode=args.nn_mode)
@@ -474,7 +477,7 @@ def main():
         ctx.sync()
         return poses, ncorr, time.perf_counter() - t0, order
     seq = None
-    if world == 1 and V >= 4:
+    if world == 1 and V >= 4 and not args.no_secondary:
         ctx.tune(nn_mode=args.nn_mode, pair_streams=6, pair_groups=2)
         sequential_sweep()                                              # warm-up: allocations, orderings
         seq_poses, seq_ncorr, seq_dt, seq_order = sequential_sweep()

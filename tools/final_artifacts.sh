@@ -15,11 +15,17 @@ part1)
   MVR_BENCH_FORCE_DIST=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 \
       --no-cpu-baseline --no-bruteforce-pass > $O/bench_torchrun_1rank_rccl.json 2> $O/torchrun.err || { tail -5 $O/torchrun.err; exit 1; }
   echo torchrun done
+  ;&
+stats)
   cd /tmp && export TMPDIR=/tmp
-  # kernel stats of the bench with the pairs in one group (one launch = all 12 pairs, the roofline's unit) and with the default
+  # kernel stats of the bench with the pairs in one group (one launch = all 12 pairs, the roofline's unit) and with the default.
+  # MVR_BENCH_PREWARM=0: without the 20 set-up passes every launch of the run belongs to a window that starts from the
+  # prior, like the windows the bench's own HIP events cover, and --no-secondary keeps the one-pair launches of the sequential
+  # mode (the same kernel on a 200k-query launch) out of the statistics -- the two averages are then over the same kind of launch
+  export MVR_BENCH_PREWARM=0
   for g in 1 2; do
     export MVR_PAIR_GROUPS=$g
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_g$g -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-bruteforce-pass --repeats 0 > $O/bench_under_rocprof_groups$g.json 2> $O/rocprof_g$g.err || { tail -5 $O/rocprof_g$g.err; exit 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_g$g -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-bruteforce-pass --no-secondary --repeats 0 > $O/bench_under_rocprof_groups$g.json 2> $O/rocprof_g$g.err || { tail -5 $O/rocprof_g$g.err; exit 1; }
     cp $(find $O/stats_g$g -name "*kernel_stats.csv" | head -1) $O/bench_n1_kernel_stats_groups$g.csv
   done
   unset MVR_PAIR_GROUPS
@@ -78,5 +84,5 @@ part3)
   echo stats done
   MVR_TRAFFIC_VIEWS=36 MVR_TRAFFIC_POINTS=1000000 $R/tools/measure_traffic.sh final_traffic_36x1M || exit 1
   ;;
-*) echo "usage: $0 part1|part2|part3"; exit 2 ;;
+*) echo "usage: $0 part1|stats|part2|part3"; exit 2 ;;
 esac
