@@ -356,16 +356,29 @@ API int mvr_moments_from_moments2(const mvr_pair_moments2_t *m2, mvr_pair_moment
 }
 
 // pcl::getTransformation(x, y, z, roll, pitch, yaw) = Translation * Rz(yaw) Ry(pitch) Rx(roll)
-API void mvr_pose_to_mat4(const double pose[6], double T[16])
+// (the six trigonometric values of a pose, computed once per LUM iteration and vertex: the matrix and the incidence
+// correction of the same pose both need them -- 116 libm calls per iteration were half of its time)
+struct PoseTrig { double cr, sr, cp, sp, cy, sy; };
+static inline PoseTrig pose_trig(const double pose[6])
 {
-  const double cr = std::cos(pose[3]), sr = std::sin(pose[3]);
-  const double cp = std::cos(pose[4]), sp = std::sin(pose[4]);
-  const double cy = std::cos(pose[5]), sy = std::sin(pose[5]);
+  PoseTrig t;
+  t.cr = std::cos(pose[3]); t.sr = std::sin(pose[3]);
+  t.cp = std::cos(pose[4]); t.sp = std::sin(pose[4]);
+  t.cy = std::cos(pose[5]); t.sy = std::sin(pose[5]);
+  return t;
+}
+static inline void pose_to_mat4_trig(const double pose[6], const PoseTrig &g, double T[16])
+{
+  const double cr = g.cr, sr = g.sr, cp = g.cp, sp = g.sp, cy = g.cy, sy = g.sy;
   std::memset(T, 0, 16 * sizeof(double));
   T[0] = cy * cp; T[4] = cy * sp * sr - sy * cr; T[8]  = sy * sr + cy * sp * cr; T[12] = pose[0];
   T[1] = sy * cp; T[5] = cy * cr + sy * sp * sr; T[9]  = sy * sp * cr - cy * sr; T[13] = pose[1];
   T[2] = -sp;     T[6] = cp * sr;                T[10] = cp * cr;                T[14] = pose[2];
   T[15] = 1.0;
+}
+API void mvr_pose_to_mat4(const double pose[6], double T[16])
+{
+  pose_to_mat4_trig(pose, pose_trig(pose), T);
 }
 
 // LUM::computeEdge from raw moments.  With p' = p - o,
@@ -634,9 +647,9 @@ API void mvr_lum_incidence(const double pose[6], double H[36]) { lum_incidence(p
 //   x3 + sy x5 = b3,   sx x4 + cx cy x5 = b4,   cx x4 - sx cy x5 = b5      (determinant of the 2 x 2: -cy)
 // and rows 0..2 are the identity plus the top-right block times those three.  (Eleven general 6 x 6 eliminations
 // per LUM iteration were a fifth of its time.)  false: cos(pitch) = 0, H is singular.
-static bool solve_incidence(const double pose[6], const double b[6], double x[6])
+static bool solve_incidence(const double pose[6], const PoseTrig &g, const double b[6], double x[6])
 {
-  const double cx = std::cos(pose[3]), sx = std::sin(pose[3]), cy = std::cos(pose[4]), sy = std::sin(pose[4]);
+  const double cx = g.cr, sx = g.sr, cy = g.cp, sy = g.sp;
   if (std::fabs(cy) < 1e-300) return false;
   // [sx, cx cy; cx, -sx cy] (x4, x5)^T = (b4, b5)^T
   const double det = -sx * sx * cy - cx * cx * cy;      // = -cy
@@ -676,9 +689,10 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     for (int r = 0; r < 6; ++r) row_end[6 * (vi - 1) + r] = 6 * hi;
   }
   std::vector<double> Tv((size_t)n * 16);
+  std::vector<PoseTrig> trig((size_t)n);
   int it = 0;
   for (; it < max_iterations; ++it) {
-    for (int v = 0; v < n; ++v) mvr_pose_to_mat4(poses + 6 * v, &Tv[(size_t)v * 16]);
+    for (int v = 0; v < n; ++v) { trig[(size_t)v] = pose_trig(poses + 6 * v); pose_to_mat4_trig(poses + 6 * v, trig[(size_t)v], &Tv[(size_t)v * 16]); }
     auto store_edge = [&](int e, int rc, const double *MM, const double *MZ, double ss) {
       if (rc != MVR_OK || ss < 0.0000000000001 || !std::isfinite(ss)) {
         std::fill(cinv.begin() + 36 * e, cinv.begin() + 36 * (e + 1), 0.0);
@@ -725,7 +739,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     double sum = 0.0;
     for (int vi = 1; vi < n; ++vi) {
       double sol[6], dp[6], nrm = 0.0;
-      if (!solve_incidence(poses + 6 * vi, &B[6 * (vi - 1)], sol)) continue;       // incidence^-1 * X_vi
+      if (!solve_incidence(poses + 6 * vi, trig[(size_t)vi], &B[6 * (vi - 1)], sol)) continue;       // incidence^-1 * X_vi (the pose is still the one the iteration began with)
       for (int r = 0; r < 6; ++r) { dp[r] = -sol[r]; nrm += sol[r] * sol[r]; }
       sum += std::sqrt(nrm);
       for (int r = 0; r < 6; ++r) poses[6 * vi + r] += dp[r];

@@ -412,6 +412,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   if (c->seq_row) (void)hipFree(c->seq_row);
   if (c->h_pose_in) (void)hipHostFree(c->h_pose_in);
   if (c->pose_tab) (void)hipFree(c->pose_tab);
+  if (c->done_counter) (void)hipFree(c->done_counter);
   if (c->gate) { if (c->gate_is_signal) (void)hipFree(c->gate); else (void)hipHostFree(c->gate); }
   if (c->h_done) (void)hipHostFree(c->h_done);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
@@ -783,7 +784,11 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     if (pass == 0) {
       for (size_t i = 0; i < which.size(); ++i) if (handled[i]) { done[which[i]] = 1; n[which[i]] = 0; }    // posed by the refresh launch
       std::vector<const Mat44d *> Tp((size_t)count, nullptr);
-      if (c->pose_from_table) for (int k = 0; k < count; ++k) if (in[k] && c->slots[dst[k]].pose_dev && dst[k] != src[k]) Tp[k] = &c->slots[dst[k]].pose_dev->T;
+      if (c->pose_from_table) {
+        bool any = false;
+        for (int k = 0; k < count; ++k) if (in[k] && n[k] && c->slots[dst[k]].pose_dev && dst[k] != src[k]) { Tp[k] = &c->slots[dst[k]].pose_dev->T; any = true; }
+        if (any) { if (int rc = ensure_pose_table(c)) return rc; }
+      }
       if (int rc = launch_transform_f64_batch(c, count, in.data(), out.data(), n.data(), T, Tp.data())) return rc;
       for (size_t i = 0; i < which.size(); ++i) if (handled[i]) n[which[i]] = c->slots[dst[which[i]]].n;
     }
@@ -1159,6 +1164,10 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
         if (!c->grid_wide) { if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc; }
       } else if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc;
     }
+    if (c->signal_armed && w == c && base + kBatchPairs >= n_pairs && c->done_counter && c->d_done) {      // the chain's last launch carries its completion word
+      gb.done_word = c->d_done; gb.done_counter = c->done_counter; gb.done_seq = c->signal_seq;
+      c->signal_armed = false; c->signal_sent = true;
+    }
     if (int rc = launch_accept_moments2_batch(w, gb, m)) return rc;
   }
   if (recip) w->bbound_clean = true;
@@ -1217,6 +1226,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     // 0.508 / 0.506 / 0.504 ms with 1 / 2 / 3 -- and one stream needs no fork / join events between queued passes)
     const int G = (n_pairs >= 4 * c->pair_groups && !c->pose_from_table && !c->single_group) ? c->pair_groups : 1;
     c->last_batch.assign((size_t)n_pairs, BatchPairRec());
+    if (G != 1 || out) c->signal_armed = false;      // (the sums launch is then not the last thing on the stream)
     if (G == 1) {
       if (int rc = pair_batch_fused(c, c, n_pairs, src, dst, max_dist, reciprocal, fma, q_begin, q_count, origin, table)) return rc;
     } else {
@@ -1373,34 +1383,22 @@ __global__ void pose_prep_kernel(const double *__restrict__ in, PoseRec *__restr
 {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n_views) return;
-  PoseRec r;
   double T[16];
-  for (int j = 0; j < 16; ++j) { T[j] = in[16 * v + j]; r.T.m[j] = T[j]; }
-  // inverse of x -> A x + t (column-major 4 x 4): by cofactors, in double, as make_grid_pair does on the host
-  const double A[3][3] = {{T[0], T[4], T[8]}, {T[1], T[5], T[9]}, {T[2], T[6], T[10]}};
-  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-  const double id = 1.0 / det;
-  const double I[3][3] = {{(A[1][1] * A[2][2] - A[1][2] * A[2][1]) * id, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id},
-                          {(A[1][2] * A[2][0] - A[1][0] * A[2][2]) * id, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id},
-                          {(A[1][0] * A[2][1] - A[1][1] * A[2][0]) * id, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id}};
-  for (int rr = 0; rr < 3; ++rr) {
-    for (int k = 0; k < 3; ++k) r.minv[4 * rr + k] = I[rr][k];
-    r.minv[4 * rr + 3] = -(I[rr][0] * T[12] + I[rr][1] * T[13] + I[rr][2] * T[14]);
-  }
-  // (the host has checked e <= 1e-3 before it released this pass: note_pose's bar)
-  double e2 = 0.0;
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b) {
-      const double d = T[4 * a] * T[4 * b] + T[4 * a + 1] * T[4 * b + 1] + T[4 * a + 2] * T[4 * b + 2];
-      const double x = d - (a == b ? 1.0 : 0.0);
-      e2 += x * x;
-    }
-  const double e = fmin(sqrt(e2), 0.5);
-  r.stretch = __double2float_ru((1.0 / sqrt(1.0 - e)) * (1.0 + 1e-6));
-  r.pad_ = 0.f;
-  out[v] = r;
+  for (int j = 0; j < 16; ++j) T[j] = in[16 * v + j];
+  make_pose_rec(T, out + v);
 }
+
+}  // namespace
+
+int ensure_pose_table(Ctx *c)
+{
+  if (!c->pose_tab_pending) return MVR_OK;
+  c->pose_tab_pending = false;
+  hipLaunchKernelGGL(pose_prep_kernel, dim3((unsigned)((c->pose_tab_n + 63) / 64)), dim3(64), 0, c->stream, c->pose_in_cur, c->pose_tab_cur, c->pose_tab_n);
+  return hipGetLastError() == hipSuccess ? MVR_OK : set_error(c, MVR_E_HIP, "pose_prep_kernel");
+}
+
+namespace {
 
 // note_pose's test: an affine matrix whose 3 x 3 is a rotation up to e = |A^T A - I|_F <= 1e-3
 bool pose_nearly_rigid(const double *T)
@@ -1435,6 +1433,10 @@ int pipe_setup(Ctx *c, int n_views)
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_done), 64, hipHostMallocMapped) != hipSuccess) { c->h_done = nullptr; return MVR_E_HIP; }
     *c->h_done = 0u;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_done), c->h_done, 0) != hipSuccess) return MVR_E_HIP;
+  }
+  if (!c->done_counter) {
+    if (hipMalloc(&c->done_counter, 64) != hipSuccess) { c->done_counter = nullptr; return MVR_E_HIP; }
+    if (hipMemset(c->done_counter, 0, 64) != hipSuccess) return MVR_E_HIP;
   }
   if (c->pose_tab_cap < (size_t)n_views) {
     if (c->h_pose_in) (void)hipHostFree(c->h_pose_in);
@@ -1564,15 +1566,21 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
       const uint32_t seq = ++c->pipe_seq;
       *seq_out = seq;
       if (gated) MVR_HIP_TRY(c, hipStreamWaitValue32(c->stream, c->gate, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
-      hipLaunchKernelGGL(pose_prep_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, c->stream, c->d_pose_in + (size_t)par * cap * 16,
-                         c->pose_tab + (size_t)par * cap, V);
-      int rc = hipGetLastError() == hipSuccess ? L.enqueue(L.self) : set_error(c, MVR_E_HIP, "pose_prep_kernel");
+      // the device records of these poses are filled by the chain's first launch that reads them (the posing launch does it
+      // on the way, any other reader through ensure_pose_table): no launch of its own at the head of the chain
+      c->signal_seq = seq; c->signal_sent = false; c->signal_armed = L.ends_with_sums;
+      c->pose_in_cur = c->d_pose_in + (size_t)par * cap * 16; c->pose_tab_cur = c->pose_tab + (size_t)par * cap; c->pose_tab_n = V; c->pose_tab_pending = true;
+      int rc = L.enqueue(L.self);
+      if (rc == MVR_OK) rc = ensure_pose_table(c);       // (a chain that never posed anything)
       // whatever was queued drains into the completion word, also after a failed enqueue (the caller waits for it)
-      if (hipStreamWriteValue32(c->stream, c->d_done, seq, 0) != hipSuccess && rc == MVR_OK) rc = set_error(c, MVR_E_HIP, "hipStreamWriteValue32");
+      // (the final sums launch has taken the word along when it is the chain's last operation: no packet of its own then)
+      const bool sent = c->signal_sent && rc == MVR_OK;
+      c->signal_armed = false; c->signal_sent = false;
+      if (!sent && hipStreamWriteValue32(c->stream, c->d_done, seq, 0) != hipSuccess && rc == MVR_OK) rc = set_error(c, MVR_E_HIP, "hipStreamWriteValue32");
       return rc;
     };
     auto leave = [&]() {      // back to by-value poses; the host's pose bookkeeping catches up with what the last chain computed
-      c->pose_from_table = false; c->no_sync = false; c->skip_posed_pts = false;
+      c->pose_from_table = false; c->no_sync = false; c->skip_posed_pts = false; c->pose_tab_pending = false;
       std::vector<const float4 *> in; std::vector<float4 *> out; std::vector<size_t> nn; std::vector<double> Ts;
       for (int v = 0; v < V; ++v) {
         Cloud &d = c->slots[L.posed_slots[v]];
@@ -1730,7 +1738,7 @@ API int mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_sl
   for (int e = 0; e < ne; ++e) { r.ss[(size_t)e] = posed_slots[edge_src[e]]; r.ts[(size_t)e] = posed_slots[edge_tgt[e]]; }
   PassLoop L;
   L.n_views = n_views; L.posed_slots = posed_slots; L.raw_slots = raw_slots; L.poses = poses;
-  L.enqueue = &RingRun::enqueue; L.solve = &RingRun::solve; L.self = &r;
+  L.enqueue = &RingRun::enqueue; L.solve = &RingRun::solve; L.self = &r; L.ends_with_sums = true;
   L.sig = pass_loop_sig(c, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, 0);
   L.reach = max_dist;
   return ring_passes(c, n_steps, L, timing_ms);

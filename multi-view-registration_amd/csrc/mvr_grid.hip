@@ -629,6 +629,23 @@ bool ensure_grid(Ctx *c, Cloud &canon, double reach)
 }
 
 // posed copies: coordinates in grid order (and the grid-position -> Hilbert-position map, once per ordering)
+int grid_coords_prepare(Ctx *c, Cloud *cl, bool *ok)
+{
+  *ok = false;
+  if (!cl || !cl->grid || !cl->pose_known || cl->n == 0 || cl->grid->n != cl->n) return MVR_OK;
+  if (int rc = ensure(c, cl->gsorted, cl->gsorted_cap, cl->n)) return rc;
+  if (cl->grid->ready && !cl->grid->ready_waited) {      // built on the side stream: this is its first use on the main one
+    MVR_HIP_TRY(c, hipStreamWaitEvent(c->stream, cl->grid->ready, 0));
+    cl->grid->ready_waited = true;
+  }
+  if (cl->order && cl->grid->built_for != cl->order.get()) {
+    hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h, cl->grid->h2g);
+    cl->grid->built_for = cl->order.get();
+  }
+  *ok = true;
+  return MVR_OK;
+}
+
 int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
 {
   for (int base = 0; base < count; base += kBatchClouds) {
@@ -638,19 +655,14 @@ int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
     int used = 0;
     for (int k = 0; k < m; ++k) {
       Cloud *cl = posed[base + k];
-      if (!cl || !cl->grid || !cl->pose_known || cl->gcoords_valid || cl->n == 0 || cl->grid->n != cl->n) continue;
-      if (int rc = ensure(c, cl->gsorted, cl->gsorted_cap, cl->n)) return rc;
-      if (cl->grid->ready && !cl->grid->ready_waited) {      // built on the side stream: this is its first use on the main one
-        MVR_HIP_TRY(c, hipStreamWaitEvent(c->stream, cl->grid->ready, 0));
-        cl->grid->ready_waited = true;
-      }
-      if (cl->order && cl->grid->built_for != cl->order.get()) {
-        hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h, cl->grid->h2g);
-        cl->grid->built_for = cl->order.get();
-      }
+      if (!cl || cl->gcoords_valid) continue;
+      bool ok = false;
+      if (int rc = grid_coords_prepare(c, cl, &ok)) return rc;
+      if (!ok) continue;
       b.graw[used] = cl->grid->graw; b.out[used] = cl->gsorted; b.n[used] = cl->n;
       std::memcpy(b.T[used].m, cl->pose, sizeof b.T[used].m);
       b.Tp[used] = (c->pose_from_table && cl->pose_dev) ? &cl->pose_dev->T : nullptr;
+      if (b.Tp[used]) { if (int rc = ensure_pose_table(c)) return rc; }
       nmax = std::max(nmax, cl->n);
       cl->gcoords_valid = true;
       ++used;

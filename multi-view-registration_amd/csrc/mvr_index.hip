@@ -190,6 +190,18 @@ __device__ __forceinline__ float wave_max_f32(float v) { return wave_minmax_f32<
 __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
 {
   const int cloud = blockIdx.y;
+  // the pose straight from where the host put it (pinned memory, one 128-byte read per block), block 0 of the cloud leaving the
+  // device record behind for the launches that follow (what a launch of its own did at the head of every pass: 4 us + a gap)
+  // (whichever way the pose comes -- pinned memory, device record, kernel argument -- the block's 16 doubles go through LDS:
+  // one address space for the loop below)
+  __shared__ Mat44d s_T;
+  const double *tin = rb.Tin[cloud];
+  if (rb.from[cloud]) {
+    const double *tsrc = tin ? tin : (rb.Tp[cloud] ? rb.Tp[cloud]->m : nullptr);
+    if (threadIdx.x < 16) s_T.m[threadIdx.x] = tsrc ? tsrc[threadIdx.x] : rb.T[cloud].m[threadIdx.x];
+    __syncthreads();
+    if (tin && blockIdx.x == 0 && threadIdx.x == 0) make_pose_rec(s_T.m, reinterpret_cast<PoseRec *>(const_cast<Mat44d *>(rb.Tp[cloud])));
+  }
   const float4 *__restrict__ pts = rb.pts[cloud];
   const uint32_t *__restrict__ perm = rb.perm[cloud];
   const float4 *__restrict__ from = rb.from[cloud];
@@ -209,10 +221,16 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
       float4 v;
       if (from) {                     // posed copy of an indexed cloud: pose its sorted copy, in order
         const float4 p = from[k];
-        const Mat44d &T = rb.Tp[cloud] ? *rb.Tp[cloud] : rb.T[cloud];
+        const Mat44d &T = s_T;
         v = pose_point_f64(T, p);
         v.w = p.w;
         if (rb.xsrc[cloud]) rb.xdst[cloud][k] = pose_point_f64(T, rb.xsrc[cloud][k]);     // and the points in original order
+        if (rb.graw[cloud]) {                                                             // and in the order of the set's cell grid
+          const float4 g = rb.graw[cloud][k];
+          float4 w = pose_point_f64(T, g);
+          w.w = g.w;
+          rb.gout[cloud][k] = w;
+        }
       } else {
         const uint32_t o = perm[k];
         v = pts[o];
@@ -595,8 +613,22 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
 
 // from / T: optional, per cloud (see RefreshBatch)
 static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *const *from = nullptr, const double *T = nullptr,
-                         const float4 *const *xsrc = nullptr, const Mat44d *const *Tp = nullptr)
+                         const float4 *const *xsrc = nullptr, const Mat44d *const *Tp = nullptr, bool with_grid = false)
 {
+  // a pass enqueued ahead of its poses whose device records nobody has filled yet: this launch does it when it poses EVERY view
+  // of the table (the ordinary case: a ring pass poses all its views in one call), else the launch made for that goes first
+  bool fill_table = false;
+  if (Tp && c->pose_tab_pending) {
+    int with = 0;
+    for (int k = 0; k < count; ++k)
+      if (from && from[k] && Tp[k]) {
+        const PoseRec *r = reinterpret_cast<const PoseRec *>(Tp[k]);
+        if (r >= c->pose_tab_cur && r < c->pose_tab_cur + c->pose_tab_n && clouds[k]->n) ++with;
+      }
+    fill_table = with == c->pose_tab_n;
+    if (!fill_table && with) { if (int rc = ensure_pose_table(c)) return rc; }
+    if (fill_table) c->pose_tab_pending = false;
+  }
   for (int base = 0; base < count; base += kBatchClouds) {
     RefreshBatch rb;
     const int m = std::min(kBatchClouds, count - base);
@@ -606,8 +638,15 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
       rb.from[k] = (cl && from) ? from[base + k] : nullptr;
       if (rb.from[k]) std::memcpy(rb.T[k].m, T + (size_t)(base + k) * 16, sizeof rb.T[k].m);
       rb.Tp[k] = (rb.from[k] && Tp) ? Tp[base + k] : nullptr;
+      rb.Tin[k] = (rb.Tp[k] && fill_table) ? c->pose_in_cur + 16 * (reinterpret_cast<const PoseRec *>(rb.Tp[k]) - c->pose_tab_cur) : nullptr;
       rb.xsrc[k] = (rb.from[k] && xsrc) ? xsrc[base + k] : nullptr;
       rb.xdst[k] = rb.xsrc[k] ? cl->pts : nullptr;
+      rb.graw[k] = nullptr; rb.gout[k] = nullptr;
+      if (rb.from[k] && with_grid && !cl->gcoords_valid) {      // a posed copy whose set has a cell grid: its grid-ordered coordinates too
+        bool ok = false;
+        if (int rc = grid_coords_prepare(c, cl, &ok)) return rc;
+        if (ok) { rb.graw[k] = cl->grid->graw; rb.gout[k] = cl->gsorted; cl->gcoords_valid = true; work += 32.0 * (double)cl->n; }
+      }
       rb.pts[k] = cl ? cl->pts : nullptr; rb.perm[k] = cl ? cl->order->perm : nullptr; rb.n[k] = cl ? cl->n : 0;
       rb.sorted[k] = cl ? cl->sorted : nullptr; rb.tlo[k] = cl ? cl->tlo : nullptr; rb.thi[k] = cl ? cl->thi : nullptr;
       rb.cbox[k] = cl ? cl->cbox : nullptr; rb.sbox[k] = cl ? cl->sbox : nullptr;
@@ -646,7 +685,8 @@ int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src,
     Tps.push_back((c->pose_from_table && d->pose_dev) ? &d->pose_dev->T : nullptr);      // (an address in device memory: not read here)
     if (handled) handled[k] = 1;
   }
-  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data(), with_pts ? xsrc.data() : nullptr, Tps.data());
+  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data(), with_pts ? xsrc.data() : nullptr, Tps.data(),
+                                             c->ring_search != 0 && c->pair_fused);
 }
 
 int ensure_index(Ctx *c, Cloud &cl)

@@ -265,6 +265,13 @@ struct Ctx {
   bool pose_from_table = false;                       // mvr_cloud_transform_batch ignores its T values: every destination reads Cloud::pose_dev
   double *h_pose_in = nullptr, *d_pose_in = nullptr;  // pinned, mapped: [2][views][16] poses the host writes before it opens the gate
   PoseRec *pose_tab = nullptr; size_t pose_tab_cap = 0;      // device: [2][views]
+  // the chain being enqueued reads its poses from pose_in_cur (pinned) / pose_tab_cur (device records, n of them); pending: the records
+  // are not filled yet -- the posing launch of the chain does it on the way (refresh_batch), any other reader calls ensure_pose_table first
+  // the completion word of the chain being enqueued: stored by the final sums launch itself when that launch is the last thing
+  // of the chain (signal_armed, set by the pass loop for hosts that end a pass with the fused sums on this stream; signal_sent
+  // tells the loop that it needs no write-value operation behind the chain)
+  uint32_t *done_counter = nullptr; uint32_t signal_seq = 0; bool signal_armed = false, signal_sent = false;
+  const double *pose_in_cur = nullptr; PoseRec *pose_tab_cur = nullptr; int pose_tab_n = 0; bool pose_tab_pending = false;
   uint32_t *gate = nullptr; bool gate_is_signal = false;     // host-writable word the stream waits on (hipStreamWaitValue32)
   uint32_t *h_done = nullptr, *d_done = nullptr;      // pinned, mapped: the stream writes the pass number here when a pass's chain has drained
   bool pipe_ops_warm = false;                         // the stream's wait-value / write-value operations have been used once
@@ -366,6 +373,35 @@ __device__ __forceinline__ float4 pose_point_f64(const Mat44d &T, const float4 p
   o.w = 1.0f;
   return o;
 }
+// the device record of a pose (PoseRec) from its 16 doubles: inverse of x -> A x + t by cofactors, in double, as make_grid_pair
+// does on the host; the stretch for ANY invertible matrix (the host has checked e <= 1e-3 before it released the pass: note_pose's bar)
+__device__ __forceinline__ void make_pose_rec(const double *T, PoseRec *out)
+{
+  PoseRec r;
+  for (int j = 0; j < 16; ++j) r.T.m[j] = T[j];
+  const double A[3][3] = {{T[0], T[4], T[8]}, {T[1], T[5], T[9]}, {T[2], T[6], T[10]}};
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  const double id = 1.0 / det;
+  const double I[3][3] = {{(A[1][1] * A[2][2] - A[1][2] * A[2][1]) * id, (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id, (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id},
+                          {(A[1][2] * A[2][0] - A[1][0] * A[2][2]) * id, (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id, (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id},
+                          {(A[1][0] * A[2][1] - A[1][1] * A[2][0]) * id, (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id, (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id}};
+  for (int rr = 0; rr < 3; ++rr) {
+    for (int k = 0; k < 3; ++k) r.minv[4 * rr + k] = I[rr][k];
+    r.minv[4 * rr + 3] = -(I[rr][0] * T[12] + I[rr][1] * T[13] + I[rr][2] * T[14]);
+  }
+  double e2 = 0.0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const double d = T[4 * a] * T[4 * b] + T[4 * a + 1] * T[4 * b + 1] + T[4 * a + 2] * T[4 * b + 2];
+      const double x = d - (a == b ? 1.0 : 0.0);
+      e2 += x * x;
+    }
+  const double e = fmin(sqrt(e2), 0.5);
+  r.stretch = __double2float_ru((1.0 / sqrt(1.0 - e)) * (1.0 + 1e-6));
+  r.pad_ = 0.f;
+  *out = r;
+}
 struct RefreshBatch {
   const float4 *pts[kBatchClouds]; const uint32_t *perm[kBatchClouds]; unsigned long long n[kBatchClouds];
   float4 *sorted[kBatchClouds], *tlo[kBatchClouds], *thi[kBatchClouds], *cbox[kBatchClouds], *sbox[kBatchClouds];
@@ -375,8 +411,15 @@ struct RefreshBatch {
   // optional, with `from`: the source's points in original order and where their posed copies go (the transform itself,
   // done by the same launch)
   const float4 *xsrc[kBatchClouds]; float4 *xdst[kBatchClouds];
+  // optional, with `from`: the cloud's points in the order of its set's cell grid (canonical coordinates) and where their posed
+  // copies go -- the grid search's side of a posed copy, written by the same launch (else: refresh_grid_coords_batch)
+  const float4 *graw[kBatchClouds]; float4 *gout[kBatchClouds];
+  // optional, with Tp: the pose's 16 doubles where the host put them (pinned memory) -- every block reads them from THERE and block 0
+  // of the cloud fills the device record Tp[k] points into (PoseRec) for the launches that follow: no launch of its own for that
+  const double *Tin[kBatchClouds];
   unsigned tile_begin[kBatchClouds];       // refresh tiles from this one on (a cloud that grew at its end keeps its leading tiles)
 };
+static_assert(sizeof(RefreshBatch) <= 4096, "RefreshBatch travels as a kernel argument");
 // index of posed copies, straight from the sources' sorted copies (culled mode; called by mvr_cloud_transform_batch).
 // with_pts: also write dst->pts = T * src->pts.  handled[k] (optional) = cloud k was refreshed by this call.
 int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts = false,
@@ -495,11 +538,16 @@ int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo x
 bool ensure_grid(Ctx *c, Cloud &canon, double reach);
 int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream_t on, hipEvent_t after);      // the same for many sets at once, enqueued on `on` (no wait afterwards)      // reach: the search radius the distance map should be able to rule out (mm)
 int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
+int ensure_pose_table(Ctx *c);      // (mvr_ctx.hip) fills the device pose records of the chain being enqueued if nobody has yet
+// can the posed cloud's grid-ordered coordinates be written now (grid there and ready, buffer, position maps)?  Queues what that needs
+// on the context's stream; the caller then writes gsorted[] and sets gcoords_valid.
+int grid_coords_prepare(Ctx *c, Cloud *cl, bool *ok);      // (*ok = false: no grid to write for; the return value is a status)
 // the pipelined pass loop shared by mvr_ring_run and mvr_ring_run_sharded (mvr_ctx.hip).  enqueue(): one pass's GPU work on
 // c->stream, ending with the edge table on its way to c->h_table; solve(): the host step on c->h_table, poses in / out.
 struct PassLoop {
   int n_views = 0; const int *posed_slots = nullptr, *raw_slots = nullptr; double *poses = nullptr;     // poses: [views][16], in / out
   int (*enqueue)(void *self) = nullptr; int (*solve)(void *self) = nullptr; void *self = nullptr;
+  bool ends_with_sums = false;      // enqueue()'s last operation on the stream is the fused sums launch writing the host's table (it may carry the completion word)
   double reach = 0.0;              // the search radius of the passes (mm): with it the loop builds the scans' grids while the first pass searches
   unsigned long long sig = 0;      // identifies the registration (slots, point sets, edges, parameters): a run that ended in steady state lets the next run of the SAME registration start pipelined
 };
@@ -546,7 +594,13 @@ struct GluePair {
   int blocks = 0, by_pos = 0;
   uint32_t *zero_a = nullptr, *zero_b = nullptr, *zero_c = nullptr;          // optional: two device words the moments launch resets to 0 (the grid search's wide-list counters of this pair)
 };
-struct GlueBatch { GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal; };
+struct GlueBatch {
+  GluePair p[kBatchPairs]; double max2; double origin[3]; int reciprocal;
+  // optional: the LAST block of the final sums launch to finish stores done_seq into done_word (pinned host memory): the
+  // host of a pipelined pass loop learns from the kernel itself that the pass's table is complete, instead of from a
+  // stream write-value operation queued behind it (a packet of its own: 4 us + a 9 us gap on the critical path)
+  uint32_t *done_word = nullptr, *done_counter = nullptr; uint32_t done_seq = 0;
+};
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);
 int launch_compact_flags_batch(Ctx *c, const GlueBatch &b, int n_pairs);      // flags -> ordered list / slot / count, 3 launches for all pairs
 int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs);

@@ -533,6 +533,17 @@ __global__ void __launch_bounds__(kRT) moments2_final_batch_kernel(GlueBatch b)
     a.out[0] = s[0]; a.out[1] = b.origin[0]; a.out[2] = b.origin[1]; a.out[3] = b.origin[2];
     for (int k = 1; k < 28; ++k) a.out[3 + k] = s[k];
     a.out[31] = s[28];
+    if (b.done_word) {
+      // this block's row is on its way to the host; the last block to get here tells the host that all of them are
+      // (a dozen blocks: a dozen fences, not the thousands that made a last-block reduction of the sums themselves a loss)
+      __threadfence_system();
+      const uint32_t before = __hip_atomic_fetch_add(b.done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (before + 1u == gridDim.x) {
+        __hip_atomic_store(b.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch that counts here starts after this one has ended)
+        __threadfence_system();
+        __hip_atomic_store(b.done_word, b.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
