@@ -323,6 +323,61 @@ int solve_spd(int n, double *A, double *b, const int *row_end = nullptr)
   return MVR_OK;
 }
 
+// The same factorisation on BAND storage, for systems whose upper rows reach at most W entries from the diagonal (a ring or
+// chain of views: W = 12, one block beside the diagonal one): row j lives in band[j * S .. + W) as U(j, j .. j + W), zero up
+// to S = 2 W, so every row update below is three fixed 4-wide operations per 12 columns -- no counted loops, no scan for the
+// row ends, no dense n x n matrix to clear and copy (a 66 x 66 solve: 7k -> 3k cycles).  Element by element the operations
+// and their order are those of solve_spd (multiply, then subtract; the back substitution in column order); the only
+// additions are updates by an exact zero.  false: a pivot is not safely positive (the caller takes the dense route).
+template <int W>
+bool solve_spd_band(int n, double *band, double *b, double *dinv, double *y)
+{
+  constexpr int S = 2 * W;
+  static_assert(W % 4 == 0, "rows are walked four columns at a time");
+  double amax = 0.0;
+  for (int j = 0; j < n; ++j) amax = std::max(amax, std::fabs(band[(size_t)j * S]));
+  if (!(amax > 0.0)) return false;
+  for (int j = 0; j < n; ++j) {
+    double *Uj = band + (size_t)j * S;
+    const double d = Uj[0];
+    if (!(d > 1e-13 * amax)) return false;
+    const double ujj = std::sqrt(d), inv = 1.0 / ujj;
+    dinv[j] = inv;
+    const __m256d vinv = _mm256_set1_pd(inv);
+    for (int k = 0; k < W; k += 4) _mm256_storeu_pd(Uj + k, _mm256_mul_pd(_mm256_loadu_pd(Uj + k), vinv));
+    Uj[0] = ujj;
+    const int last = std::min(W, n - j);
+    for (int i = 1; i < last; ++i) {
+      const double f = Uj[i];
+      if (f == 0.0) continue;
+      double *Ui = band + (size_t)(j + i) * S;
+      const __m256d vf = _mm256_set1_pd(f);
+      for (int k = 0; k < W; k += 4)          // columns j + i + k: U(j, .) from offset i on (zero beyond the band)
+        _mm256_storeu_pd(Ui + k, _mm256_sub_pd(_mm256_loadu_pd(Ui + k), _mm256_mul_pd(vf, _mm256_loadu_pd(Uj + i + k))));
+    }
+  }
+  std::memcpy(y, b, (size_t)n * sizeof(double));
+  std::memset(y + n, 0, (size_t)S * sizeof(double));
+  for (int i = 0; i < n; ++i) {                       // U^T y = b, column-oriented: axpy over row i of U
+    const double yi = y[i] * dinv[i];
+    const double *Ui = band + (size_t)i * S;
+    const __m256d vy = _mm256_set1_pd(yi);
+    // (entries 1 .. W-1 of the row against y[i + 1 ..]; entry 0 is the diagonal: that lane is put back below)
+    for (int k = 0; k < W; k += 4)
+      _mm256_storeu_pd(y + i + k, _mm256_sub_pd(_mm256_loadu_pd(y + i + k), _mm256_mul_pd(_mm256_loadu_pd(Ui + k), vy)));
+    y[i] = yi;
+  }
+  for (int i = n - 1; i >= 0; --i) {                  // U x = y (a sum: kept in order)
+    const double *Ui = band + (size_t)i * S;
+    double sacc = y[i];
+    const int last = std::min(W, n - i);
+    for (int k = 1; k < last; ++k) sacc -= Ui[k] * y[i + k];
+    y[i] = sacc * dinv[i];
+  }
+  std::memcpy(b, y, (size_t)n * sizeof(double));
+  return true;
+}
+
 }  // namespace mvr
 
 using namespace mvr;
@@ -688,6 +743,15 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     for (int vj = 1; vj < n; ++vj) if (eidx[(size_t)vi * n + vj] >= 0) hi = std::max(hi, vj);
     for (int r = 0; r < 6; ++r) row_end[6 * (vi - 1) + r] = 6 * hi;
   }
+  // a ring or a chain (every neighbour of a view is the next or the previous one, or the fixed view 0): the upper rows of G
+  // reach 12 entries from the diagonal at most -- assembled and factorised on band storage (solve_spd_band)
+  constexpr int kBandW = 12;
+  int reach = 0;
+  for (int j = 0; j < dim; ++j) reach = std::max(reach, row_end[(size_t)j] - j);
+  static const bool force_dense = std::getenv("MVR_LUM_DENSE") != nullptr;       // (tests: the two routes give the same bits)
+  const bool banded = reach <= kBandW && !force_dense;
+  std::vector<double> band, bscratch;
+  if (banded) { band.resize((size_t)(dim + kBandW) * 2 * kBandW); bscratch.resize((size_t)2 * dim + 4 * kBandW); }
   std::vector<double> Tv((size_t)n * 16);
   std::vector<PoseTrig> trig((size_t)n);
   int it = 0;
@@ -722,6 +786,28 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
       const int rc = lum_edge_from_moments_T(&m2[e], &Tv[(size_t)es[e] * 16], &Tv[(size_t)et[e] * 16], MM, MZ, &ss);
       store_edge(e, rc, MM, MZ, ss);
     }
+    bool solved = false;
+    if (banded) {
+      constexpr int S = 2 * kBandW;
+      std::fill(band.begin(), band.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
+      for (int vi = 1; vi < n; ++vi)
+        for (int vj = 0; vj < n; ++vj) {            // (the order the dense assembly adds the diagonal blocks up in)
+          const int e = eidx[(size_t)vi * n + vj];
+          if (e < 0) continue;
+          const bool fwd = efwd[(size_t)vi * n + vj] != 0;
+          const double *ci = &cinv[36 * (size_t)e];
+          for (int r = 0; r < 6; ++r) {
+            double *row = &band[(size_t)(6 * (vi - 1) + r) * S];
+            if (vj > vi) for (int cc = 0; cc < 6; ++cc) row[6 * (vj - vi) + cc - r] = -ci[6 * r + cc];
+            for (int cc = r; cc < 6; ++cc) row[cc - r] += ci[6 * r + cc];
+            B[6 * (vi - 1) + r] += (fwd ? 1.0 : -1.0) * cinvd[6 * e + r];
+          }
+        }
+      // (a failed factorisation -- a pivot not safely positive -- falls back to the dense route below, which assembles G itself)
+      solved = solve_spd_band<kBandW>(dim, band.data(), B.data(), bscratch.data(), bscratch.data() + dim);
+      if (!solved) std::fill(B.begin(), B.end(), 0.0);
+    }
+    if (!solved) {
     std::fill(G.begin(), G.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
     for (int vi = 1; vi < n; ++vi)
       for (int vj = 0; vj < n; ++vj) {
@@ -736,6 +822,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
         for (int r = 0; r < 6; ++r) B[6 * (vi - 1) + r] += (fwd ? 1.0 : -1.0) * cinvd[6 * e + r];
       }
     if (solve_spd(dim, G.data(), B.data(), row_end.data()) != MVR_OK) { if (iters) *iters = it; return MVR_E_SINGULAR; }
+    }
     double sum = 0.0;
     for (int vi = 1; vi < n; ++vi) {
       double sol[6], dp[6], nrm = 0.0;

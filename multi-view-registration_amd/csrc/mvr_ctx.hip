@@ -344,6 +344,7 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_PARTS_LANES")) c->parts_lanes = std::atoi(m);
   if (const char *m = std::getenv("MVR_PARTS_MAX_ROWS")) c->parts_max_rows = std::max(1, std::atoi(m));
   if (const char *m = std::getenv("MVR_GRID_DEBUG")) c->grid_debug = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_SEQ_SEED")) c->seq_seed = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_SEQ_SEARCH")) c->seq_search = std::max(0, std::min(2, std::atoi(m)));    // align against a target made of posed scans: 1 = through the scans' grids, 0 = culled kernel
   if (const char *m = std::getenv("MVR_RING_SEARCH")) c->ring_search = std::atoi(m);   // fused pass: 1 = grid search for bounded queries, 0 = culled kernel only
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
@@ -396,6 +397,9 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   for (auto &s : c->slots) cloud_free(s);
+  for (auto &kv : c->seq_seeds) if (kv.second.d) (void)hipFree(kv.second.d);
+  c->seq_seeds.clear();
+  if (c->seed_bound) (void)hipFree(c->seed_bound);
   c->orders.clear(); c->grids.clear();
   if (c->order_pool) c->order_pool->close();          // orderings that outlive the context free their buffers themselves
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
@@ -1985,8 +1989,30 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
   if (int rc = ensure_index(c, tgt)) return rc;
   plan->qperm = cur.order->perm; plan->tinv = tgt.order->inv;
   if (!parts_forward) {
-    // forward: the culled kernel over the target's composite index (keys are written by exactly one wave per query)
-    if (int rc = launch_nn_cull(c, cur, 0, ns, nullptr, tgt, cap2, fma, c->keys)) return rc;
+    // forward: the culled kernel over the target's composite index (keys are written by exactly one wave per query) -- every
+    // query starting from the distance of the point it matched when this scan was last aligned, if it was (Ctx::seq_seed)
+    CullPair fp = make_cull_pair(cur, 0, ns, nullptr, tgt, c->keys);
+    if (c->seq_seed && nt <= 0xFFFFFFF0ull) {
+      auto it = c->seq_seeds.find(cur.set_id);
+      if (it != c->seq_seeds.end() && it->second.d && it->second.n == ns) {
+        if (int rc = ensure(c, c->seed_bound, c->seed_bound_cap, ns)) return rc;
+        if (int rc = launch_seed_to_bound(c, cur.sorted, ns, tgt.sorted, nt, it->second.d, fma, c->seed_bound)) return rc;
+        fp.qbound = c->seed_bound;
+      }
+    }
+    if (ns > 0xFFFFFFF0ull || nt > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+    if (int rc = launch_nn_cull_batch(c, &fp, 1, cap2, fma)) return rc;
+    if (c->seq_seed) {
+      if (c->seq_seeds.size() >= 256 && !c->seq_seeds.count(cur.set_id)) {      // (scans that are gone: start over rather than grow without bound)
+        MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (auto &kv : c->seq_seeds) if (kv.second.d) (void)hipFree(kv.second.d);
+        c->seq_seeds.clear();
+      }
+      Ctx::SeedBuf &sb = c->seq_seeds[cur.set_id];
+      if (int rc = ensure(c, sb.d, sb.cap, ns)) return rc;
+      sb.n = ns;
+      if (int rc = launch_keys_to_seed(c, cur.sorted, ns, c->keys, tgt.order->inv, sb.d)) return rc;
+    }
   } else {
   if (int rc = launch_nn_parts(c, cur, (int)tgt.parts.size(), cap2, fma, c->keys, c->bheavy)) return rc;
   if (c->grid_debug) {           // diagnostics: how many queries the parts could not answer
@@ -2358,6 +2384,14 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "fused_mark")) { if (value < 0 || value > 2) return MVR_E_ARG; c->fused_mark = value; }
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
   else if (!std::strcmp(key, "seq_search")) { if (value < 0 || value > 2) return MVR_E_ARG; c->seq_search = value; }
+  else if (!std::strcmp(key, "seq_seed")) {          // 0 also forgets what the aligns so far have left behind
+    c->seq_seed = value != 0;
+    if (!c->seq_seed) {
+      MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (auto &kv : c->seq_seeds) if (kv.second.d) (void)hipFree(kv.second.d);
+      c->seq_seeds.clear();
+    }
+  }
   else if (!std::strcmp(key, "parts_lanes")) { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->parts_lanes = value; }
   else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }

@@ -895,6 +895,46 @@ int launch_nn_cull(Ctx *c, const Cloud &q, size_t q_begin, size_t q_count, const
   return launch_nn_cull_batch(c, &one, 1, cap2, fma);
 }
 
+namespace {
+template <bool FMA>
+__global__ void seed_to_bound_kernel(const float4 *__restrict__ qs, uint32_t nq, const float4 *__restrict__ ts, uint32_t nt,
+                                     const uint32_t *__restrict__ seed, uint32_t *__restrict__ bound)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t prev = seed[i];
+  uint32_t v = 0xFFFFFFFFu;
+  if (prev < nt) { const float4 q = qs[i]; v = __float_as_uint(dist2<FMA>(ts[prev], q.x, q.y, q.z)); }
+  bound[i] = v;
+}
+__global__ void keys_to_seed_kernel(const float4 *__restrict__ qs, uint32_t nq, const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ tinv,
+                                    uint32_t *__restrict__ seed)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t low = (uint32_t)keys[__float_as_uint(qs[i].w)];
+  seed[i] = low != kNone ? tinv[low] : 0xFFFFFFFFu;
+}
+}  // namespace
+
+int launch_seed_to_bound(Ctx *c, const float4 *qs, size_t nq, const float4 *ts, size_t nt, const uint32_t *seed, bool fma, uint32_t *bound)
+{
+  if (nq == 0) return MVR_OK;
+  const unsigned blocks = (unsigned)((nq + 255) / 256);
+  if (fma) hipLaunchKernelGGL(seed_to_bound_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, qs, (uint32_t)nq, ts, (uint32_t)nt, seed, bound);
+  else hipLaunchKernelGGL(seed_to_bound_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, qs, (uint32_t)nq, ts, (uint32_t)nt, seed, bound);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
+int launch_keys_to_seed(Ctx *c, const float4 *qs, size_t nq, const nnkey_t *keys, const uint32_t *tinv, uint32_t *seed)
+{
+  if (nq == 0) return MVR_OK;
+  hipLaunchKernelGGL(keys_to_seed_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, c->stream, qs, (uint32_t)nq, keys, tinv, seed);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
 CullPair make_cull_pair(const Cloud &q, size_t q_begin, size_t q_count, const uint8_t *qflags, const Cloud &t, nnkey_t *keys)
 {
   CullPair p;

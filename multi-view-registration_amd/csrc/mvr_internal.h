@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "mvr_hip.h"
@@ -181,6 +182,14 @@ struct Ctx {
   std::map<uint64_t, std::weak_ptr<Order> > orders;   // set_id -> ordering (shared between posed copies)
   std::map<uint64_t, std::weak_ptr<CellGrid> > grids;     // set_id -> uniform grid (shared between posed copies)
   int grid_light_rows = 12;                           // grid search (default = kGridLightRows): rows of cells a thread walks itself; wider balls leave for a wave of their own or for the culled kernel
+  // mvr_icp_align of a posed scan remembers, per point set, where each query's match sat in the target (sorted position) and
+  // starts the NEXT align of that scan from the distance of that point under the current coordinates: the sweeps of the sequential
+  // mode (registrator.cpp:530-577, repeat_times of them) and the rounds of AutoReg align the same scans again and again against a
+  // model that has barely moved.  Any target point gives a valid inclusive bound, so a stale seed costs time, never exactness.
+  int seq_seed = 1;
+  struct SeedBuf { uint32_t *d = nullptr; size_t n = 0, cap = 0; };
+  std::unordered_map<unsigned long long, SeedBuf> seq_seeds;      // by the source's point-set id
+  uint32_t *seed_bound = nullptr; size_t seed_bound_cap = 0;
   int seq_search = 1;                                 // mvr_icp_align of a posed scan: 1 (default) = the REVERSE searches walk the source scan's cell grid (compaction by the fused pass's kernels, no hipCUB), the forward search stays with the culled kernel; 2 = the forward search too, through the grids of the posed scans the target is made of (nn_parts_kernel: exact, measured slower -- DESIGN.md 4.5); 0 = the culled kernel for both
   int parts_lanes = 0, parts_max_rows = 25;           // nn_parts_kernel: lanes per query (1, 2, 4, 8; 0 = by the number of parts) and the widest ball (rows of cells) a lane walks itself
   int ring_search = 1;                                // fused pass: 1 = seeded searches walk the uniform grid (thread per query), 0 = always the culled kernel
@@ -610,6 +619,11 @@ int reduce_blocks_for(const Ctx *c, size_t n);
 int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                        const uint32_t *tinv, size_t nt, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *slot);
 // bound[sorted target position] = bits of the forward d2 of a source that matched it (~0: none): where the reverse search of a matched target starts
+// seeds of an align's forward searches (mvr_cull.hip): bound[q] = bits of the distance from query q (sorted position) to target point
+// seed[q] (sorted position; >= nt: none -> ~0), with the searches' own formula; and the seeds an align leaves behind: the sorted
+// position of every query's match (keys by ORIGINAL index, low word = the match's original index)
+int launch_seed_to_bound(Ctx *c, const float4 *qs, size_t nq, const float4 *ts, size_t nt, const uint32_t *seed, bool fma, uint32_t *bound);
+int launch_keys_to_seed(Ctx *c, const float4 *qs, size_t nq, const nnkey_t *keys, const uint32_t *tinv, uint32_t *seed);
 int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                        const uint32_t *tinv, size_t nt, uint32_t *bound);
 // culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)

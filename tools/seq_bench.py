@@ -71,6 +71,12 @@ def main():
         for name, mode in (("culled", 1),) + ((("brute", 0),) if not a.no_brute else ()):
             ctx.tune(nn_mode=mode)
             gpu_sweep(mvr, ctx, scans, poses0, params, order, 1)                     # warm-up (allocations, sorts)
+            # the warm-up aligned the same scans from the same poses: what it left for the next aligns' searches to start from
+            # (seq_seed) is forgotten, so that the timed run's FIRST sweep is a first sweep and only its later ones are seeded
+            seeds = int(os.environ.get("MVR_SEQ_SEED", "1"))
+            ctx.tune(seq_seed=0)
+            if seeds:
+                ctx.tune(seq_seed=1)
             poses, log, dt = gpu_sweep(mvr, ctx, scans, poses0, params, order, a.repeat)
             per = len(order)
             out["gpu_%s" % name] = dict(total_s=dt, ms_per_align=1e3 * dt / len(log), queries_per_s=N * len(log) / dt,
