@@ -1988,33 +1988,26 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
   if (int rc = ensure_index(c, cur)) return rc;
   if (int rc = ensure_index(c, tgt)) return rc;
   plan->qperm = cur.order->perm; plan->tinv = tgt.order->inv;
-  if (!parts_forward) {
-    // forward: the culled kernel over the target's composite index (keys are written by exactly one wave per query) -- every
-    // query starting from the distance of the point it matched when this scan was last aligned, if it was (Ctx::seq_seed)
+  if (ns > 0xFFFFFFF0ull || nt > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+  // every query starts from the distance of the point it matched when this scan was last aligned, if it was (Ctx::seq_seed)
+  const uint32_t *qb = nullptr;
+  if (c->seq_seed) {
+    auto it = c->seq_seeds.find(cur.set_id);
+    if (it != c->seq_seeds.end() && it->second.d && it->second.n == ns) {
+      if (int rc = ensure(c, c->seed_bound, c->seed_bound_cap, ns)) return rc;
+      if (int rc = launch_seed_to_bound(c, cur.sorted, ns, tgt.sorted, nt, it->second.d, fma, c->seed_bound)) return rc;
+      qb = c->seed_bound;
+    }
+  }
+  // seq_search 2: forward through the parts' grids (measured slower)
+  const bool through_parts = parts_forward && c->seq_search == 2;
+  if (!through_parts) {
+    // forward: the culled kernel over the target's composite index (keys are written by exactly one wave per query)
     CullPair fp = make_cull_pair(cur, 0, ns, nullptr, tgt, c->keys);
-    if (c->seq_seed && nt <= 0xFFFFFFF0ull) {
-      auto it = c->seq_seeds.find(cur.set_id);
-      if (it != c->seq_seeds.end() && it->second.d && it->second.n == ns) {
-        if (int rc = ensure(c, c->seed_bound, c->seed_bound_cap, ns)) return rc;
-        if (int rc = launch_seed_to_bound(c, cur.sorted, ns, tgt.sorted, nt, it->second.d, fma, c->seed_bound)) return rc;
-        fp.qbound = c->seed_bound;
-      }
-    }
-    if (ns > 0xFFFFFFF0ull || nt > 0xFFFFFFF0ull) return set_error(c, MVR_E_ARG, "cloud too large for 32-bit indices");
+    fp.qbound = qb;
     if (int rc = launch_nn_cull_batch(c, &fp, 1, cap2, fma)) return rc;
-    if (c->seq_seed) {
-      if (c->seq_seeds.size() >= 256 && !c->seq_seeds.count(cur.set_id)) {      // (scans that are gone: start over rather than grow without bound)
-        MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (auto &kv : c->seq_seeds) if (kv.second.d) (void)hipFree(kv.second.d);
-        c->seq_seeds.clear();
-      }
-      Ctx::SeedBuf &sb = c->seq_seeds[cur.set_id];
-      if (int rc = ensure(c, sb.d, sb.cap, ns)) return rc;
-      sb.n = ns;
-      if (int rc = launch_keys_to_seed(c, cur.sorted, ns, c->keys, tgt.order->inv, sb.d)) return rc;
-    }
   } else {
-  if (int rc = launch_nn_parts(c, cur, (int)tgt.parts.size(), cap2, fma, c->keys, c->bheavy)) return rc;
+  if (int rc = launch_nn_parts(c, cur, (int)tgt.parts.size(), cap2, fma, c->keys, c->bheavy, qb)) return rc;
   if (c->grid_debug) {           // diagnostics: how many queries the parts could not answer
     std::vector<uint8_t> hv(ns);
     MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2025,9 +2018,21 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
   }
   {   // the flagged queries: the culled kernel over the composite index, keys by SORTED position into rkeys[], then merged
     CullPair p = make_cull_pair(cur, 0, ns, c->bheavy, tgt, c->rkeys);
+    p.qbound = qb;
     if (int rc = launch_nn_cull_batch(c, &p, 1, cap2, fma)) return rc;
     if (int rc = launch_merge_flagged_keys(c, cur.sorted, c->bheavy, c->rkeys, ns, c->keys)) return rc;
   }
+  }
+  if (c->seq_seed) {
+    if (c->seq_seeds.size() >= 256 && !c->seq_seeds.count(cur.set_id)) {      // (scans that are gone: start over rather than grow without bound)
+      MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (auto &kv : c->seq_seeds) if (kv.second.d) (void)hipFree(kv.second.d);
+      c->seq_seeds.clear();
+    }
+    Ctx::SeedBuf &sb = c->seq_seeds[cur.set_id];
+    if (int rc = ensure(c, sb.d, sb.cap, ns)) return rc;
+    sb.n = ns;
+    if (int rc = launch_keys_to_seed(c, cur.sorted, ns, c->keys, tgt.order->inv, sb.d)) return rc;
   }
   if (!reciprocal || nt == 0) return MVR_OK;
   // reverse: the distinct matched targets, each starting from the distance of the source that matched it

@@ -963,7 +963,7 @@ namespace {
 template <bool FMA, int G>
 __global__ void __launch_bounds__(256) nn_parts_kernel(const float4 *__restrict__ qs, uint32_t nq, const PartDesc *__restrict__ parts, int n_parts,
                                                        float cap2, int max_rows, nnkey_t *__restrict__ keys, uint8_t *__restrict__ heavy,
-                                                       unsigned long long *__restrict__ evals)
+                                                       const uint32_t *__restrict__ qbound, unsigned long long *__restrict__ evals)
 {
   const uint32_t pos = (blockIdx.x * 256u + threadIdx.x) / G;
   const int sub = (int)(threadIdx.x % G);
@@ -975,6 +975,10 @@ __global__ void __launch_bounds__(256) nn_parts_kernel(const float4 *__restrict_
   float bd = cap2;                   // nothing beyond it is wanted; AT it, it is (inclusive)
   uint32_t bi = kNone;
   bool in_reach = false, too_wide = false;
+  // a query that comes WITH a bound (the distance, now, of the point it matched when this scan was last aligned: some target
+  // point lies within it) needs no probe: phase B at once
+  bool seeded = false;
+  if (live && qbound) { const uint32_t v = qbound[pos]; if (v <= __float_as_uint(cap2)) { bd = __uint_as_float(v); seeded = true; } }
   auto map_into = [&](const PartDesc &a, float &rx, float &ry, float &rz, float &slack) {
     rx = (float)(((a.minv[0] * qx + a.minv[1] * qy) + a.minv[2] * qz) + a.minv[3]);
     ry = (float)(((a.minv[4] * qx + a.minv[5] * qy) + a.minv[6] * qz) + a.minv[7]);
@@ -1023,7 +1027,7 @@ __global__ void __launch_bounds__(256) nn_parts_kernel(const float4 *__restrict_
   // query (d = 0 before d = 1) is probed -- the 27 cells around the query -- by the lane that owns it; should that probe
   // find nothing within the cap, the next candidate is tried.
   uint32_t cand_mask = 0;            // bit j: this lane's j-th part (k = sub + j G) has d <= 1; bit 16 + j: d == 0
-  if (live) {
+  if (live && !seeded) {
     int j = 0;
     for (int k = sub; k < n_parts; k += G, ++j) {
       const PartDesc &a = parts[k];
@@ -1062,7 +1066,7 @@ __global__ void __launch_bounds__(256) nn_parts_kernel(const float4 *__restrict_
     share();
     if (bi != kNone) break;                                // (uniform: shared)
   }
-  const bool have = bi != kNone;     // (uniform over the group)
+  const bool have = seeded || bi != kNone;     // (uniform over the group)
   // ---- B: the exact ball of the bound, in every part that can reach into it
   if (live && have) {
     for (int k = sub; k < n_parts; k += G) {
@@ -1155,7 +1159,7 @@ int fill_part_coords(Ctx *c, Cloud &target, GridPart &part)
   return MVR_OK;
 }
 
-int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnkey_t *keys, uint8_t *heavy)
+int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnkey_t *keys, uint8_t *heavy, const uint32_t *qbound)
 {
   if (q.n == 0 || count <= 0) return MVR_OK;
   const bool per_launch = c->prof && !c->prof_totals;
@@ -1166,7 +1170,7 @@ int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnk
   if (c->parts_lanes == 1 || c->parts_lanes == 2 || c->parts_lanes == 4 || c->parts_lanes == 8) lanes = c->parts_lanes;
   const unsigned blocks = (unsigned)((q.n * (size_t)lanes + 255) / 256);
   const int max_rows = c->parts_max_rows;      // a ball that still spans more rows of cells than this goes to the culled kernel
-#define MVR_PARTS_LAUNCH(F, GG) hipLaunchKernelGGL((nn_parts_kernel<F, GG>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q.n, c->d_parts, count, cap2, max_rows, keys, heavy, c->evals)
+#define MVR_PARTS_LAUNCH(F, GG) hipLaunchKernelGGL((nn_parts_kernel<F, GG>), dim3(blocks), dim3(256), 0, c->stream, q.sorted, (uint32_t)q.n, c->d_parts, count, cap2, max_rows, keys, heavy, qbound, c->evals)
   switch (lanes) {
     case 1: if (fma) MVR_PARTS_LAUNCH(true, 1); else MVR_PARTS_LAUNCH(false, 1); break;
     case 2: if (fma) MVR_PARTS_LAUNCH(true, 2); else MVR_PARTS_LAUNCH(false, 2); break;

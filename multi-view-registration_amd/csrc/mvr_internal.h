@@ -580,7 +580,7 @@ struct PartDesc {
 // forward search of the queries q.sorted[0, nq) in the `count` parts described at c->d_parts: keys[original query index] =
 // (d2 bits, COMPOSITE original target index), kKeyInit = nothing within cap2; heavy[sorted position] = 1 for the queries
 // that were NOT answered here (an unbounded ball too wide to walk): the culled kernel takes those
-int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnkey_t *keys, uint8_t *heavy);
+int launch_nn_parts(Ctx *c, const Cloud &q, int count, float cap2, bool fma, nnkey_t *keys, uint8_t *heavy, const uint32_t *qbound = nullptr);
 int fill_part_coords(Ctx *c, Cloud &target, GridPart &part);
 // keys[original index of sorted[pos]] = by_pos[pos] for the flagged positions (the culled kernel answers flagged queries by sorted position)
 int launch_merge_flagged_keys(Ctx *c, const float4 *sorted, const uint8_t *flags, const nnkey_t *by_pos, size_t n, nnkey_t *keys);      // target.gsorted[part.base ...] <- the part's coordinates in its grid's order

@@ -205,15 +205,16 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
     # ... the same without the seeds one align of a scan leaves for the next (seq_seed: the forward searches of a sweep start from
     # the matches of the sweep before) -- three sweeps, so that seeds left by seeded searches are used as well
     seeded = []
-    for seed in (1, 0):
+    for seed, mode in ((1, 1), (0, 1), (1, 2), (1, 0)):      # (the seeds serve the culled kernel and the walk through the parts' grids alike)
         with mvr.Context(0) as ctx:
-            ctx.tune(seq_seed=seed)
+            ctx.tune(seq_seed=seed, seq_search=mode)
             for v in range(V):
                 ctx.upload(16 + v, scans[v])
             poses, log, merged = _sequential(mvr, ctx, scans, poses0, params, 3, V)
             seeded.append((np.asarray(poses).tobytes(), log, merged.tobytes()))
-    assert seeded[0][1] == seeded[1][1], case
-    assert seeded[0][0] == seeded[1][0] and seeded[0][2] == seeded[1][2], case
+    for r in seeded[1:]:
+        assert seeded[0][1] == r[1], case
+        assert seeded[0][0] == r[0] and seeded[0][2] == r[2], case
     # ... and against the oracle: the first align's correspondences, one by one
     with mvr.Context(0) as ctx:
         for v in range(V):

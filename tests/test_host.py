@@ -125,6 +125,54 @@ def test_moments2_to_moments_and_lum_edge(mvr, orc):
         assert abs(ssg - ss) <= 1e-7 * ss
 
 
+_LUM_BAND_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import importlib
+mvr = importlib.import_module("multi-view-registration_amd")
+out = []
+for V, chain in ((3, False), (4, False), (12, False), (12, True), (36, False)):
+    rng = np.random.default_rng(V)
+    origin = np.array([-13.4, 50.2, 917.5])
+    edges = [(i, (i + 1) %% V) for i in range(V if not chain else V - 1)]
+    m2 = []
+    for e, (s_, t_) in enumerate(edges):
+        p = rng.normal(size=(3000, 3)) * 40 + origin
+        a = 0.002 * (e + 1)
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        q = (p - origin) @ R.T + origin + rng.normal(size=p.shape) * 0.1 + 0.01 * e
+        pc, qc = p - origin, q - origin
+        row = np.zeros(32); row[0] = len(p); row[1:4] = origin; row[4:7] = pc.sum(0); row[7:10] = qc.sum(0)
+        sym = lambda m: [m[0, 0], m[0, 1], m[0, 2], m[1, 1], m[1, 2], m[2, 2]]
+        row[10:16] = sym(pc.T @ pc); row[16:22] = sym(qc.T @ qc); row[22:31] = (pc.T @ qc).ravel()
+        m2.append(mvr.moments2_from_row(row))
+    rc, P, its = mvr.lum_compute(V, edges, m2, max_iterations=16)
+    out.append("%%d %%d %%d %%s" %% (V, rc, its, hashlib.sha256(np.asarray(P).tobytes()).hexdigest()))
+print("\n".join(out))
+"""
+
+
+def test_lum_band_route_gives_the_bits_of_the_dense_one():
+    """rings and chains of views: mvr_lum_compute assembles the normal equations on band storage and factorises them there
+    (solve_spd_band); MVR_LUM_DENSE=1 forces the dense matrix and solve_spd.  Same operations in the same order: the
+    poses must be the same bytes (3 ... 36 views, 16 iterations)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for dense in ("", "1"):
+        env = dict(os.environ)
+        env.pop("MVR_LUM_DENSE", None)
+        if dense:
+            env["MVR_LUM_DENSE"] = dense
+        r = subprocess.run([sys.executable, "-c", _LUM_BAND_SCRIPT % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(r.stdout.strip().splitlines())
+    assert len(runs[0]) == 5 and runs[0] == runs[1], (runs[0], runs[1])
+    for line in runs[0]:
+        assert line.split()[1] == "0", line
+
+
 def test_lum_edge_four_at_once_is_bit_identical_to_the_scalar_function(mvr):
     """mvr_lum_compute sends its edges four at a time through an AVX2 pass (one edge per lane): every lane must give
     the bytes of the scalar LUM::computeEdge -- and a group with a degenerate edge must be refused (-> scalar path)."""
