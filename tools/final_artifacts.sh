@@ -63,7 +63,13 @@ P
   for k in "pipeline=1" "pipeline=0" "pipeline=1" "pipeline=0" "pipeline=1 ring_search=0" "pipeline=0 ring_search=0"; do
     MVR_PROBE_PROF=0 timeout -k 10 120 python3 tools/step_probe.py 12 200000 40 25 $k >> $O/ab_pipeline_ring_search.log 2>> $O/ab.err || exit 1
   done
-  for m in 1 0 2 1 0 2; do MVR_SEQ_SEARCH=$m timeout -k 10 200 python3 tools/seq_bench.py --no-cpu --no-brute --repeat 2 2>> $O/ab.err | sed "s/^/seq_search=$m /" >> $O/ab_seq_search.log; done
+  for m in 1 0 2 1 0 2; do MVR_SEQ_SEED=0 MVR_SEQ_SEARCH=$m timeout -k 10 200 python3 tools/seq_bench.py --no-cpu --no-brute --repeat 2 2>> $O/ab.err | sed "s/^/seq_search=$m /" >> $O/ab_seq_search.log; done
+  # the sequential mode as the reference runs it (repeat_times = 5): ms per align by sweep, with and without the seeds an align leaves
+  for m in 1 0 1 0; do MVR_SEQ_SEED=$m timeout -k 10 200 python3 tools/seq_bench.py --no-cpu --no-brute --repeat 5 2>> $O/ab.err | sed "s/^/seq_seed=$m /" >> $O/ab_seq_seed.log; done
+  # one bench-like window pass by pass: 20 passes restarted from the prior in a warm context
+  MVR_PROBE_PASSLOG=1 MVR_PROBE_PROF=0 timeout -k 10 120 python3 tools/step_probe.py 12 200000 20 25 > $O/window_pass_log.json 2>> $O/ab.err
+  # timeline of the steady passes WITHOUT the per-launch instrumentation of the probe (no fill / copy operations between the kernels)
+  MVR_PROBE_PROF=0 timeout -k 10 200 tools/timeline.sh final_noprof pipeline=1 > $O/step_timeline_pipelined_plain.txt || exit 1
   # a registration from a standing start, in a warm process (second context): per-pass wall times, with the host stopwatch
   MVR_TRACE_HOST=1 timeout -k 10 200 python3 tools/cold_probe.py 12 200000 12 one_call=1 reps=2 > $O/cold_registration.jsonl 2> $O/cold_host_trace.txt || exit 1
   timeout -k 10 200 python3 tools/cold_probe.py 12 200000 12 one_call=1 reps=2 pipeline=0 >> $O/cold_registration.jsonl 2>> $O/ab.err

@@ -37,4 +37,5 @@ with mvr.Context(0) as ctx:
     launches, ms, evals = ctx.prof_get(mvr.K_NN)
     print(json.dumps(dict(views=V, n=n, steps=steps, warm=warm, knobs=knobs, lib=os.environ.get("MVR_LIB_VARIANT", "default"), ms_per_step=1e3 * dt / steps, nn_launches=launches, nn_ms=ms,
                           nn_evals=evals, ms_per_launch=ms / max(launches, 1), evals_per_launch=evals / max(launches, 1),
-                          n_corr=sum(info["pair_n"]), timing_ms=[t / steps for t in info["timing_ms"]])))
+                          n_corr=sum(info["pair_n"]), timing_ms=[t / steps for t in info["timing_ms"]],
+                          **({"pass_ms": [round(v, 4) for v in ctx.pass_log()], "piped": ctx.stat("piped_passes")} if os.environ.get("MVR_PROBE_PASSLOG") else {}))))
