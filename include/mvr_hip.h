@@ -442,6 +442,11 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * "pipeline" (1, default: mvr_ring_run / mvr_ring_run_sharded enqueue pass k+1's whole launch chain while pass k runs,
  * behind a hipStreamWaitValue32 gate the host opens after its solve, the poses reaching the kernels through a device table,
  * once a pass has run without allocating or waiting; 0: every pass is enqueued after the previous solve; also MVR_PIPELINE);
+ * the aligns of the sequential mode: "seq_search" (mvr_icp_align of a posed scan against a model made of posed scans: 1, default:
+ * the reverse searches walk the source scan's cell grid; 2: the forward search goes through the merged scans' grids as well; 0:
+ * the culled kernel both ways), "seq_seed" (1, default: an align's forward searches start from the distance, now, of the point
+ * each query matched when the same scan was last aligned on this context -- the sweeps of registrationICP, the rounds of
+ * AutoReg; 0: off, and what the aligns so far have left is forgotten);
  * multi-GPU: "wait_timeout_ms" (how long a rank waits for a pass that contains a collective before it aborts its
  * communicator), and the test hooks "inject_fail_pass" / "inject_stall_pass" (the k-th sharded pass or iteration from now:
  * this rank's local work fails / its stream stalls in front of the collective as if a peer never arrived; -1: off).
