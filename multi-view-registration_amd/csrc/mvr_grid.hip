@@ -226,11 +226,12 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }      // (the same point, read from the array the walk is about to read)
     }
     // the ball in the target's canonical frame (the mapping itself is done in double)
-    const Ball ball = grid_ball(a, q, bound);
-    const float rad = ball.rad, rx = ball.rx, ry = ball.ry, rz = ball.rz;
-    const int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
-    const int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
-    const int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+    Ball ball = grid_ball(a, q, bound);
+    const float rx = ball.rx, ry = ball.ry, rz = ball.rz;
+    float rad = ball.rad;
+    int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+    int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+    int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
     bool worth = true;
     if (!seeded) {
       // nothing known: is any target point near at all?  The query's own cell (clamped into the grid) is dt cells from the
@@ -241,10 +242,95 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       const float least = (d == 255u ? (float)a.dt_max : (float)d - 1.f) * a.h;
       worth = !(least > rad);
     }
-    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    // the candidate so far and the walk of a box of cells [x0, x1] x [y0, y1] x [z0, z1]: rows of cells (x-runs: ONE contiguous
+    // range of the grid-ordered array each); the next row's range is requested while this row's points are evaluated.
+    // (a row's range = two entries of the cell-start array at most three cells apart in all but the widest balls:
+    // ONE 16-byte load from the first of them brings both)
+    float bd = bound;                 // candidates beyond the bound cannot be the answer; at the bound they can (inclusive)
+    uint32_t bi = kNone, bk = 0;
+    auto walk_box = [&](const int wx0, const int wx1, const int wy0, const int wy1, const int wz0, const int wz1) {
+      const uint32_t nxm = (uint32_t)(wx1 - wx0);
+      auto row_range = [&](uint32_t row, uint32_t &s, uint32_t &e) {
+#if MVR_GRID_ROW4
+        const Start4 v = *reinterpret_cast<const Start4 *>(a.start + row + (uint32_t)wx0);
+        s = v.a;
+        e = nxm == 0u ? v.b : nxm == 1u ? v.c : v.d;
+        if (nxm > 2u) e = a.start[row + (uint32_t)wx1 + 1u];
+#else
+        s = a.start[row + (uint32_t)wx0]; e = a.start[row + (uint32_t)wx1 + 1u];
+#endif
+      };
+      const int ny = wy1 - wy0 + 1, nrows = ny * (wz1 - wz0 + 1);
+      uint32_t s, e;
+      uint32_t row = (uint32_t)((wz0 * a.dim[1] + wy0) * a.dim[0]);          // rows in y-major order: the next one is dim[0] further, or at the next z
+      const uint32_t row_step = (uint32_t)a.dim[0], z_step = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
+      int yy = 0;
+      row_range(row, s, e);
+      for (int it = 0; it < nrows; ++it) {
+        uint32_t s2 = 0, e2 = 0;
+        if (it + 1 < nrows) {
+          row += row_step;
+          if (++yy == ny) { yy = 0; row += z_step; }
+          row_range(row, s2, e2);
+        }
+        if (sub == 0) n_eval += e - s;
+        if (G == 1) {
+          // one lane per query: the points four at a time (a short row repeats its last point: re-evaluating a point
+          // changes nothing)
+          for (uint32_t k = s; k < e; k += 4) {
+            const uint32_t last = e - 1u;
+            const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
+            const float4 t0 = a.gts[k], t1 = a.gts[k1], t2 = a.gts[k2], t3 = a.gts[k3];
+            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
+            const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
+            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
+            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
+            if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; bk = k2; }
+            if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; bk = k3; }
+          }
+        } else {
+          // G lanes per query: they take CONSECUTIVE points of the row -- one instruction, one cache line per query
+          // (what a gather costs in the L1 is the number of distinct lines its lanes touch, not the bytes per lane:
+          // tools/exp_ta.hip), two rounds in flight
+          for (uint32_t k = s + sub; k < e; k += 2 * G) {
+            const uint32_t k1 = k + G < e ? k + G : k;
+            const float4 t0 = a.gts[k], t1 = a.gts[k1];
+            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
+            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w);
+            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
+            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
+          }
+        }
+        s = s2; e = e2;
+      }
+    };
+    int nrows = (y1 - y0 + 1) * (z1 - z0 + 1);
+    bool wide = worth && nrows > batch.light_rows;
+    if (G == 1 && wide && batch.probe) {
+      // A wide ball is a LOOSE bound more often than a far neighbour: the seed of a pass after a large motion (the first passes
+      // of a registration, a restart) is the old match, a millimetre or two off, while the nearest point is where it always
+      // is -- in the cell next to the query.  So before the query leaves for the slow lanes: the 2 x 2 x 2 cells nearest to it
+      // (its own and, per axis, the neighbour on the side it leans to -- four short rows).  Whatever that finds is a point of
+      // the target: its distance is a valid (inclusive) bound, and the ball of THAT bound is what is walked or handed on.
+      const float fx = (rx - a.lo[0]) * a.inv_h, fy = (ry - a.lo[1]) * a.inv_h, fz = (rz - a.lo[2]) * a.inv_h;
+      const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
+      const int px0 = max(cx - (fx - (float)cx < 0.5f ? 1 : 0), 0), px1 = min(px0 + 1, a.dim[0] - 1);
+      const int py0 = max(cy - (fy - (float)cy < 0.5f ? 1 : 0), 0), py1 = min(py0 + 1, a.dim[1] - 1);
+      const int pz0 = max(cz - (fz - (float)cz < 0.5f ? 1 : 0), 0), pz1 = min(pz0 + 1, a.dim[2] - 1);
+      walk_box(px0, px1, py0, py1, pz0, pz1);
+      if (bi != kNone) {              // (bd <= the old bound: the walk only takes candidates within it)
+        ball = grid_ball(a, q, bd);
+        rad = ball.rad;
+        x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]); x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+        y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]); y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+        z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]); z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+        nrows = (y1 - y0 + 1) * (z1 - z0 + 1);
+        wide = nrows > batch.light_rows;       // (still wide: it goes where it would have gone without the probe)
+      }
+    }
     // wide balls are not walked here: without a bound they come in clusters (the rim of the overlap) and go to the culled
     // kernel, which answers 64 neighbouring queries at once; with a bound they are scattered and get a wave each
-    const bool wide = worth && nrows > batch.light_rows;
     bool to_cull = wide && a.heavy != nullptr && (!seeded || a.wide_list == nullptr);
     if (G == 1 && a.heavy != nullptr && a.wide_list != nullptr) {
       // ... unless the wave is full of them (a stretch of rim whose matches lie far: the same 64 queries are one set of the culled kernel)
@@ -254,69 +340,10 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     if (a.heavy && sub == 0) a.heavy[a.qlist ? pos : qpos] = to_cull ? 1 : 0;
     went_wide = to_wave && sub == 0;
     went_cull = to_cull;
+    // (a wide query that goes on with a bound from the probe: the launch that answers it starts from the start bound or the
+    // seed again -- it finds the probe's point itself; what the probe saves there is nothing, what it costs is four short rows)
     if (!to_cull && !to_wave) {
-      float bd = bound;                 // candidates beyond the bound cannot be the answer; at the bound they can (inclusive)
-      uint32_t bi = kNone, bk = 0;
-      if (worth) {
-        // rows of cells (x-runs: ONE contiguous range of the grid-ordered array each); the next row's range is requested
-        // while this row's points are evaluated.
-        // (a row's range = two entries of the cell-start array at most three cells apart in all but the widest balls:
-        // ONE 16-byte load from the first of them brings both)
-        const uint32_t nxm = (uint32_t)(x1 - x0);
-        auto row_range = [&](uint32_t row, uint32_t &s, uint32_t &e) {
-#if MVR_GRID_ROW4
-          const Start4 v = *reinterpret_cast<const Start4 *>(a.start + row + (uint32_t)x0);
-          s = v.a;
-          e = nxm == 0u ? v.b : nxm == 1u ? v.c : v.d;
-          if (nxm > 2u) e = a.start[row + (uint32_t)x1 + 1u];
-#else
-          s = a.start[row + (uint32_t)x0]; e = a.start[row + (uint32_t)x1 + 1u];
-#endif
-        };
-        uint32_t s, e;
-        uint32_t row = (uint32_t)((z0 * a.dim[1] + y0) * a.dim[0]);          // rows in y-major order: the next one is dim[0] further, or at the next z
-        const uint32_t row_step = (uint32_t)a.dim[0], z_step = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
-        int yy = 0;
-        row_range(row, s, e);
-        for (int it = 0; it < nrows; ++it) {
-          uint32_t s2 = 0, e2 = 0;
-          if (it + 1 < nrows) {
-            row += row_step;
-            if (++yy == ny) { yy = 0; row += z_step; }
-            row_range(row, s2, e2);
-          }
-          if (sub == 0) n_eval += e - s;
-          if (G == 1) {
-            // one lane per query: the points four at a time (a short row repeats its last point: re-evaluating a point
-            // changes nothing)
-            for (uint32_t k = s; k < e; k += 4) {
-              const uint32_t last = e - 1u;
-              const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
-              const float4 t0 = a.gts[k], t1 = a.gts[k1], t2 = a.gts[k2], t3 = a.gts[k3];
-              const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
-              const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
-              const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
-              if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
-              if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
-              if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; bk = k2; }
-              if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; bk = k3; }
-            }
-          } else {
-            // G lanes per query: they take CONSECUTIVE points of the row -- one instruction, one cache line per query
-            // (what a gather costs in the L1 is the number of distinct lines its lanes touch, not the bytes per lane:
-            // tools/exp_ta.hip), two rounds in flight
-            for (uint32_t k = s + sub; k < e; k += 2 * G) {
-              const uint32_t k1 = k + G < e ? k + G : k;
-              const float4 t0 = a.gts[k], t1 = a.gts[k1];
-              const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
-              const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w);
-              if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
-              if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
-            }
-          }
-          s = s2; e = e2;
-        }
-      }
+      if (worth) walk_box(x0, x1, y0, y1, z0, z1);
       // the group's answer: the smallest (d2, index) of its lanes
 #pragma unroll
       for (int o = 1; o < G; o <<= 1) {
@@ -724,6 +751,7 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     batch.cap2 = cap2;
     batch.light_rows = c->grid_light_rows;
     batch.cluster = c->grid_cluster;
+    batch.probe = c->grid_probe;
     if (total == 0) continue;
     map.n_pairs = (uint32_t)m;
     unsigned grid_blocks = 0;
