@@ -2401,6 +2401,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
   else if (!std::strcmp(key, "grid_probe")) c->grid_probe = value != 0;
+  else if (!std::strcmp(key, "pose_prep_launch")) c->pose_prep_launch = value != 0;
   else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;
   else if (!std::strcmp(key, "grid_debug")) c->grid_debug = value != 0;
   else if (!std::strcmp(key, "cull_list")) c->cull_list = value != 0;

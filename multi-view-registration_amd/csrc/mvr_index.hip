@@ -625,7 +625,7 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
         const PoseRec *r = reinterpret_cast<const PoseRec *>(Tp[k]);
         if (r >= c->pose_tab_cur && r < c->pose_tab_cur + c->pose_tab_n && clouds[k]->n) ++with;
       }
-    fill_table = with == c->pose_tab_n;
+    fill_table = with == c->pose_tab_n && !c->pose_prep_launch;
     if (!fill_table && with) { if (int rc = ensure_pose_table(c)) return rc; }
     if (fill_table) c->pose_tab_pending = false;
   }

@@ -281,6 +281,7 @@ struct Ctx {
   // of the chain (signal_armed, set by the pass loop for hosts that end a pass with the fused sums on this stream; signal_sent
   // tells the loop that it needs no write-value operation behind the chain)
   uint32_t *done_counter = nullptr; uint32_t signal_seq = 0; bool signal_armed = false, signal_sent = false;
+  int pose_prep_launch = 0;          // test hook (tune key): 1 = the device pose records are always filled by the launch made for that, never by the posing launch on the way
   const double *pose_in_cur = nullptr; PoseRec *pose_tab_cur = nullptr; int pose_tab_n = 0; bool pose_tab_pending = false;
   uint32_t *gate = nullptr; bool gate_is_signal = false;     // host-writable word the stream waits on (hipStreamWaitValue32)
   uint32_t *h_done = nullptr, *d_done = nullptr;      // pinned, mapped: the stream writes the pass number here when a pass's chain has drained

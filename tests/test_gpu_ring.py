@@ -422,8 +422,8 @@ def test_posed_index_refresh_equals_lazy_refresh(gpu, mvr):
 @pytest.mark.parametrize("case", ["ring12", "ring36", "slightly_sheared", "sheared", "two_runs", "uploads_between_runs"])
 def test_pipelined_run_equals_pass_by_pass(mvr, case):
     """mvr_ring_run enqueues pass k+1's launch chain while pass k runs (behind a gate the host's solve opens; the poses reach
-    the kernels through a device table): the SAME poses and edge tables, bit for bit, as one mvr_ring_step per pass and as
-    the run with the pipeline switched off -- on the 12- and 36-view rings, with a pose that is rigid only to 2e-4 (wider
+    the kernels through a device table, filled by the chain's posing launch on the way or by a launch of its own): the SAME
+    poses and edge tables, bit for bit, as one mvr_ring_step per pass and as the run with the pipeline switched off -- on the 12- and 36-view rings, with a pose that is rigid only to 2e-4 (wider
     balls), with one that is not nearly rigid at all (those passes must not be queued ahead), over two calls (the second
     starts pipelined) and with a scan uploaded again between two calls (the queued chain would need a new ordering: the
     run must notice and enqueue that pass the ordinary way)."""
@@ -440,9 +440,11 @@ def test_pipelined_run_equals_pass_by_pass(mvr, case):
     edges = [(i, (i + 1) % V) for i in range(V)]
     posed, raw = list(range(V)), [V + v for v in range(V)]
     runs, piped = [], []
-    for mode in ("piped", "off", "stepwise"):
+    for mode in ("piped", "off", "stepwise", "piped_prep_launch"):
         with mvr.Context(0) as ctx:
             ctx.tune(pipeline=int(mode != "off"))
+            if mode == "piped_prep_launch":      # the device pose records filled by the launch made for that (what a chain that does not pose every view gets)
+                ctx.tune(pose_prep_launch=1)
             for v in range(V):
                 ctx.upload(V + v, scans[v])
             P, log = [p.copy() for p in poses0], []
@@ -462,8 +464,8 @@ def test_pipelined_run_equals_pass_by_pass(mvr, case):
             log.append(ctx.download(3).tobytes() + ctx.download(V - 1).tobytes())      # (the queued passes leave the posed points in original order out: written when the run ends)
             runs.append(log)
             piped.append(ctx.stat("piped_passes"))
-    assert runs[0] == runs[1] == runs[2], case
-    assert piped[1] == 0 and piped[2] == 0
+    assert runs[0] == runs[1] == runs[2] == runs[3], case
+    assert piped[1] == 0 and piped[2] == 0 and piped[3] == piped[0]
     if case == "sheared":
         assert piped[0] == 0, piped                 # a pose outside the nearly-rigid range: never queued ahead
     else:
