@@ -442,6 +442,8 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * "pipeline" (1, default: mvr_ring_run / mvr_ring_run_sharded enqueue pass k+1's whole launch chain while pass k runs,
  * behind a hipStreamWaitValue32 gate the host opens after its solve, the poses reaching the kernels through a device table,
  * once a pass has run without allocating or waiting; 0: every pass is enqueued after the previous solve; also MVR_PIPELINE);
+ * "grid_probe" (1, default: a query of the grid walk whose ball is wide first looks into the 2 x 2 x 2 cells nearest to it -- a
+ * point found there is a tighter, valid bound; what a pass after a large motion needs; 0: off);
  * the aligns of the sequential mode: "seq_search" (mvr_icp_align of a posed scan against a model made of posed scans: 1, default:
  * the reverse searches walk the source scan's cell grid; 2: the forward search goes through the merged scans' grids as well; 0:
  * the culled kernel both ways), "seq_seed" (1, default: an align's forward searches start from the distance, now, of the point
