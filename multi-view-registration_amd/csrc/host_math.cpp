@@ -378,6 +378,84 @@ bool solve_spd_band(int n, double *band, double *b, double *dinv, double *y)
   return true;
 }
 
+// The normal equations of a RING or CHAIN of views are block tridiagonal (6 x 6 blocks: a view couples to the next and the
+// previous one only; the fixed view 0 just adds to its neighbours' diagonal blocks).  Block Cholesky with everything of a
+// block step in registers: D_v = L L^T, y_v = L^-1 b_v, W = L^-1 O_v, D_{v+1} -= W^T W, b_{v+1} -= W^T y_v; back substitution
+// x_v = L^-T (y_v - W_v x_{v+1}).  All loops have constant trip counts (6): the compiler unrolls them, no row ends, no zero
+// tests, no memory traffic beyond the blocks themselves -- what is left is the chain of 6 (nb) dependent square roots and
+// divisions.  The ARITHMETIC differs from the row-wise elimination of solve_spd / solve_spd_band in the order of the updates
+// (results agree to rounding: tests/test_host.py), so it is one route for every caller, not a choice per call.
+// D: nb blocks of 36 (row-major, symmetric, destroyed), O: nb - 1 coupling blocks G(v, v + 1) of 36, b: nb * 6 in / out.
+// false: a pivot is not safely positive (the caller takes the generic route).
+static bool solve_chain6(int nb, double *D, double *O, double *b)
+{
+  double amax = 0.0;
+  for (int v = 0; v < nb; ++v) for (int k = 0; k < 6; ++k) amax = std::max(amax, std::fabs(D[36 * (size_t)v + 7 * k]));
+  if (!(amax > 0.0)) return false;
+  const double tiny = 1e-13 * amax;
+  for (int v = 0; v < nb; ++v) {
+    double *A = D + 36 * (size_t)v;          // becomes L (lower triangle), diagonal inverted in dinv
+    double dinv[6];
+    for (int j = 0; j < 6; ++j) {
+      double d = A[7 * j];
+      for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
+      if (!(d > tiny)) return false;
+      const double l = std::sqrt(d), inv = l * (1.0 / d);      // 1 / sqrt(d): the root and the reciprocal run side by side (the chain of 6 nb pivots is what this routine costs)
+      A[7 * j] = l; dinv[j] = inv;
+      for (int i = j + 1; i < 6; ++i) {
+        double sacc = A[6 * i + j];
+        for (int k = 0; k < j; ++k) sacc -= A[6 * i + k] * A[6 * j + k];
+        A[6 * i + j] = sacc * inv;
+      }
+    }
+    double *y = b + 6 * (size_t)v;
+    for (int i = 0; i < 6; ++i) {              // y = L^-1 b
+      double sacc = y[i];
+      for (int k = 0; k < i; ++k) sacc -= A[6 * i + k] * y[k];
+      y[i] = sacc * dinv[i];
+    }
+    if (v + 1 < nb) {
+      double *W = O + 36 * (size_t)v;        // O_v (rows: block v, columns: block v + 1) -> W = L^-1 O_v, column by column
+      for (int c = 0; c < 6; ++c)
+        for (int i = 0; i < 6; ++i) {
+          double sacc = W[6 * i + c];
+          for (int k = 0; k < i; ++k) sacc -= A[6 * i + k] * W[6 * k + c];
+          W[6 * i + c] = sacc * dinv[i];
+        }
+      double *Dn = D + 36 * (size_t)(v + 1), *bn = b + 6 * (size_t)(v + 1);
+      for (int r = 0; r < 6; ++r) {            // D_{v+1} -= W^T W (full block: the factorisation reads its lower triangle), b_{v+1} -= W^T y
+        for (int c = 0; c < 6; ++c) {
+          double sacc = 0.0;
+          for (int k = 0; k < 6; ++k) sacc += W[6 * k + r] * W[6 * k + c];
+          Dn[6 * r + c] -= sacc;
+        }
+        double t = 0.0;
+        for (int k = 0; k < 6; ++k) t += W[6 * k + r] * y[k];
+        bn[r] -= t;
+      }
+    }
+    for (int j = 0; j < 6; ++j) A[7 * j] = dinv[j];      // (the back substitution wants the inverted diagonal)
+  }
+  for (int v = nb - 1; v >= 0; --v) {
+    const double *A = D + 36 * (size_t)v;
+    double *x = b + 6 * (size_t)v;
+    if (v + 1 < nb) {
+      const double *W = O + 36 * (size_t)v, *xn = b + 6 * (size_t)(v + 1);
+      for (int i = 0; i < 6; ++i) {
+        double t = 0.0;
+        for (int c = 0; c < 6; ++c) t += W[6 * i + c] * xn[c];
+        x[i] -= t;
+      }
+    }
+    for (int i = 5; i >= 0; --i) {             // x = L^-T x
+      double sacc = x[i];
+      for (int k = i + 1; k < 6; ++k) sacc -= A[6 * k + i] * x[k];
+      x[i] = sacc * A[7 * i];
+    }
+  }
+  return true;
+}
+
 }  // namespace mvr
 
 using namespace mvr;
@@ -748,8 +826,20 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   constexpr int kBandW = 12;
   int reach = 0;
   for (int j = 0; j < dim; ++j) reach = std::max(reach, row_end[(size_t)j] - j);
-  static const bool force_dense = std::getenv("MVR_LUM_DENSE") != nullptr;       // (tests: the two routes give the same bits)
+  static const bool force_dense = std::getenv("MVR_LUM_DENSE") != nullptr;       // (tests: the two row-wise routes give the same bits)
+  static const bool force_band = std::getenv("MVR_LUM_BAND") != nullptr;         // (tests: the block route agrees with them to rounding)
   const bool banded = reach <= kBandW && !force_dense;
+  const bool chain = banded && !force_band && n >= 2;                            // (reach <= 12: a view's neighbours are the next, the previous and view 0)
+  // every view's edges in ascending order of the neighbour (the order all three assemblies add the diagonal blocks up in)
+  struct Nbr { int vj, e; double sign; };
+  std::vector<std::vector<Nbr>> nbrs((size_t)n);
+  for (int vi = 1; vi < n; ++vi)
+    for (int vj = 0; vj < n; ++vj) {
+      const int e = eidx[(size_t)vi * n + vj];
+      if (e >= 0) nbrs[(size_t)vi].push_back(Nbr{vj, e, efwd[(size_t)vi * n + vj] ? 1.0 : -1.0});
+    }
+  std::vector<double> Dc, Oc;
+  if (chain) { Dc.resize((size_t)(n - 1) * 36); Oc.resize((size_t)std::max(n - 2, 1) * 36); }
   std::vector<double> band, bscratch;
   if (banded) { band.resize((size_t)(dim + kBandW) * 2 * kBandW); bscratch.resize((size_t)2 * dim + 4 * kBandW); }
   std::vector<double> Tv((size_t)n * 16);
@@ -787,20 +877,31 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
       store_edge(e, rc, MM, MZ, ss);
     }
     bool solved = false;
-    if (banded) {
+    if (chain) {
+      std::fill(Dc.begin(), Dc.end(), 0.0); std::fill(Oc.begin(), Oc.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
+      for (int vi = 1; vi < n; ++vi)
+        for (const Nbr &nb : nbrs[(size_t)vi]) {
+          const double *ci = &cinv[36 * (size_t)nb.e];
+          double *Dv = &Dc[36 * (size_t)(vi - 1)];
+          for (int k = 0; k < 36; ++k) Dv[k] += ci[k];
+          if (nb.vj == vi + 1) { double *Ov = &Oc[36 * (size_t)(vi - 1)]; for (int k = 0; k < 36; ++k) Ov[k] = -ci[k]; }
+          for (int r = 0; r < 6; ++r) B[6 * (vi - 1) + r] += nb.sign * cinvd[6 * nb.e + r];
+        }
+      solved = solve_chain6(n - 1, Dc.data(), Oc.data(), B.data());
+      if (!solved) std::fill(B.begin(), B.end(), 0.0);
+    }
+    if (!solved && banded) {
       constexpr int S = 2 * kBandW;
       std::fill(band.begin(), band.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
       for (int vi = 1; vi < n; ++vi)
-        for (int vj = 0; vj < n; ++vj) {            // (the order the dense assembly adds the diagonal blocks up in)
-          const int e = eidx[(size_t)vi * n + vj];
-          if (e < 0) continue;
-          const bool fwd = efwd[(size_t)vi * n + vj] != 0;
+        for (const Nbr &nb : nbrs[(size_t)vi]) {    // (the order the dense assembly adds the diagonal blocks up in)
+          const int vj = nb.vj, e = nb.e;
           const double *ci = &cinv[36 * (size_t)e];
           for (int r = 0; r < 6; ++r) {
             double *row = &band[(size_t)(6 * (vi - 1) + r) * S];
             if (vj > vi) for (int cc = 0; cc < 6; ++cc) row[6 * (vj - vi) + cc - r] = -ci[6 * r + cc];
             for (int cc = r; cc < 6; ++cc) row[cc - r] += ci[6 * r + cc];
-            B[6 * (vi - 1) + r] += (fwd ? 1.0 : -1.0) * cinvd[6 * e + r];
+            B[6 * (vi - 1) + r] += nb.sign * cinvd[6 * e + r];
           }
         }
       // (a failed factorisation -- a pivot not safely positive -- falls back to the dense route below, which assembles G itself)
