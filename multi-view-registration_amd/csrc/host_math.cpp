@@ -182,7 +182,7 @@ int solve6(const double A[36], const double b[6], double x[6])
 // positive (degenerate correspondences: the caller's NaN / singular handling stays as it was).
 int solve6_spd(const double A[36], const double b[6], double x[6])
 {
-  double L[6][6], y[6];
+  double L[6][6], y[6], dinv[6];
   double amax = 0.0;
   for (int k = 0; k < 6; ++k) amax = std::max(amax, std::fabs(A[7 * k]));
   for (int j = 0; j < 6; ++j) {
@@ -190,15 +190,16 @@ int solve6_spd(const double A[36], const double b[6], double x[6])
     for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
     if (!(d > 1e-13 * amax)) return solve6(A, b, x);
     const double ljj = std::sqrt(d), inv = 1.0 / ljj;
-    L[j][j] = ljj;
+    L[j][j] = ljj; dinv[j] = inv;
     for (int i = j + 1; i < 6; ++i) {
       double v = A[6 * i + j];
       for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
       L[i][j] = v * inv;
     }
   }
-  for (int i = 0; i < 6; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
-  for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k]; x[i] = v / L[i][i]; }
+  // (the substitutions multiply by the reciprocals the factorisation has: twelve divisions off the dependent chain)
+  for (int i = 0; i < 6; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[i][k] * y[k]; y[i] = v * dinv[i]; }
+  for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k]; x[i] = v * dinv[i]; }
   return MVR_OK;
 }
 
@@ -385,72 +386,82 @@ bool solve_spd_band(int n, double *band, double *b, double *dinv, double *y)
 // tests, no memory traffic beyond the blocks themselves -- what is left is the chain of 6 (nb) dependent square roots and
 // divisions.  The ARITHMETIC differs from the row-wise elimination of solve_spd / solve_spd_band in the order of the updates
 // (results agree to rounding: tests/test_host.py), so it is one route for every caller, not a choice per call.
-// D: nb blocks of 36 (row-major, symmetric, destroyed), O: nb - 1 coupling blocks G(v, v + 1) of 36, b: nb * 6 in / out.
+// D: nb blocks (row-major, symmetric, destroyed), O: nb - 1 coupling blocks G(v, v + 1), b: nb * 6 in / out.
 // false: a pivot is not safely positive (the caller takes the generic route).
+// Blocks are stored with rows of EIGHT doubles (six used): a row is two 4-wide vectors, and the two O(6^3) parts -- W = L^-1 O
+// and the update D_{v+1} -= W^T W -- run a row at a time.
 static bool solve_chain6(int nb, double *D, double *O, double *b)
 {
+  constexpr int R = 8, B2 = 6 * R;        // row stride, block size
   double amax = 0.0;
-  for (int v = 0; v < nb; ++v) for (int k = 0; k < 6; ++k) amax = std::max(amax, std::fabs(D[36 * (size_t)v + 7 * k]));
+  for (int v = 0; v < nb; ++v) for (int k = 0; k < 6; ++k) amax = std::max(amax, std::fabs(D[B2 * (size_t)v + (R + 1) * k]));
   if (!(amax > 0.0)) return false;
   const double tiny = 1e-13 * amax;
   for (int v = 0; v < nb; ++v) {
-    double *A = D + 36 * (size_t)v;          // becomes L (lower triangle), diagonal inverted in dinv
+    double *A = D + B2 * (size_t)v;          // becomes L (lower triangle), diagonal inverted in dinv
     double dinv[6];
     for (int j = 0; j < 6; ++j) {
-      double d = A[7 * j];
-      for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
+      double d = A[(R + 1) * j];
+      for (int k = 0; k < j; ++k) d -= A[R * j + k] * A[R * j + k];
       if (!(d > tiny)) return false;
       const double l = std::sqrt(d), inv = l * (1.0 / d);      // 1 / sqrt(d): the root and the reciprocal run side by side (the chain of 6 nb pivots is what this routine costs)
-      A[7 * j] = l; dinv[j] = inv;
+      A[(R + 1) * j] = l; dinv[j] = inv;
       for (int i = j + 1; i < 6; ++i) {
-        double sacc = A[6 * i + j];
-        for (int k = 0; k < j; ++k) sacc -= A[6 * i + k] * A[6 * j + k];
-        A[6 * i + j] = sacc * inv;
+        double sacc = A[R * i + j];
+        for (int k = 0; k < j; ++k) sacc -= A[R * i + k] * A[R * j + k];
+        A[R * i + j] = sacc * inv;
       }
     }
     double *y = b + 6 * (size_t)v;
     for (int i = 0; i < 6; ++i) {              // y = L^-1 b
       double sacc = y[i];
-      for (int k = 0; k < i; ++k) sacc -= A[6 * i + k] * y[k];
+      for (int k = 0; k < i; ++k) sacc -= A[R * i + k] * y[k];
       y[i] = sacc * dinv[i];
     }
     if (v + 1 < nb) {
-      double *W = O + 36 * (size_t)v;        // O_v (rows: block v, columns: block v + 1) -> W = L^-1 O_v, column by column
-      for (int c = 0; c < 6; ++c)
-        for (int i = 0; i < 6; ++i) {
-          double sacc = W[6 * i + c];
-          for (int k = 0; k < i; ++k) sacc -= A[6 * i + k] * W[6 * k + c];
-          W[6 * i + c] = sacc * dinv[i];
+      double *W = O + B2 * (size_t)v;        // O_v (rows: block v, columns: block v + 1) -> W = L^-1 O_v, a row of W at a time
+      __m256d w0[6], w1[6];
+      for (int i = 0; i < 6; ++i) {
+        __m256d r0 = _mm256_loadu_pd(W + R * i), r1 = _mm256_loadu_pd(W + R * i + 4);
+        for (int k = 0; k < i; ++k) {
+          const __m256d l = _mm256_set1_pd(A[R * i + k]);
+          r0 = _mm256_sub_pd(r0, _mm256_mul_pd(l, w0[k])); r1 = _mm256_sub_pd(r1, _mm256_mul_pd(l, w1[k]));
         }
-      double *Dn = D + 36 * (size_t)(v + 1), *bn = b + 6 * (size_t)(v + 1);
-      for (int r = 0; r < 6; ++r) {            // D_{v+1} -= W^T W (full block: the factorisation reads its lower triangle), b_{v+1} -= W^T y
-        for (int c = 0; c < 6; ++c) {
-          double sacc = 0.0;
-          for (int k = 0; k < 6; ++k) sacc += W[6 * k + r] * W[6 * k + c];
-          Dn[6 * r + c] -= sacc;
-        }
+        const __m256d di = _mm256_set1_pd(dinv[i]);
+        w0[i] = _mm256_mul_pd(r0, di); w1[i] = _mm256_mul_pd(r1, di);
+        _mm256_storeu_pd(W + R * i, w0[i]); _mm256_storeu_pd(W + R * i + 4, w1[i]);
+      }
+      double *Dn = D + B2 * (size_t)(v + 1), *bn = b + 6 * (size_t)(v + 1);
+      for (int r = 0; r < 6; ++r) {            // D_{v+1} -= W^T W (row r: sum over k of W[k][r] * row k of W), b_{v+1} -= W^T y
+        __m256d a0 = _mm256_loadu_pd(Dn + R * r), a1 = _mm256_loadu_pd(Dn + R * r + 4);
         double t = 0.0;
-        for (int k = 0; k < 6; ++k) t += W[6 * k + r] * y[k];
+        for (int k = 0; k < 6; ++k) {
+          const double wkr = W[R * k + r];
+          const __m256d f = _mm256_set1_pd(wkr);
+          a0 = _mm256_sub_pd(a0, _mm256_mul_pd(f, w0[k])); a1 = _mm256_sub_pd(a1, _mm256_mul_pd(f, w1[k]));
+          t += wkr * y[k];
+        }
+        _mm256_storeu_pd(Dn + R * r, a0); _mm256_storeu_pd(Dn + R * r + 4, a1);
         bn[r] -= t;
       }
     }
-    for (int j = 0; j < 6; ++j) A[7 * j] = dinv[j];      // (the back substitution wants the inverted diagonal)
+    for (int j = 0; j < 6; ++j) A[(R + 1) * j] = dinv[j];      // (the back substitution wants the inverted diagonal)
   }
   for (int v = nb - 1; v >= 0; --v) {
-    const double *A = D + 36 * (size_t)v;
+    const double *A = D + B2 * (size_t)v;
     double *x = b + 6 * (size_t)v;
     if (v + 1 < nb) {
-      const double *W = O + 36 * (size_t)v, *xn = b + 6 * (size_t)(v + 1);
+      const double *W = O + B2 * (size_t)v, *xn = b + 6 * (size_t)(v + 1);
       for (int i = 0; i < 6; ++i) {
         double t = 0.0;
-        for (int c = 0; c < 6; ++c) t += W[6 * i + c] * xn[c];
+        for (int c = 0; c < 6; ++c) t += W[R * i + c] * xn[c];
         x[i] -= t;
       }
     }
     for (int i = 5; i >= 0; --i) {             // x = L^-T x
       double sacc = x[i];
-      for (int k = i + 1; k < 6; ++k) sacc -= A[6 * k + i] * x[k];
-      x[i] = sacc * A[7 * i];
+      for (int k = i + 1; k < 6; ++k) sacc -= A[R * k + i] * x[k];
+      x[i] = sacc * A[(R + 1) * i];
     }
   }
   return true;
@@ -636,7 +647,7 @@ inline M3v vsym6(const v4d s[6]) { M3v m; m(0, 0) = s[0]; m(0, 1) = m(1, 0) = s[
 // solve6_spd, four systems at once; false if any lane's pivot is not safely positive (the caller falls back)
 inline bool solve6_spd_x4(const v4d A[36], const v4d b[6], v4d x[6])
 {
-  v4d L[6][6], y[6];
+  v4d L[6][6], y[6], dinv[6];
   v4d amax = vsplat(0.0);
   for (int k = 0; k < 6; ++k) amax = vmax(amax, vabs(A[7 * k]));
   for (int j = 0; j < 6; ++j) {
@@ -645,15 +656,15 @@ inline bool solve6_spd_x4(const v4d A[36], const v4d b[6], v4d x[6])
     const v4i okm = d > vsplat(1e-13) * amax;
     if (!(okm[0] && okm[1] && okm[2] && okm[3])) return false;
     const v4d ljj = vsqrt(d), inv = vsplat(1.0) / ljj;
-    L[j][j] = ljj;
+    L[j][j] = ljj; dinv[j] = inv;
     for (int i = j + 1; i < 6; ++i) {
       v4d v = A[6 * i + j];
       for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
       L[i][j] = v * inv;
     }
   }
-  for (int i = 0; i < 6; ++i) { v4d v = b[i]; for (int k = 0; k < i; ++k) v -= L[i][k] * y[k]; y[i] = v / L[i][i]; }
-  for (int i = 5; i >= 0; --i) { v4d v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k]; x[i] = v / L[i][i]; }
+  for (int i = 0; i < 6; ++i) { v4d v = b[i]; for (int k = 0; k < i; ++k) v -= L[i][k] * y[k]; y[i] = v * dinv[i]; }
+  for (int i = 5; i >= 0; --i) { v4d v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k]; x[i] = v * dinv[i]; }
   return true;
 }
 
@@ -839,7 +850,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
       if (e >= 0) nbrs[(size_t)vi].push_back(Nbr{vj, e, efwd[(size_t)vi * n + vj] ? 1.0 : -1.0});
     }
   std::vector<double> Dc, Oc;
-  if (chain) { Dc.resize((size_t)(n - 1) * 36); Oc.resize((size_t)std::max(n - 2, 1) * 36); }
+  if (chain) { Dc.resize((size_t)(n - 1) * 48 + 8); Oc.resize((size_t)std::max(n - 2, 1) * 48 + 8); }      // (blocks of 6 rows of 8: solve_chain6)
   std::vector<double> band, bscratch;
   if (banded) { band.resize((size_t)(dim + kBandW) * 2 * kBandW); bscratch.resize((size_t)2 * dim + 4 * kBandW); }
   std::vector<double> Tv((size_t)n * 16);
@@ -882,9 +893,9 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
       for (int vi = 1; vi < n; ++vi)
         for (const Nbr &nb : nbrs[(size_t)vi]) {
           const double *ci = &cinv[36 * (size_t)nb.e];
-          double *Dv = &Dc[36 * (size_t)(vi - 1)];
-          for (int k = 0; k < 36; ++k) Dv[k] += ci[k];
-          if (nb.vj == vi + 1) { double *Ov = &Oc[36 * (size_t)(vi - 1)]; for (int k = 0; k < 36; ++k) Ov[k] = -ci[k]; }
+          double *Dv = &Dc[48 * (size_t)(vi - 1)];
+          for (int r = 0; r < 6; ++r) for (int k = 0; k < 6; ++k) Dv[8 * r + k] += ci[6 * r + k];
+          if (nb.vj == vi + 1) { double *Ov = &Oc[48 * (size_t)(vi - 1)]; for (int r = 0; r < 6; ++r) for (int k = 0; k < 6; ++k) Ov[8 * r + k] = -ci[6 * r + k]; }
           for (int r = 0; r < 6; ++r) B[6 * (vi - 1) + r] += nb.sign * cinvd[6 * nb.e + r];
         }
       solved = solve_chain6(n - 1, Dc.data(), Oc.data(), B.data());
