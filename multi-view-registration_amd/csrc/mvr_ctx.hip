@@ -1168,7 +1168,9 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
         if (!c->grid_wide) { if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc; }
       } else if (int rc = launch_nn_cull_batch(w, rev.data() + base, m, cap2, fma != 0)) return rc;
     }
-    if (c->signal_armed && w == c && base + kBatchPairs >= n_pairs && c->done_counter && c->d_done) {      // the chain's last launch carries its completion word
+    bool will_launch = false;
+    for (int j = 0; j < m; ++j) will_launch = will_launch || gb.p[j].blocks > 0;
+    if (c->signal_armed && will_launch && w == c && base + kBatchPairs >= n_pairs && c->done_counter && c->d_done) {      // the chain's last launch carries its completion word
       gb.done_word = c->d_done; gb.done_counter = c->done_counter; gb.done_seq = c->signal_seq;
       c->signal_armed = false; c->signal_sent = true;
     }
