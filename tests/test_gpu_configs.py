@@ -117,6 +117,39 @@ def test_config3_sequential_12x200k_vs_oracle_driver(gpu, orc, mvr):
     assert np.array_equal(bits(merged[:N]), bits(orc.transform_f64(poses0[0], scans[0])))
 
 
+def test_config3_second_sweep_seeded_vs_oracle_driver(gpu, orc, mvr):
+    """the same mode over TWO of the reference's `repeat_times` sweeps (registrator.cpp:530): in the second sweep every
+    forward search starts from the match the scan's align of the first sweep left (seq_seed) -- counts equal and poses
+    within the bar of the oracle driver run over the same two sweeps, align by align (12 x 100k: the oracle's 22 aligns)."""
+    one_variant(gpu)
+    V, N = 12, 100000
+    sp, scans, poses0 = scene(mvr, V, N, 3)
+    order = ref_driver.view_order(V)
+    RAW, TARGET, SOURCE, OUT = 16, 0, 1, 2
+    for v in range(V):
+        gpu.upload(RAW + v, scans[v])
+    params = mvr.icp_params(max_dist=4.0, max_iter=1000)
+    poses, log = [p.copy() for p in poses0], []
+    for sweep in range(2):
+        gpu.transform(TARGET, RAW + 0, poses[0]); gpu.reserve(TARGET, V * N)
+        for v in order:
+            gpu.transform(SOURCE, RAW + v, poses[v])
+            T, st, rc = gpu.icp_align(SOURCE, TARGET, OUT, params)
+            assert rc == 0
+            log.append(dict(view=v, T=T, n_corr=st["n_corr"], mse=st["mse"], iterations=st["iterations"]))
+            poses[v] = mvr.mat4d_mul(T.astype(np.float64), poses[v])
+            gpu.append(TARGET, OUT)
+    oposes, olog = ref_driver.sequential_icp(orc, scans, poses0, orc.make_params(max_dist=4.0, max_iter=1000), V, repeat=2, fitness_last=False)
+    assert len(log) == len(olog) == 2 * len(order)
+    for g, o in zip(log, olog):
+        assert g["view"] == o["view"] and g["iterations"] == o["iterations"]
+        assert g["n_corr"] == o["n_corr"], (g["view"], g["n_corr"], o["n_corr"])
+        assert abs(g["mse"] - o["mse"]) < 1e-9
+        assert_pose_close(g["T"], o["T"], g["view"])
+    for v in range(V):
+        assert_pose_close(poses[v], oposes[v], v)
+
+
 # ------------------------------------------------------------------ configs[4]
 
 def test_config5_ring_36_views_vs_oracle_lum_pass(mvr, orc, ring):
