@@ -134,10 +134,7 @@ void cloud_free(Cloud &cl)
 {
   if (cl.pts) (void)hipFree(cl.pts);
   if (cl.sorted) (void)hipFree(cl.sorted);
-  if (cl.tlo) (void)hipFree(cl.tlo);
-  if (cl.thi) (void)hipFree(cl.thi);
-  if (cl.cbox) (void)hipFree(cl.cbox);
-  if (cl.sbox) (void)hipFree(cl.sbox);
+  if (cl.tlo) (void)hipFree(cl.tlo);        // (thi / cbox / sbox live in the same block: prepare_index)
   if (cl.nrm) (void)hipFree(cl.nrm);
   if (cl.gsorted) (void)hipFree(cl.gsorted);
   cl.order.reset(); cl.grid.reset();

@@ -593,17 +593,15 @@ static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
     if (cl.tiles_cap < tiles) {
       MVR_MAY_BLOCK(c, "a cloud's box arrays have to grow");
       cl.fresh_tiles = 0;
-      (void)hipStreamSynchronize(c->stream);
-      if (cl.tlo) (void)hipFree(cl.tlo);
-      if (cl.thi) (void)hipFree(cl.thi);
-      if (cl.cbox) (void)hipFree(cl.cbox);
-      if (cl.sbox) (void)hipFree(cl.sbox);
+      // the four box arrays are ONE allocation (tlo is its start: a registration's first pass made four hipMalloc per view here,
+      // and synchronised before each batch of them -- needed only when there IS an old block the GPU may still be reading)
+      if (cl.tlo) { (void)hipStreamSynchronize(c->stream); (void)hipFree(cl.tlo); }
       cl.tlo = cl.thi = cl.cbox = cl.sbox = nullptr; cl.tiles_cap = 0;
       const size_t cap = std::max(tiles + tiles / 4, room_tiles) + 16;
-      MVR_HIP_TRY(c, hipMalloc(&cl.tlo, cap * sizeof(float4)));
-      MVR_HIP_TRY(c, hipMalloc(&cl.thi, cap * sizeof(float4)));
-      MVR_HIP_TRY(c, hipMalloc(&cl.cbox, cap * 8 * sizeof(float4)));
-      MVR_HIP_TRY(c, hipMalloc(&cl.sbox, (cap / 64 + 2) * 2 * sizeof(float4)));
+      const size_t n_sb = (cap / 64 + 2) * 2;
+      float4 *block = nullptr;
+      MVR_HIP_TRY(c, hipMalloc(&block, (cap * 10 + n_sb) * sizeof(float4)));
+      cl.tlo = block; cl.thi = block + cap; cl.cbox = block + 2 * cap; cl.sbox = block + 10 * cap;
       cl.tiles_cap = cap;
     }
     *stale = true;
