@@ -1521,11 +1521,13 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
       if (!c->side_after && hipEventCreateWithFlags(&c->side_after, hipEventDisableTiming) != hipSuccess) c->side_after = nullptr;
       if (c->side_after) (void)hipEventRecord(c->side_after, c->stream);
     }
-    // set-up that overlaps the pass: the grids on the side stream, the pipe's few allocations -- the GPU is busy with this
-    // pass meanwhile.  NOT behind a pass that contains a collective: streams share hardware queues, and a collective that
+    // set-up that overlaps the pass: the grids on the side stream, the pipe's few allocations.  Enqueued BEFORE the pass's own
+    // chain by default (setup_first): the host is the bottleneck of a registration's first pass whichever comes first, the
+    // bounding boxes come back at once from an idle GPU (behind the pass they waited 0.4 ms), and the grids are ready when the
+    // second pass wants them.  In any case NOT behind a pass that contains a collective: streams share hardware queues, and a collective that
     // a lost peer keeps from finishing would hold the side stream's packets behind it -- the host would wait for the side
     // stream instead of reaching the bounded wait that ends such a pass (found with the injected stall of the tests).
-    const bool setup_first = c->comm != nullptr || c->inject_stall_at >= 0;
+    const bool setup_first = c->comm != nullptr || c->inject_stall_at >= 0 || c->setup_first;
     if (more_follow && setup_first) { prebuild_grids(); if (pipe_possible()) (void)pipe_setup(c, V); }
     if (int rc = L.enqueue(L.self)) return rc;
     host_mark("pass: chain enqueued");
@@ -2400,6 +2402,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
   else if (!std::strcmp(key, "grid_probe")) c->grid_probe = value != 0;
+  else if (!std::strcmp(key, "setup_first")) c->setup_first = value != 0;
   else if (!std::strcmp(key, "pose_prep_launch")) c->pose_prep_launch = value != 0;
   else if (!std::strcmp(key, "grid_wide")) c->grid_wide = value != 0;
   else if (!std::strcmp(key, "grid_debug")) c->grid_debug = value != 0;

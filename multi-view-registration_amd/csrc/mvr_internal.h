@@ -281,6 +281,7 @@ struct Ctx {
   // of the chain (signal_armed, set by the pass loop for hosts that end a pass with the fused sums on this stream; signal_sent
   // tells the loop that it needs no write-value operation behind the chain)
   uint32_t *done_counter = nullptr; uint32_t signal_seq = 0; bool signal_armed = false, signal_sent = false;
+  int setup_first = 1;               // plain passes: 1 (default) = the grid builds (side stream) and the pipe's set-up are enqueued BEFORE the pass's own chain instead of behind it: the first pass of a registration is host-bound either way, and the grids are then ready when the second pass wants them (12 x 200k: 2.8 + 2.1 ms -> 3.7 + 0.5)
   int pose_prep_launch = 0;          // test hook (tune key): 1 = the device pose records are always filled by the launch made for that, never by the posing launch on the way
   const double *pose_in_cur = nullptr; PoseRec *pose_tab_cur = nullptr; int pose_tab_n = 0; bool pose_tab_pending = false;
   uint32_t *gate = nullptr; bool gate_is_signal = false;     // host-writable word the stream waits on (hipStreamWaitValue32)
