@@ -2096,15 +2096,14 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   const size_t ns = c->slots[ss].n;
   if (p->point_to_plane && c->slots[ts].n && !c->slots[ts].has_normals)
     return set_error(c, MVR_E_ARG, "point-to-plane needs target normals (mvr_cloud_upload_normals)");
-  // App. A.1: input_transformed = *input (guess == identity)
-  Cloud &cur = c->slots[kScratchCur];
-  cur.n = 0;
-  if (int rc = cloud_reserve(c, cur, ns, false)) return rc;
+  // App. A.1: input_transformed = *input (guess == identity).  The first iteration searches the source WHERE IT LIES: the
+  // copy PCL makes is only needed once the source moves (a second iteration, which the reference's settings never reach) --
+  // a device copy, an index refresh and a grid posing per align that nothing read differently (-25 us of 0.45 ms)
+  Cloud &scratch = c->slots[kScratchCur];
+  Cloud *curp = &c->slots[ss];
+  bool on_scratch = false;
   const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  if (ns) MVR_HIP_TRY(c, hipMemcpyAsync(cur.pts, c->slots[ss].pts, ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-  cur.n = ns;
   if (c->nn_mode != 0 && ns) { if (int rc = ensure_index(c, c->slots[ss])) return rc; }   // sort the source once, share it
-  inherit_point_set(cur, c->slots[ss]);
   MVR_HIP_TRY(c, hipMemsetAsync(c->evals + kEvalRegion, 0, kEvalRegion * sizeof(uint64_t), c->stream));   // running totals of the culled kernel
   float fin[16], tr[16];
   std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
@@ -2117,20 +2116,20 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   // reach, take the culled kernel: the moved source's coordinates are no longer a known pose of its scan)
   // (seq_search 2: forward through the parts as well; measured on the 12 x 200k sweep it does NOT pay -- DESIGN.md 4.5 -- so
   // the default, 1, keeps the culled kernel for the forward search and takes the grid for the reverse one)
-  const bool parts_ok = ns > 0 && tgt.n > 0 && ts != ss && prepare_parts_search(c, c->slots[ss], cur, tgt, p->max_corr_dist);
+  const bool parts_ok = ns > 0 && tgt.n > 0 && ts != ss && prepare_parts_search(c, c->slots[ss], *curp, tgt, p->max_corr_dist);
   const bool rev_grid_ok = parts_ok || (ns > 0 && tgt.n > 0 && ts != ss && p->use_reciprocal && tgt.n <= 0xFFFFFFF0ull &&
-                                        prepare_source_grid(c, c->slots[ss], cur, p->max_corr_dist));
+                                        prepare_source_grid(c, c->slots[ss], *curp, p->max_corr_dist));
   do {
     double ev = 0.0;
     SearchPlan plan;
-    if (rev_grid_ok && iters == 0) { if (int rc = run_search_parts(c, cur, tgt, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &plan, parts_ok)) return rc; }
+    if (rev_grid_ok && iters == 0) { if (int rc = run_search_parts(c, *curp, tgt, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &plan, parts_ok)) return rc; }
     else
-    if (int rc = run_search(c, cur, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev, &plan)) return rc;
-    if (int rc = launch_pass1(c, cur.pts, tgt.pts, c->keys, c->rkeys, plan.slot, plan.count, plan.qperm, plan.tinv, 0, ns,
+    if (int rc = run_search(c, *curp, tgt, 0, ns, p->max_corr_dist, p->use_reciprocal != 0, p->fma_dist != 0, &ev, &plan)) return rc;
+    if (int rc = launch_pass1(c, curp->pts, tgt.pts, c->keys, c->rkeys, plan.slot, plan.count, plan.qperm, plan.tinv, 0, ns,
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
-    if (p->point_to_plane) { if (int rc = launch_p2plane(c, cur.pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc; }
-    else if (int rc = launch_pass2(c, cur.pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
+    if (p->point_to_plane) { if (int rc = launch_p2plane(c, curp->pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc; }
+    else if (int rc = launch_pass2(c, curp->pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
     // the search kernels' running evaluation totals ride along with the moments (the statistic needs no wait of its own)
     if (st && c->nn_mode != 0)
       MVR_HIP_TRY(c, hipMemcpyAsync(c->h_evals, c->evals + kEvalRegion, kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -2150,9 +2149,17 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
     ++iters;
     converged = crit.converged(tr, cur_mse, iters, &state) ? 1 : 0;
     if (!converged) {          // (the moved source is only needed by another iteration: the output is final * the ORIGINAL input)
-      if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
-      cur.stale_coords();
-      cur.pose_known = false; cur.grid.reset();
+      if (!on_scratch) {         // the source moves for the first time: into the scratch cloud, which the later iterations search and move
+        scratch.n = 0;
+        if (int rc = cloud_reserve(c, scratch, ns, false)) return rc;
+        if (int rc = launch_transform_f32(c, curp->pts, scratch.pts, ns, tr)) return rc;
+        scratch.n = ns;
+        inherit_point_set(scratch, c->slots[ss]);
+        on_scratch = true;
+        curp = &scratch;
+      } else if (int rc = launch_transform_f32(c, curp->pts, curp->pts, ns, tr)) return rc;
+      curp->stale_coords();
+      curp->pose_known = false; curp->fin_known = false; curp->grid.reset(); curp->parts.clear();
     }
   } while (!converged);
   // output = final * (*input), from the ORIGINAL input: alias-safe (registrator.cpp:920)
