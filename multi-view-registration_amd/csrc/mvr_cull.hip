@@ -859,7 +859,10 @@ int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2,
       map.sets[k] = k < m ? (uint32_t)(((size_t)batch.p[k].q_count + 64 * Q - 1) / (64 * Q)) : 0u;
       sets += map.sets[k];
     }
-    int W = sets >= (size_t)c->n_cu * 40 ? 1 : 2;
+    // ... and a launch of few sets (a lone align of 200k points: 3.1k sets, twelve waves per SIMD in all) is bound by that chain
+    // outright: four waves per set (the sequential mode's align against a 2 M-point model: 0.45 -> 0.42 ms, 12 x 50k: 0.26 ->
+    // 0.22; 4 x 200k equal)
+    int W = sets >= (size_t)c->n_cu * 40 ? 1 : sets >= (size_t)c->n_cu * 16 ? 2 : 4;
     if (c->cull_w == 1 || c->cull_w == 2 || c->cull_w == 4) W = c->cull_w;      // tuning override
     map.n_pairs = (uint32_t)m;
     unsigned grid_blocks = 0;
