@@ -177,6 +177,44 @@ def test_lum_routes_agree():
         assert np.abs(pb - pr).max() <= 1e-9 * max(1.0, np.abs(pr).max()), (blk[0], np.abs(pb - pr).max())
 
 
+def test_lum_view_without_correspondences_is_singular_on_every_route():
+    """a view whose two edges carry no usable correspondences has an all-zero block row: the block route's pivot test
+    refuses it, the row-wise routes refuse it, the pivoted elimination finds the zero column -- MVR_E_SINGULAR whichever
+    route was asked for, poses untouched."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, importlib
+import numpy as np
+sys.path.insert(0, %r)
+mvr = importlib.import_module("multi-view-registration_amd")
+V = 6
+rng = np.random.default_rng(5); origin = np.array([-13.4, 50.2, 917.5])
+edges = [(i, (i + 1) %% V) for i in range(V)]
+m2 = []
+for e in range(V):
+    n = 3000 if e not in (2, 3) else 2
+    p = rng.normal(size=(n, 3)) * 40 + origin
+    q = p + rng.normal(size=p.shape) * 0.1
+    pc, qc = p - origin, q - origin
+    row = np.zeros(32); row[0] = n; row[1:4] = origin; row[4:7] = pc.sum(0); row[7:10] = qc.sum(0)
+    sym = lambda m: [m[0, 0], m[0, 1], m[0, 2], m[1, 1], m[1, 2], m[2, 2]]
+    row[10:16] = sym(pc.T @ pc); row[16:22] = sym(qc.T @ qc); row[22:31] = (pc.T @ qc).ravel()
+    m2.append(mvr.moments2_from_row(row))
+rc, P, its = mvr.lum_compute(V, edges, m2, max_iterations=4)
+print(rc, its, float(np.abs(np.asarray(P)).max()))
+""" % root
+    for var in (None, "MVR_LUM_BAND", "MVR_LUM_DENSE"):
+        env = dict(os.environ)
+        env.pop("MVR_LUM_DENSE", None); env.pop("MVR_LUM_BAND", None)
+        if var:
+            env[var] = "1"
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rc, its, pmax = r.stdout.split()
+        assert int(rc) == -5 and int(its) == 0 and float(pmax) == 0.0, (var, r.stdout)
+
+
 def test_lum_edge_four_at_once_is_bit_identical_to_the_scalar_function(mvr):
     """mvr_lum_compute sends its edges four at a time through an AVX2 pass (one edge per lane): every lane must give
     the bytes of the scalar LUM::computeEdge -- and a group with a degenerate edge must be refused (-> scalar path)."""
