@@ -163,11 +163,13 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
     dict(cull_list=0), dict(cull_list_w=1), dict(cull_list_w=4, grid_cluster=1), dict(grid_cluster=65),
     dict(grid_cell_points=1), dict(grid_cell_points=40, grid_light_rows=3), dict(fused_mark=0), dict(fused_mark=2), dict(grid_sets=0), dict(grid_tail=0), dict(grid_sets=2, grid_light_rows=1, grid_cluster=1), dict(grid_sets=2, grid_cell_points=1, grid_light_rows=2, grid_cluster=2), dict(fused_mark=0, grid_lanes=4, pair_groups=1),
     dict(grid_wide_waves=1), dict(pair_groups=3, cull_slices=8),
+    dict(grid_probe=0), dict(grid_probe=0, grid_light_rows=2), dict(grid_probe=1, grid_light_rows=1, grid_cluster=1), dict(setup_first=0), dict(cull_w=4), dict(cull_w=2),
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
     """Every routing knob of the grid search (lanes per query, cell size, what counts as a wide ball, where the wide ones
     go, set lists, marking) only moves queries between three exact searches: six passes of the 12 x 20k ring from the
-    prior give the same poses and edge tables, bit for bit, as the default settings."""
+    prior give the same poses and edge tables, bit for bit, as the default settings (so do the probe for wide balls, the order of
+    the set-up of a plain pass and the waves per query set of the culled kernel)."""
     V, N, max_d = 12, 20000, 4.0
     sp = mvr.synth_params(V, 3)
     scans = [mvr.synth_view(sp, v, N) for v in range(V)]
