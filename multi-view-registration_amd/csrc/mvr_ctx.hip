@@ -2024,6 +2024,7 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
     if (int rc = launch_merge_flagged_keys(c, cur.sorted, c->bheavy, c->rkeys, ns, c->keys)) return rc;
   }
   }
+  uint32_t *seed_out = nullptr;
   if (c->seq_seed) {
     if (c->seq_seeds.size() >= 256 && !c->seq_seeds.count(cur.set_id)) {      // (scans that are gone: start over rather than grow without bound)
       MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2033,12 +2034,14 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
     Ctx::SeedBuf &sb = c->seq_seeds[cur.set_id];
     if (int rc = ensure(c, sb.d, sb.cap, ns)) return rc;
     sb.n = ns;
-    if (int rc = launch_keys_to_seed(c, cur.sorted, ns, c->keys, tgt.order->inv, sb.d)) return rc;
+    seed_out = sb.d;
+    // (with reciprocal searches the launch that sets the reverse searches' start bounds walks the same keys: it leaves the seeds)
+    if (!reciprocal || nt == 0) { if (int rc = launch_keys_to_seed(c, cur.sorted, ns, c->keys, tgt.order->inv, sb.d)) return rc; }
   }
   if (!reciprocal || nt == 0) return MVR_OK;
   // reverse: the distinct matched targets, each starting from the distance of the source that matched it
   if (int rc = ensure(c, c->bound, c->bound_cap, nt)) return rc;
-  if (int rc = launch_seed_bounds(c, c->keys, plan->qperm, 0, ns, max2, plan->tinv, nt, c->bound)) return rc;
+  if (int rc = launch_seed_bounds(c, c->keys, plan->qperm, 0, ns, max2, plan->tinv, nt, c->bound, seed_out)) return rc;
   const size_t nl = std::min(ns, nt), chunks = (nt + 255) / 256;
   if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
   if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;

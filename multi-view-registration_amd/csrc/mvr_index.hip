@@ -312,16 +312,19 @@ __global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint
 
 // bound[sorted target position] = bits of the forward d2 of A source that matched the target (array preset to ~0)
 __global__ void seed_bounds_kernel(const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ qperm, size_t q_begin,
-                                   size_t q_count, double max2, const uint32_t *__restrict__ tinv, uint32_t *__restrict__ bound)
+                                   size_t q_count, double max2, const uint32_t *__restrict__ tinv, uint32_t *__restrict__ bound,
+                                   uint32_t *__restrict__ seed)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= q_count) return;
   const size_t i = qperm ? qperm[q_begin + k] : (q_begin + k);
   const nnkey_t key = keys[i];
   const uint32_t j = (uint32_t)key;
+  const uint32_t tpos = j != kNone ? tinv[j] : kNone;
+  if (seed) seed[k] = tpos;          // (optional: where this query's match sits -- what the scan's NEXT align starts from, Ctx::seq_seed)
   if (j == kNone) return;
   if ((double)__uint_as_float((uint32_t)(key >> 32)) > max2) return;
-  __hip_atomic_store(&bound[tinv[j]], (uint32_t)(key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // any match's distance will do (see flag_matched_batch_kernel)
+  __hip_atomic_store(&bound[tpos], (uint32_t)(key >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // any match's distance will do (see flag_matched_batch_kernel)
 }
 
 __global__ void flag_matched_batch_kernel(GlueBatch b)
@@ -757,13 +760,13 @@ int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs)
 }
 
 int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
-                       const uint32_t *tinv, size_t nt, uint32_t *bound)
+                       const uint32_t *tinv, size_t nt, uint32_t *bound, uint32_t *seed_out)
 {
   if (q_count == 0 || nt == 0) return MVR_OK;
   ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count + 4.0 * (double)nt);
   MVR_HIP_TRY(c, hipMemsetAsync(bound, 0xFF, nt * sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(seed_bounds_kernel, dim3((unsigned)((q_count + 255) / 256)), dim3(256), 0, c->stream, keys, qperm, q_begin,
-                     q_count, max2, tinv, bound);
+                     q_count, max2, tinv, bound, seed_out);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }

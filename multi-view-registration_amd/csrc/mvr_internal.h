@@ -628,7 +628,7 @@ int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_
 int launch_seed_to_bound(Ctx *c, const float4 *qs, size_t nq, const float4 *ts, size_t nt, const uint32_t *seed, bool fma, uint32_t *bound);
 int launch_keys_to_seed(Ctx *c, const float4 *qs, size_t nq, const nnkey_t *keys, const uint32_t *tinv, uint32_t *seed);
 int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
-                       const uint32_t *tinv, size_t nt, uint32_t *bound);
+                       const uint32_t *tinv, size_t nt, uint32_t *bound, uint32_t *seed_out = nullptr);
 // culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)
 int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                         const uint32_t *tinv, size_t nt, uint8_t *flags);
