@@ -75,6 +75,47 @@ def test_config2_point_to_plane_200k_vs_oracle(gpu, orc, mvr):
         assert np.abs(gpu.download(2)[:, :3] - out[:, :3]).max() < 2e-4
 
 
+def test_config2_reciprocal_correspondences_200k_vs_scipy(gpu, mvr):
+    """An anchor that does not pass through this repo's oracle: the reciprocal correspondences of 2 x 200k posed scans
+    (App. A.2: j = NN_tgt(s_i) within max_d, kept iff NN_src(t_j) == i) from the GPU against scipy's cKDTree on the same
+    float32 points.  scipy measures in double, the spec (FLANN's L2_Simple on floats) in float: the two may pick different
+    neighbours only where two candidates are closer to each other than the float rounding of d2 -- every difference must be
+    such a near-tie, and there may be next to none of them."""
+    cKDTree = pytest.importorskip("scipy.spatial").cKDTree
+    one_variant(gpu)
+    N, max_d = 200000, 4.0
+    sp, scans, poses0 = scene(mvr, 12, N, 2)
+    gpu.upload(16, scans[1]); gpu.upload(17, scans[0])
+    gpu.transform(0, 16, poses0[1]); gpu.transform(1, 17, poses0[0])
+    q, m, d2 = gpu.correspondences(0, 1, max_d, reciprocal=True)
+    s = gpu.download(0)[:, :3].astype(np.float64); t = gpu.download(1)[:, :3].astype(np.float64)
+    ds, j = cKDTree(t).query(s)                    # forward: nearest target of every source point
+    dt, i_back = cKDTree(s).query(t[j])            # reverse: nearest source of that target
+    keep = (ds <= max_d) & (i_back == np.arange(N))
+    ref_q = np.nonzero(keep)[0]
+    ref = dict(zip(ref_q.tolist(), j[keep].tolist()))
+    got = dict(zip(q.tolist(), m.tolist()))
+    # float32 distance of a pair by the spec's expression (rounded per operation)
+    def d2f(a, b):
+        e = (s[a].astype(np.float32) - t[b].astype(np.float32))
+        r = np.float32(e[0] * e[0]); r = np.float32(r + np.float32(e[1] * e[1])); r = np.float32(r + np.float32(e[2] * e[2]))
+        return r
+    diff = [k for k in set(ref) | set(got) if ref.get(k) != got.get(k)]
+    assert len(diff) <= 20, (len(diff), len(ref), len(got))          # (a handful of near-ties in 200k at most)
+    for k in diff:
+        # a difference is a near-tie: the neighbour scipy chose and the one the GPU chose (or the cap, or the reverse winner)
+        # are within a few ulp of each other in float
+        if k in ref and k in got:
+            a, b = d2f(k, ref[k]), d2f(k, got[k])
+            assert abs(float(a) - float(b)) <= 4 * np.spacing(max(a, b)), (k, a, b)
+    # the distances of the agreed pairs: the GPU's float d2 equals the spec's expression on the downloaded points, bit for bit
+    both = [k for k in got if ref.get(k) == got[k]][:5000]
+    dg = dict(zip(q.tolist(), d2.tolist()))
+    for k in both[::50]:
+        assert np.float32(dg[k]) == d2f(k, got[k]), k
+    assert abs(len(got) - len(ref)) <= 20 and len(got) > 0.2 * N
+
+
 # ------------------------------------------------------------------ configs[2]
 
 def test_config3_sequential_12x200k_vs_oracle_driver(gpu, orc, mvr):
