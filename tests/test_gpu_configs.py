@@ -116,6 +116,32 @@ def test_config2_reciprocal_correspondences_200k_vs_scipy(gpu, mvr):
     assert abs(len(got) - len(ref)) <= 20 and len(got) > 0.2 * N
 
 
+def test_config2_rigid_solve_200k_vs_numpy_kabsch(gpu, mvr):
+    """The second half of an ICP iteration against an independent construction: one align of 2 x 200k posed scans
+    (reference settings: one iteration) must return the rigid motion numpy's SVD gives for the GPU's own accepted
+    correspondences (Kabsch / Umeyama without scaling in float64: R = U diag(1, 1, det) V^T of the cross-covariance,
+    t = mean_q - R mean_p) -- rotation within 1e-5, translation within 1e-4 mm; and the mean squared distance it reports is
+    the mean of the d2 of those correspondences."""
+    one_variant(gpu)
+    N, max_d = 200000, 4.0
+    sp, scans, poses0 = scene(mvr, 12, N, 2)
+    gpu.upload(16, scans[1]); gpu.upload(17, scans[0])
+    gpu.transform(0, 16, poses0[1]); gpu.transform(1, 17, poses0[0])
+    q, m, d2 = gpu.correspondences(0, 1, max_d, reciprocal=True)
+    T, st, rc = gpu.icp_align(0, 1, 2, mvr.icp_params(max_dist=max_d, max_iter=1000))
+    assert rc == 0 and st["iterations"] == 1 and st["n_corr"] == len(q)
+    p = gpu.download(0)[q, :3].astype(np.float64); t = gpu.download(1)[m, :3].astype(np.float64)
+    pm, tm = p.mean(0), t.mean(0)
+    H = (t - tm).T @ (p - pm) / len(q)                      # sigma = E[(q - mq)(p - mp)^T]
+    U, S, Vt = np.linalg.svd(H)
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+    R = U @ D @ Vt
+    tr = tm - R @ pm
+    To = np.eye(4); To[:3, :3] = R; To[:3, 3] = tr
+    assert_pose_close(T, To, "align vs Kabsch")
+    assert abs(st["mse"] - float(d2.astype(np.float64).mean())) <= 1e-9 * max(1.0, st["mse"])
+
+
 # ------------------------------------------------------------------ configs[2]
 
 def test_config3_sequential_12x200k_vs_oracle_driver(gpu, orc, mvr):
