@@ -311,3 +311,45 @@ def test_config4_full_size_ring_every_search_route_gives_the_same_tables(mvr):
     assert runs[0][2] > 900000
     for r in runs[1:]:
         assert r == runs[0]
+
+
+def test_config4_full_size_edge_table_vs_scipy_and_numpy(mvr):
+    """One pass of the 12 x 200k ring in the steady state of a registration (grid walk, pipelined loop) against constructions
+    that pass through neither the oracle nor the library's own other kernels: for three edges the accepted correspondences
+    the pass leaves (mvr_pair_batch_correspondences) are the reciprocal nearest neighbours scipy's cKDTree finds between
+    the two posed clouds (differences only at float near-ties), and the edge's row of the table -- count, sums of the points,
+    of their outer products and of d2, about the origin -- is what numpy adds up over those pairs (1e-11 relative: the GPU adds
+    in double, in its own order)."""
+    cKDTree = pytest.importorskip("scipy.spatial").cKDTree
+    V, N, max_d = 12, 200000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v])
+        poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=12)
+        assert ctx.stat("piped_passes") >= 5
+        poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin, steps=1)      # the pass that is checked
+        rows = info["rows"]
+        for e in (0, 5, V - 1):
+            a, b = edges[e]
+            q, m, d2 = ctx.pair_batch_correspondences(e, N)
+            s32, t32 = ctx.download(a)[:, :3], ctx.download(b)[:, :3]
+            s, t = s32.astype(np.float64), t32.astype(np.float64)
+            ds, j = cKDTree(t).query(s)
+            dt, back = cKDTree(s).query(t[j])
+            keep = (ds <= max_d) & (back == np.arange(N))
+            ref = dict(zip(np.nonzero(keep)[0].tolist(), j[keep].tolist()))
+            got = dict(zip(q.tolist(), m.tolist()))
+            diff = [k for k in set(ref) | set(got) if ref.get(k) != got.get(k)]
+            assert len(diff) <= 20 and len(got) > 50000, (e, len(diff), len(got))
+            # the row: {n, origin[3], sum p', sum q', sum p'p'^T (6), sum q'q'^T (6), sum p'q'^T (9), sum d2}
+            pc, qc = s[q] - origin, t[m] - origin
+            sym = lambda M: np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+            want = np.concatenate([[len(q)], origin, pc.sum(0), qc.sum(0), sym(pc.T @ pc), sym(qc.T @ qc), (pc.T @ qc).ravel(), [d2.astype(np.float64).sum()]])
+            scale = np.maximum(np.abs(want), np.array([1.0] * 4 + [np.abs(pc).sum()] * 6 + [(pc * pc).sum()] * 21 + [1.0]))
+            assert np.all(np.abs(rows[e] - want) <= 1e-11 * scale), (e, np.abs(rows[e] - want) / scale)
