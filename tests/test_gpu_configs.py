@@ -353,3 +353,41 @@ def test_config4_full_size_edge_table_vs_scipy_and_numpy(mvr):
             want = np.concatenate([[len(q)], origin, pc.sum(0), qc.sum(0), sym(pc.T @ pc), sym(qc.T @ qc), (pc.T @ qc).ravel(), [d2.astype(np.float64).sum()]])
             scale = np.maximum(np.abs(want), np.array([1.0] * 4 + [np.abs(pc).sum()] * 6 + [(pc * pc).sum()] * 21 + [1.0]))
             assert np.all(np.abs(rows[e] - want) <= 1e-11 * scale), (e, np.abs(rows[e] - want) / scale)
+
+
+def test_config4_registration_approaches_the_ground_truth(mvr):
+    """What no comparison with a restatement can show: that the registration REGISTERS.  The synthetic scans are one object
+    turned by v * 30 degrees about a known axis, the prior that starts the registration is off by (1.5, -1, 2) mm in the pivot
+    and 0.5 degrees in the axis -- up to 6.3 mm on the object's surface.  The passes of the global registration (reciprocal
+    correspondences within 4 mm, Lu-Milios with 16 iterations per pass, registrator.cpp:623-664) must bring every view towards
+    the TRUE motion, pass after pass: the largest displacement of a scan point from where the truth puts it falls below a
+    third of the prior's within 45 passes and keeps falling (measured: 6.3 -> 4.2 -> 2.7 -> 2.0 -> 1.5 mm after 1 / 5 / 15 / 45)."""
+    V, N, max_d = 12, 200000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    a = np.array(sp.axis); a /= np.linalg.norm(a)
+    truth = [np.eye(4)] + [mvr.axis_rotation(np.array(sp.pivot), a, mvr.turntable_angle(v, V)) for v in range(1, V)]
+
+    def worst(P):
+        out = 0.0
+        for v in range(1, V):
+            p = scans[v][::200, :3].astype(np.float64)
+            e = (p @ P[v][:3, :3].T + P[v][:3, 3]) - (p @ truth[v][:3, :3].T + truth[v][:3, 3])
+            out = max(out, float(np.sqrt((e * e).sum(1)).max()))
+        return out
+
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    errs = [worst(poses0)]
+    assert 5.0 < errs[0] < 8.0
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v])
+        P = [p.copy() for p in poses0]
+        for steps in (1, 4, 10, 30):
+            P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, P, max_d, origin, steps=steps)
+            errs.append(worst(P))
+    assert all(b < a for a, b in zip(errs, errs[1:])), errs
+    assert errs[-1] < errs[0] / 3.0, errs
