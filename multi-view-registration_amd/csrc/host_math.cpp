@@ -814,7 +814,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   if (n < 2 || ne < 0 || !es || !et || !m2 || !poses) return MVR_E_ARG;
   for (int e = 0; e < ne; ++e) if (es[e] < 0 || es[e] >= n || et[e] < 0 || et[e] >= n) return MVR_E_ARG;
   const int dim = 6 * (n - 1);
-  std::vector<double> G((size_t)dim * dim), B(dim), cinv((size_t)ne * 36), cinvd((size_t)ne * 6);
+  std::vector<double> G, B(dim), cinv((size_t)ne * 36), cinvd((size_t)ne * 6);      // (G: the dense matrix, only if the dense route runs)
   // edge between an (unordered) vertex pair, looked up once: first as (s, t), then as (t, s)
   std::vector<int> eidx((size_t)n * n, -1);
   std::vector<char> efwd((size_t)n * n, 0);
@@ -920,7 +920,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
       if (!solved) std::fill(B.begin(), B.end(), 0.0);
     }
     if (!solved) {
-    std::fill(G.begin(), G.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
+    G.assign((size_t)dim * dim, 0.0); std::fill(B.begin(), B.end(), 0.0);
     for (int vi = 1; vi < n; ++vi)
       for (int vj = 0; vj < n; ++vj) {
         const int e = eidx[(size_t)vi * n + vj];
