@@ -852,7 +852,7 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   std::vector<double> Dc, Oc;
   if (chain) { Dc.resize((size_t)(n - 1) * 48 + 8); Oc.resize((size_t)std::max(n - 2, 1) * 48 + 8); }      // (blocks of 6 rows of 8: solve_chain6)
   std::vector<double> band, bscratch;
-  if (banded) { band.resize((size_t)(dim + kBandW) * 2 * kBandW); bscratch.resize((size_t)2 * dim + 4 * kBandW); }
+
   std::vector<double> Tv((size_t)n * 16);
   std::vector<PoseTrig> trig((size_t)n);
   int it = 0;
@@ -903,7 +903,8 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
     }
     if (!solved && banded) {
       constexpr int S = 2 * kBandW;
-      std::fill(band.begin(), band.end(), 0.0); std::fill(B.begin(), B.end(), 0.0);
+      band.assign((size_t)(dim + kBandW) * 2 * kBandW, 0.0); bscratch.resize((size_t)2 * dim + 4 * kBandW);      // (only if this route runs)
+      std::fill(B.begin(), B.end(), 0.0);
       for (int vi = 1; vi < n; ++vi)
         for (const Nbr &nb : nbrs[(size_t)vi]) {    // (the order the dense assembly adds the diagonal blocks up in)
           const int vj = nb.vj, e = nb.e;
