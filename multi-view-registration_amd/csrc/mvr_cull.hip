@@ -774,7 +774,9 @@ nn_cull_body(const float4 *__restrict__ qs, uint32_t q_begin, uint32_t q_count, 
 // u mod 8, one slice after the other: an XCD works on one target at a time and a target is read by `slices` XCDs
 // instead of 8.  Interleaved slices keep the XCDs balanced: heavy query sets are neighbours in the Hilbert order.
 template <bool FMA, int Q, int W>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? MVR_CULL_WAVES : 3)))
+// (residency: the four-waves-per-set instantiation is the lone launch of an align -- a dozen waves per SIMD in all, bound by its
+// chains: one more resident wave per SIMD measured 2.5 % faster there; the fused launches keep MVR_CULL_WAVES, beyond which they spill)
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(Q == 1 ? (W == 4 ? MVR_CULL_WAVES + 1 : MVR_CULL_WAVES) : 3)))
 nn_cull_kernel(CullBatch batch, XcdMap map, unsigned long long *__restrict__ evals)
 {
   uint32_t pair = 0, set = 0;
