@@ -691,6 +691,12 @@ API int mvr_cloud_transform(mvr_ctx *ctx, int dst, int src, const double T[16])
   if (!ctx || !slot_ok(dst) || !slot_ok(src) || !T) return MVR_E_ARG;
   Ctx *c = CTX(ctx);
   MVR_HIP_TRY(c, hipSetDevice(c->device));
+  // a posed COPY of a plain cloud that is going to be searched: the batch path with one entry -- where the set's ordering exists,
+  // ONE launch poses the source's sorted copy in order and writes the points in original order (and the grid-ordered copy) with
+  // it, instead of a transform launch now and a gather through the permutation at the first search (the sequential mode poses
+  // its source this way before every align: two launches and a dispatch gap less)
+  if (dst != src && c->nn_mode != 0 && c->posed_refresh && !c->slots[src].has_normals && c->slots[src].segs.empty() && c->slots[src].n)
+    return mvr_cloud_transform_batch(ctx, 1, &dst, &src, T);
   const size_t n = c->slots[src].n;
   if (dst != src) { c->slots[dst].n = 0; if (int rc = cloud_reserve(c, c->slots[dst], n, false)) return rc; }
   if (int rc = launch_transform_f64(c, c->slots[src].pts, c->slots[dst].pts, n, T)) return rc;
@@ -1875,8 +1881,13 @@ static bool prepare_source_grid(Ctx *c, const Cloud &posed_src, Cloud &cur, doub
   for (Cloud &o : c->slots) if (o.set_id == posed_src.set_id && o.canonical && o.n == posed_src.n) { src_canon = &o; break; }
   if (!src_canon) return false;
   if (ensure_grids(c, &src_canon, 1, max_dist + 0.5, c->stream, nullptr) != MVR_OK || !src_canon->grid || src_canon->grid->n != src_canon->n) return false;
+  // (the align searches the posed source where it lies: its grid-ordered coordinates may be current already -- the posing launch
+  // writes them along when the set has its grid)
+  const bool current = &cur == &posed_src && cur.gcoords_valid && cur.grid == src_canon->grid && cur.gsorted;
   cur.pose_known = true; cur.pose_stretch = posed_src.pose_stretch; std::memcpy(cur.pose, posed_src.pose, sizeof cur.pose);
-  cur.grid = src_canon->grid; cur.gcoords_valid = false;
+  cur.grid = src_canon->grid;
+  if (current) return true;
+  cur.gcoords_valid = false;
   Cloud *one = &cur;
   return refresh_grid_coords_batch(c, &one, 1) == MVR_OK && cur.gcoords_valid;
 }
