@@ -2052,17 +2052,18 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
   if (!reciprocal || nt == 0) return MVR_OK;
   // reverse: the distinct matched targets, each starting from the distance of the source that matched it
   if (int rc = ensure(c, c->bound, c->bound_cap, nt)) return rc;
-  if (int rc = launch_seed_bounds(c, c->keys, plan->qperm, 0, ns, max2, plan->tinv, nt, c->bound, seed_out)) return rc;
-  const size_t nl = std::min(ns, nt), chunks = (nt + 255) / 256;
-  if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
-  if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
-  if (int rc = ensure(c, c->bchunks, c->bchunks_cap, chunks + 8)) return rc;
-  if (int rc = ensure(c, c->bwide, c->bwide_cap, nl)) return rc;
   if (!c->bwide_count) {
     MVR_MAY_BLOCK(c, "the wide-query counters are not allocated yet");
     MVR_HIP_TRY(c, hipMalloc(&c->bwide_count, 3 * kWideCounters * sizeof(uint32_t)));
     MVR_HIP_TRY(c, hipMemsetAsync(c->bwide_count, 0, 3 * kWideCounters * sizeof(uint32_t), c->stream));
   }
+  uint32_t *rev_wide_count = c->bwide_count + kWideCounters - 1;      // (a counter the fused pass does not use; put to zero by the bounds launch)
+  if (int rc = launch_seed_bounds(c, c->keys, plan->qperm, 0, ns, max2, plan->tinv, nt, c->bound, seed_out, rev_wide_count)) return rc;
+  const size_t nl = std::min(ns, nt), chunks = (nt + 255) / 256;
+  if (int rc = ensure(c, c->slot, c->slot_cap, nt)) return rc;
+  if (int rc = ensure(c, c->list, c->list_cap, nl)) return rc;
+  if (int rc = ensure(c, c->bchunks, c->bchunks_cap, chunks + 8)) return rc;
+  if (int rc = ensure(c, c->bwide, c->bwide_cap, nl)) return rc;
   GlueBatch gb;
   gb.max2 = max2; gb.reciprocal = 1; gb.origin[0] = gb.origin[1] = gb.origin[2] = 0.0;
   GluePair &g = gb.p[0];
@@ -2071,8 +2072,7 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
   plan->slot = c->slot; plan->count = c->count;
   GridPair rev = make_grid_pair(tgt, 0, nl, cur, c->rkeys);
   rev.qlist = c->list; rev.qcount = c->count; rev.qbound = c->bound;
-  rev.wide_list = c->bwide; rev.wide_count = c->bwide_count + kWideCounters - 1;      // (a counter the fused pass does not use)
-  MVR_HIP_TRY(c, hipMemsetAsync(rev.wide_count, 0, sizeof(uint32_t), c->stream));
+  rev.wide_list = c->bwide; rev.wide_count = rev_wide_count;
   if (int rc = launch_nn_grid_batch(c, &rev, 1, cap2, fma)) return rc;
   return launch_nn_grid_wide_batch(c, &rev, 1, cap2, fma);
 }
@@ -2122,7 +2122,7 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   float fin[16], tr[16];
   std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
   Criteria crit(p);          // DefaultConvergenceCriteria (App. A.4)
-  double cur_mse = 0.0, evals = 0.0, fwdq = 0.0;
+  double cur_mse = 0.0, evals = 0.0, fwdq = 0.0, evals_total = 0.0;
   int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
   Cloud &tgt = c->slots[ts];
   // a target made of posed scans (the sequential mode's model) is searched through the scans' grids -- in the first
@@ -2143,12 +2143,14 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
     if (p->point_to_plane) { if (int rc = launch_p2plane(c, curp->pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc; }
-    else if (int rc = launch_pass2(c, curp->pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments)) return rc;
-    // the search kernels' running evaluation totals ride along with the moments (the statistic needs no wait of its own)
-    if (st && c->nn_mode != 0)
+    else if (int rc = launch_pass2(c, curp->pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments, (st && c->nn_mode != 0) ? c->evals + kEvalRegion : nullptr)) return rc;
+    // the search kernels' running evaluation totals ride along with the moments (the statistic needs neither a wait nor a copy
+    // of its own: the last sums launch adds the counters up into moments[18]; point-to-plane keeps the copy)
+    if (st && c->nn_mode != 0 && p->point_to_plane)
       MVR_HIP_TRY(c, hipMemcpyAsync(c->h_evals, c->evals + kEvalRegion, kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    if (int rc = read_moments(c, p->point_to_plane ? 64 : 18)) return rc;
+    if (int rc = read_moments(c, p->point_to_plane ? 64 : 19)) return rc;
     const double *h = c->h_moments;
+    if (st && c->nn_mode != 0 && !p->point_to_plane) evals_total = h[18];
     fwdq += (double)ns;
     evals += (c->nn_mode != 0) ? 0.0 : ev + h[17] * (double)ns;   // forward Ns*Nt + reverse Nt'*Ns (brute force)
     ncorr = (int)h[0];
@@ -2205,8 +2207,8 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   }
   std::memcpy(T_out, fin, sizeof fin);
   if (st && c->nn_mode != 0) {
-    evals = 0.0;
-    for (int k = 0; k < kEvalShards; ++k) evals += (double)c->h_evals[(size_t)k * kEvalStride];
+    evals = evals_total;
+    if (p->point_to_plane) { evals = 0.0; for (int k = 0; k < kEvalShards; ++k) evals += (double)c->h_evals[(size_t)k * kEvalStride]; }
   }
   if (st) {
     st->iterations = iters; st->converged = converged; st->state = state; st->n_corr = ncorr; st->mse = cur_mse;

@@ -313,9 +313,10 @@ __global__ void flag_matched_kernel(const nnkey_t *__restrict__ keys, const uint
 // bound[sorted target position] = bits of the forward d2 of A source that matched the target (array preset to ~0)
 __global__ void seed_bounds_kernel(const nnkey_t *__restrict__ keys, const uint32_t *__restrict__ qperm, size_t q_begin,
                                    size_t q_count, double max2, const uint32_t *__restrict__ tinv, uint32_t *__restrict__ bound,
-                                   uint32_t *__restrict__ seed)
+                                   uint32_t *__restrict__ seed, uint32_t *__restrict__ zero_word)
 {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && zero_word) *zero_word = 0u;      // (optional: a counter of the launches that follow, put back to zero on the way)
   if (k >= q_count) return;
   const size_t i = qperm ? qperm[q_begin + k] : (q_begin + k);
   const nnkey_t key = keys[i];
@@ -760,13 +761,13 @@ int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs)
 }
 
 int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
-                       const uint32_t *tinv, size_t nt, uint32_t *bound, uint32_t *seed_out)
+                       const uint32_t *tinv, size_t nt, uint32_t *bound, uint32_t *seed_out, uint32_t *zero_word)
 {
   if (q_count == 0 || nt == 0) return MVR_OK;
   ProfScope ps(c, MVR_K_GLUE, 16.0 * (double)q_count + 4.0 * (double)nt);
   MVR_HIP_TRY(c, hipMemsetAsync(bound, 0xFF, nt * sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(seed_bounds_kernel, dim3((unsigned)((q_count + 255) / 256)), dim3(256), 0, c->stream, keys, qperm, q_begin,
-                     q_count, max2, tinv, bound, seed_out);
+                     q_count, max2, tinv, bound, seed_out, zero_word);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }

@@ -628,7 +628,7 @@ int launch_mark_sorted(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_
 int launch_seed_to_bound(Ctx *c, const float4 *qs, size_t nq, const float4 *ts, size_t nt, const uint32_t *seed, bool fma, uint32_t *bound);
 int launch_keys_to_seed(Ctx *c, const float4 *qs, size_t nq, const nnkey_t *keys, const uint32_t *tinv, uint32_t *seed);
 int launch_seed_bounds(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
-                       const uint32_t *tinv, size_t nt, uint32_t *bound, uint32_t *seed_out = nullptr);
+                       const uint32_t *tinv, size_t nt, uint32_t *bound, uint32_t *seed_out = nullptr, uint32_t *zero_word = nullptr);
 // culled-mode reciprocal glue: flag the matched targets (one byte per sorted target position)
 int launch_flag_matched(Ctx *c, const nnkey_t *keys, const uint32_t *qperm, size_t q_begin, size_t q_count, double max2,
                         const uint32_t *tinv, size_t nt, uint8_t *flags);
@@ -652,7 +652,7 @@ int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *ke
                  int32_t *match, double *moments);
 // pass 2: sigma = (1/n) sum (q-mean_q)(p-mean_p)^T into moments[8..16]
 int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
-                 size_t q_begin, size_t q_count, double *moments);
+                 size_t q_begin, size_t q_count, double *moments, const unsigned long long *eval_totals = nullptr);
 // raw second moments about `origin` into out[0..31] (device pointer)
 int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys, const nnkey_t *rkeys,
                            const uint32_t *slot, const uint32_t *qperm, const uint32_t *tinv, size_t q_begin, size_t q_count,

@@ -332,12 +332,20 @@ pass2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, con
   block_partials<9>(acc, partials);
 }
 
+// (eval_totals, optional: the search kernels' running evaluation counters -- kEvalShards of them, kEvalStride apart; their sum
+// goes to moments[18] so that the statistic travels with the moments' copy instead of one of its own)
 __global__ void __launch_bounds__(kRT) pass2_final_kernel(const double *__restrict__ partials, int rows,
-                                                           double *__restrict__ moments)
+                                                           double *__restrict__ moments, const unsigned long long *__restrict__ eval_totals)
 {
   __shared__ double lds[9];
   double s[9];
   sum_rows<9>(partials, rows, s, lds);
+  if (eval_totals && threadIdx.x < 64) {
+    unsigned long long v = threadIdx.x < kEvalShards ? eval_totals[(size_t)threadIdx.x * kEvalStride] : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (threadIdx.x == 0) moments[18] = (double)v;
+  }
   if (threadIdx.x == 0) {
     const double n = moments[0];
     for (int k = 0; k < 9; ++k) moments[8 + k] = (n > 0) ? s[k] / n : 0.0;
@@ -772,14 +780,14 @@ int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *ke
 }
 
 int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
-                 size_t q_begin, size_t q_count, double *moments)
+                 size_t q_begin, size_t q_count, double *moments, const unsigned long long *eval_totals)
 {
   const int blocks = reduce_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
   hipLaunchKernelGGL(pass2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, qperm, q_begin,
                      q_count, moments, c->partials);
-  hipLaunchKernelGGL(pass2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments);
+  hipLaunchKernelGGL(pass2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments, eval_totals);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
