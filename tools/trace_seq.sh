@@ -7,9 +7,11 @@ rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/tools/seq_bench
 python3 - "$(find $O -name '*kernel_trace.csv' | head -1)" <<'P'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# an align begins with the f64 transform that poses its source; print the third-from-last one with the gaps
-idx=[i for i,r in enumerate(rows) if 'transform_f64_kernel' in r['Kernel_Name']]
-i0,i1=idx[-3],idx[-2]; t0=int(rows[i0]['Start_Timestamp']); prev=None
+# an align's forward search is its one launch of the culled kernel; print the third-from-last align with the gaps, from the posing
+# of its source (a few launches ahead of that search) to the same point of the next align
+idx=[i for i,r in enumerate(rows) if 'nn_cull_kernel' in r['Kernel_Name']]
+back=lambda i: max(j for j in range(i) if 'append_order_kernel' in rows[j]['Kernel_Name']) + 1
+i0,i1=back(idx[-3]),back(idx[-2]); t0=int(rows[i0]['Start_Timestamp']); prev=None
 for r in rows[i0:i1]:
     s=int(r['Start_Timestamp'])-t0; e=int(r['End_Timestamp'])-t0
     print("%8.1f %8.1f  dur %7.1f  gap %6.1f  %s" % (s/1e3, e/1e3, (e-s)/1e3, 0.0 if prev is None else (s-prev)/1e3, r['Kernel_Name'].replace('mvr::(anonymous namespace)::', '').replace('void ', '').split('(')[0][:50]))
