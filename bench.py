@@ -482,17 +482,13 @@ def main():
         for r in range(repeat):                                            # registrator.cpp:530: every sweep rebuilds the model from view 0
             ctx.sync()
             t0 = time.perf_counter()
-            ctx.transform(TARGET, RAW + 0, poses[0]); ctx.reserve(TARGET, V * N)
-            for v in order:
-                ctx.transform(SOURCE, RAW + v, poses[v])
-                T, st, rc = ctx.icp_align(SOURCE, TARGET, OUT, params)
-                poses[v] = mvr.mat4d_mul(T.astype(np.float64), poses[v])
-                ctx.append(TARGET, OUT)
-                if r == 0:
-                    ncorr.append(st["n_corr"])
+            # one sweep = ONE native call (mvr_seq_run: the loop of registrator.cpp:562-577 around mvr_icp_align)
+            poses, log = ctx.seq_run([RAW + v for v in range(V)], TARGET, SOURCE, OUT, params, poses, repeat=1)
             ctx.sync()
             per_sweep.append(time.perf_counter() - t0)
+            poses = [np.array(p) for p in poses]
             if r == 0:
+                ncorr = [e["n_corr"] for e in log]
                 first = [p.copy() for p in poses]
         return first, ncorr, per_sweep, order
     seq = None
@@ -509,8 +505,8 @@ def main():
                          "registrationICP runs them, target grows to %d points in each)" % (V, N, sweeps, len(seq_order), V * N),
                "ms_per_align": 1e3 * seq_dt / (sweeps * len(seq_order)), "queries_per_s": N * sweeps * len(seq_order) / seq_dt,
                "ms_per_align_by_sweep": [1e3 * t / len(seq_order) for t in seq_dts],
-               "note": "sweep 1 searches unseeded; from sweep 2 on every forward search starts from the scan's match of the sweep before "
-                       "(seq_seed); n_corr and the oracle comparison are sweep 1's",
+               "note": "one native call per sweep (mvr_seq_run); sweep 1 searches unseeded, from sweep 2 on every forward search starts from the "
+                       "scan's match of the sweep before (seq_seed); n_corr and the oracle comparison are sweep 1's",
                "n_corr": seq_ncorr}
         out["secondary_sequential"] = seq
 

@@ -254,6 +254,13 @@ int  mvr_seq_align_sharded(mvr_ctx *ctx, int src_slot, int tgt_slot, int out_slo
 int  mvr_seq_run_sharded(mvr_ctx *ctx, int n_views, const int *raw_slots, int target_slot, int source_slot, int out_slot,
                          const mvr_icp_params *params, const double origin[3], int repeat, double *poses, int *align_view,
                          float *align_T, mvr_icp_stats *align_stats, int *n_aligns);
+/* The same driver on ONE GPU around mvr_icp_align (Registrator::registrationICP, registrator.cpp:526-588, as one native call):
+ * `repeat` sweeps; each poses view 0 into target_slot (reserved once for all the scans) and aligns views 1, V-1, 2, ... against
+ * everything merged so far, pose_v <- T_icp * pose_v, target += aligned source.  poses: n_views x 16 column-major, in / out; the
+ * per-align outputs as above (capacity repeat * (n_views - 1), any may be NULL).  MVR_E_NOCORR of an align does not stop it. */
+int  mvr_seq_run(mvr_ctx *ctx, int n_views, const int *raw_slots, int target_slot, int source_slot, int out_slot,
+                 const mvr_icp_params *params, int repeat, double *poses, int *align_view, float *align_T,
+                 mvr_icp_stats *align_stats, int *n_aligns);
 
 /* raw second moments of caller-supplied correspondences (lum.setCorrespondences,
  * registrator.cpp:650): query[k] indexes src_slot, match[k] indexes tgt_slot. */

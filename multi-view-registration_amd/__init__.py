@@ -144,6 +144,8 @@ SIGNATURES = {
     "mvr_seq_align_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), _dp, _fp, C.POINTER(IcpStats)]),
     "mvr_seq_run_sharded": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), _dp, C.c_int, _dp,
                                       C.POINTER(C.c_int), _fp, C.POINTER(IcpStats), C.POINTER(C.c_int)]),
+    "mvr_seq_run": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(IcpParams), C.c_int, _dp,
+                              C.POINTER(C.c_int), _fp, C.POINTER(IcpStats), C.POINTER(C.c_int)]),
     "mvr_pair_batch_correspondences": (C.c_int, [_vp, C.c_int, _i32p, _i32p, _fp, _sz, C.POINTER(_sz)]),
     "mvr_pair_moments2_from_corr": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _sz, _dp,
                                               C.POINTER(PairMoments2)]),
@@ -672,6 +674,19 @@ class Context:
         o = np.ascontiguousarray(origin, np.float64)
         _chk(_lib.mvr_seq_run_sharded(self._h, V, rs, int(target_slot), int(source_slot), int(out_slot), C.byref(params), _p(o, C.c_double),
                                       int(repeat), _p(P, C.c_double), views, _p(Ts, C.c_float), sts, C.byref(n)), self._h)
+        log = [dict(self._stats(sts[k]), view=views[k], T=from_cm(Ts[k])) for k in range(n.value)]
+        return np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1)), log
+
+    def seq_run(self, raw_slots, target_slot, source_slot, out_slot, params: IcpParams, poses, repeat=1):
+        """mvr_seq_run: registrationICP (registrator.cpp:526-588) on one GPU as one native call -- `repeat` sweeps of aligns of
+        views 1, V-1, 2, ... against the growing model.  poses: V (4,4) float64 -> (new poses (V,4,4), log as seq_run_sharded)"""
+        V = len(raw_slots)
+        rs = (C.c_int * V)(*[int(v) for v in raw_slots])
+        P = np.ascontiguousarray(np.asarray(poses, np.float64).transpose(0, 2, 1)).reshape(V, 16)
+        cap = max(1, repeat * (V - 1))
+        views, Ts, sts, n = (C.c_int * cap)(), np.zeros((cap, 16), np.float32), (IcpStats * cap)(), C.c_int()
+        _chk(_lib.mvr_seq_run(self._h, V, rs, int(target_slot), int(source_slot), int(out_slot), C.byref(params), int(repeat),
+                              _p(P, C.c_double), views, _p(Ts, C.c_float), sts, C.byref(n)), self._h)
         log = [dict(self._stats(sts[k]), view=views[k], T=from_cm(Ts[k])) for k in range(n.value)]
         return np.ascontiguousarray(P.reshape(V, 4, 4).transpose(0, 2, 1)), log
 

@@ -2365,6 +2365,54 @@ API int mvr_seq_run_sharded(mvr_ctx *ctx, int n_views, const int *raw_slots, int
   return MVR_OK;
 }
 
+// Registrator::registrationICP (registrator.cpp:526-588) on ONE GPU, as one native call: `repeat` sweeps, each posing view 0 into
+// the model, then views 1, V-1, 2, ... aligned against everything merged so far (mvr_icp_align), pose_v <- T_icp * pose_v (:574)
+// and `*target += aligned source` (:576).  What a host language's loop over the same calls does (include/mvr/registrator.hpp:
+// registrationICPDevice; tests / bench: Python), without that language between the calls.  reserve_points: the model's final
+// size if known (0: the sum of the scans), reserved once so that the model grows in place.
+API int mvr_seq_run(mvr_ctx *ctx, int n_views, const int *raw_slots, int target_slot, int source_slot, int out_slot,
+                    const mvr_icp_params *p, int repeat, double *poses, int *align_view, float *align_T, mvr_icp_stats *align_stats,
+                    int *n_aligns)
+{
+  if (!ctx || n_views < 2 || !raw_slots || !p || !poses || repeat < 0) return MVR_E_ARG;
+  if (!slot_ok(target_slot) || !slot_ok(source_slot) || !slot_ok(out_slot) || target_slot == source_slot || target_slot == out_slot || source_slot == out_slot)
+    return MVR_E_ARG;
+  for (int v = 0; v < n_views; ++v)
+    if (!slot_ok(raw_slots[v]) || raw_slots[v] == target_slot || raw_slots[v] == source_slot || raw_slots[v] == out_slot) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<int> order;                                // registrator.cpp:530-541
+  for (int i = 1; i < n_views / 2; ++i) { order.push_back(i); order.push_back(n_views - i); }
+  if (n_views / 2 >= 1 && (order.empty() || order.back() != n_views / 2)) order.push_back(n_views / 2);
+  size_t total = 0;
+  for (int v = 0; v < n_views; ++v) total += c->slots[raw_slots[v]].n;
+  int done = 0;
+  if (n_aligns) *n_aligns = 0;
+  for (int r = 0; r < repeat; ++r) {
+    if (int rc = mvr_cloud_transform(ctx, target_slot, raw_slots[0], poses)) return rc;       // :562
+    if (int rc = mvr_cloud_reserve(ctx, target_slot, total)) return rc;
+    for (int v : order) {
+      if (int rc = mvr_cloud_transform(ctx, source_slot, raw_slots[v], poses + 16 * (size_t)v)) return rc;      // :565
+      float T[16];
+      mvr_icp_stats st;
+      std::memset(&st, 0, sizeof st);
+      const int rc = mvr_icp_align(ctx, source_slot, target_slot, out_slot, p, T, &st);                          // :566-569
+      if (rc != MVR_OK && rc != MVR_E_NOCORR) return rc;      // (PCL's "not enough correspondences": the driver goes on, registrator.cpp:569-574)
+      if (align_view) align_view[done] = v;
+      if (align_T) std::memcpy(align_T + 16 * (size_t)done, T, sizeof T);
+      if (align_stats) align_stats[done] = st;
+      ++done;
+      if (n_aligns) *n_aligns = done;
+      double Td[16], P[16];
+      for (int k = 0; k < 16; ++k) Td[k] = (double)T[k];
+      mvr_mat4d_mul(Td, poses + 16 * (size_t)v, P);            // :573-574
+      std::memcpy(poses + 16 * (size_t)v, P, sizeof P);
+      if (int rc2 = mvr_cloud_append(ctx, target_slot, out_slot)) return rc2;                                    // :576
+    }
+  }
+  return MVR_OK;
+}
+
 API int mvr_fitness(mvr_ctx *ctx, int is, int ts, const float T[16], double max_range, int fma, double *score)
 {
   if (!ctx || !slot_ok(is) || !slot_ok(ts) || !T || !score) return MVR_E_ARG;

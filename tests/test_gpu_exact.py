@@ -215,6 +215,15 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
     for r in seeded[1:]:
         assert seeded[0][1] == r[1], case
         assert seeded[0][0] == r[0] and seeded[0][2] == r[2], case
+    # ... and the native driver of the same loop (mvr_seq_run: one call for the three sweeps)
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(16 + v, scans[v])
+        nposes, nlog = ctx.seq_run([16 + v for v in range(V)], 0, 1, 2, params, poses0, repeat=3)
+        nmerged = ctx.download(0)
+    assert np.asarray(nposes).tobytes() == seeded[0][0] and nmerged.tobytes() == seeded[0][2], case
+    assert [(e["view"], e["n_corr"], e["iterations"], e["state"], e["mse"], np.asarray(e["T"], np.float32).tobytes()) for e in nlog] == \
+           [(l[0], l[1], l[2], l[3], l[4], l[5]) for l in seeded[0][1]], case
     # ... and against the oracle: the first align's correspondences, one by one
     with mvr.Context(0) as ctx:
         for v in range(V):

@@ -34,6 +34,14 @@ def gpu_sweep(mvr, ctx, scans, poses0, params, order, repeat):
     log = []
     ctx.sync()
     t0 = time.perf_counter()
+    if os.environ.get("MVR_SEQ_NATIVE", "1") != "0":                 # the whole run as ONE native call (mvr_seq_run)
+        nt = len(scans[0])
+        poses, nlog = ctx.seq_run([RAW + v for v in range(V)], TARGET, SOURCE, OUT, params, poses, repeat=repeat)
+        for k, e in enumerate(nlog):
+            nt = len(scans[0]) * (k % len(order) + 2)
+            log.append(dict(view=e["view"], n_corr=e["n_corr"], mse=e["mse"], ms=e["ms"], evals=e["evals"], nt=nt))
+        poses = [np.array(p) for p in poses]
+        repeat = 0
     for _ in range(repeat):
         ctx.transform(TARGET, RAW + 0, poses[0])                       # registrator.cpp:562
         ctx.reserve(TARGET, V * len(scans[0]))
