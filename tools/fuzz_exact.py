@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""tools/fuzz_exact.py [seconds] [seed] -- a randomised exactness campaign on the GPU: rings of 3..9 views with ragged sizes,
+random mis-calibrations, radii, frames far from the origin, a few passes each -- the edge tables and poses of the default route
+(grid walk with its probe, stragglers, pipelined loop) must equal those of the culled kernel alone and of other routings, bit for
+bit, and the brute-force kernel's in counts and to rounding in the sums (it adds in another order); and the sequential mode over three sweeps with and without the seeds.  Prints one line per failure and a summary."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+mvr = importlib.import_module("multi-view-registration_amd")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t_end = time.time() + budget
+cases = fails = 0
+while time.time() < t_end:
+    V = int(rng.integers(3, 10))
+    sizes = [int(rng.integers(300, 30000)) for _ in range(V)]
+    sp = mvr.synth_params(V, int(rng.integers(0, 1000)))
+    scans = [mvr.synth_view(sp, v, sizes[v]) for v in range(V)]
+    far = float(rng.choice([0.0, 0.0, 1e3, 1e5]))                    # the raw frame may sit far from the origin
+    shift = rng.normal(size=3); shift *= far / max(np.linalg.norm(shift), 1e-9)
+    for s_ in scans:
+        s_[:, :3] += shift.astype(np.float32)
+    piv, ax = mvr.synth_prior(sp)
+    piv = np.array(piv) + shift + rng.normal(size=3) * float(rng.uniform(0, 2.0))
+    ax = np.array(ax) + rng.normal(size=3) * float(rng.uniform(0, 0.01)); ax /= np.linalg.norm(ax)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    back = np.eye(4); back[:3, 3] = -shift                              # pose the scans back next to the origin
+    poses0 = [back @ p for p in poses0]
+    max_d = float(rng.choice([0.5, 2.0, 4.0, 4.0, 10.0]))
+    passes = int(rng.integers(2, 7))
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for knobs in ({}, dict(ring_search=0), dict(pipeline=0, grid_probe=0), dict(grid_light_rows=3, grid_cluster=2, cull_w=4)):
+        with mvr.Context(0) as ctx:
+            ctx.tune(**knobs)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            try:
+                P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=passes)
+                runs.append((np.asarray(P).tobytes(), info["rows"].tobytes()))
+            except mvr.MvrError as e:
+                runs.append(("error", str(e)))
+    # the brute-force kernel adds its sums in another order: ONE pass, the same counts and d2 sums, the other sums to 1e-9
+    one = []
+    for knobs in ({}, dict(nn_mode=0)):
+        with mvr.Context(0) as ctx:
+            ctx.tune(**knobs)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            try:
+                P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=1)
+                one.append(info["rows"].copy())
+            except mvr.MvrError as e:              # (a pair without three correspondences: a singular LUM system, on every route)
+                one.append(str(e))
+    if isinstance(one[0], str) or isinstance(one[1], str):
+        ok = one[0] == one[1] if isinstance(one[0], str) and isinstance(one[1], str) else False
+    else:
+        scale = np.maximum(np.abs(one[0]), 1.0)
+        ok = np.array_equal(one[0][:, 0], one[1][:, 0]) and np.all(np.abs(one[0] - one[1]) <= 1e-9 * scale * np.maximum(one[0][:, :1], 1.0))
+    if not ok:
+        fails += 1
+        print("BRUTE MISMATCH V=%d sizes=%s far=%g max_d=%g: %s vs %s" % (V, sizes, far, max_d, one[0] if isinstance(one[0], str) else one[0][:, 0].tolist(),
+                                                                             one[1] if isinstance(one[1], str) else one[1][:, 0].tolist()), flush=True)
+    cases += 1
+    if not all(r == runs[0] for r in runs[1:]):
+        fails += 1
+        print("RING MISMATCH V=%d sizes=%s far=%g max_d=%g passes=%d: %s" % (V, sizes, far, max_d, passes, [r == runs[0] for r in runs]), flush=True)
+    # the sequential mode: three sweeps, seeds on / off, culled both ways
+    if V >= 4:
+        params = mvr.icp_params(max_dist=max_d, max_iter=int(rng.choice([1000, 3])), teps=float(rng.choice([1e-6, 0.0])), feps=float(rng.choice([64.0, -1e300])))
+        seq = []
+        for knobs in (dict(seq_seed=1), dict(seq_seed=0), dict(seq_search=0, seq_seed=0)):
+            with mvr.Context(0) as ctx:
+                ctx.tune(**knobs)
+                for v in range(V):
+                    ctx.upload(16 + v, scans[v])
+                try:
+                    P, log = ctx.seq_run([16 + v for v in range(V)], 0, 1, 2, params, poses0, repeat=3)
+                    seq.append((np.asarray(P).tobytes(), [(e["view"], e["n_corr"], e["iterations"], e["mse"]) for e in log], ctx.download(0).tobytes()))
+                except mvr.MvrError as e:
+                    seq.append(("error", str(e)))
+        if not all(r == seq[0] for r in seq[1:]):
+            fails += 1
+            print("SEQ MISMATCH V=%d sizes=%s far=%g max_d=%g: %s" % (V, sizes, far, max_d, [r == seq[0] for r in seq]), flush=True)
+print("fuzz: %d cases, %d failures" % (cases, fails))
+sys.exit(1 if fails else 0)
