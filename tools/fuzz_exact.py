@@ -12,10 +12,14 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 cases = fails = 0
 while time.time() < t_end:
-    V = int(rng.integers(3, 10))
-    sizes = [int(rng.integers(300, 30000)) for _ in range(V)]
+    V = int(rng.integers(3, 10)) if rng.random() < 0.9 else int(rng.integers(17, 21))      # (now and then more views than one posing launch takes)
+    sizes = [int(rng.integers(300, 30000 if V < 17 else 6000)) for _ in range(V)]
     sp = mvr.synth_params(V, int(rng.integers(0, 1000)))
     scans = [mvr.synth_view(sp, v, sizes[v]) for v in range(V)]
+    if rng.random() < 0.2:                                             # exact duplicates: ties in every search (lowest index wins)
+        for s_ in scans:
+            k = max(1, len(s_) // 20); src = rng.integers(0, len(s_), k); dst = rng.integers(0, len(s_), k); s_[dst, :3] = s_[src, :3]
+    fma = bool(rng.random() < 0.25)
     far = float(rng.choice([0.0, 0.0, 1e3, 1e5]))                    # the raw frame may sit far from the origin
     shift = rng.normal(size=3); shift *= far / max(np.linalg.norm(shift), 1e-9)
     for s_ in scans:
@@ -37,7 +41,7 @@ while time.time() < t_end:
             for v in range(V):
                 ctx.upload(V + v, scans[v])
             try:
-                P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=passes)
+                P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=passes, fma=fma)
                 runs.append((np.asarray(P).tobytes(), info["rows"].tobytes()))
             except mvr.MvrError as e:
                 runs.append(("error", str(e)))
@@ -49,7 +53,7 @@ while time.time() < t_end:
             for v in range(V):
                 ctx.upload(V + v, scans[v])
             try:
-                P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=1)
+                P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=1, fma=fma)
                 one.append(info["rows"].copy())
             except mvr.MvrError as e:              # (a pair without three correspondences: a singular LUM system, on every route)
                 one.append(str(e))
@@ -67,8 +71,8 @@ while time.time() < t_end:
         fails += 1
         print("RING MISMATCH V=%d sizes=%s far=%g max_d=%g passes=%d: %s" % (V, sizes, far, max_d, passes, [r == runs[0] for r in runs]), flush=True)
     # the sequential mode: three sweeps, seeds on / off, culled both ways
-    if V >= 4:
-        params = mvr.icp_params(max_dist=max_d, max_iter=int(rng.choice([1000, 3])), teps=float(rng.choice([1e-6, 0.0])), feps=float(rng.choice([64.0, -1e300])))
+    if 4 <= V <= 12:
+        params = mvr.icp_params(max_dist=max_d, max_iter=int(rng.choice([1000, 3])), teps=float(rng.choice([1e-6, 0.0])), feps=float(rng.choice([64.0, -1e300])), fma=fma)
         seq = []
         for knobs in (dict(seq_seed=1), dict(seq_seed=0), dict(seq_search=0, seq_seed=0)):
             with mvr.Context(0) as ctx:
