@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""tools/leak_probe.py [cycles] -- device memory before / after many context lifecycles (uploads, ring passes incl. the pipelined loop,
+a sequential run with seeds, destroy): what the library allocates it must give back.  Uses hipMemGetInfo of the process's HIP runtime."""
+import ctypes as C, importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+mvr = importlib.import_module("multi-view-registration_amd")
+hip = C.CDLL(None)      # (the HIP runtime the package has loaded already: its symbols are global)
+def free_mb():
+    f, t = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+    return f.value / 2**20
+cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+V, N = 8, 20000
+sp = mvr.synth_params(V, 3)
+scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+piv, ax = mvr.synth_prior(sp)
+poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+origin = np.array(sp.pivot); edges = [(i, (i + 1) % V) for i in range(V)]
+params = mvr.icp_params(max_dist=4.0, max_iter=1000)
+def cycle():
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v]); ctx.upload(16 + V + v, scans[v])
+        P, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], 4.0, origin, steps=8)
+        ctx.seq_run([16 + V + v for v in range(V)], 40, 41, 42, params, poses0, repeat=2)
+        ctx.sync()
+for _ in range(3):
+    cycle()
+before = free_mb()
+for k in range(cycles):
+    cycle()
+after = free_mb()
+print("free device memory: %.1f MB before, %.1f MB after %d context lifecycles (difference %.1f MB)" % (before, after, cycles, before - after))
+sys.exit(0 if before - after < 64.0 else 1)
