@@ -168,7 +168,6 @@ __device__ __forceinline__ float gdist2(const float4 t, float qx, float qy, floa
   r = r + dz * dz;
   return r;
 }
-
 // The ball of a bounded query in the searched cloud's CANONICAL frame: centre r = minv (q, 1), radius rad.
 // What the margin has to cover (everything else is exact): the query q and the posed target points are FLOAT roundings
 // of the exact motion -- half an ulp per coordinate at the POSED magnitude (3e-5 mm at |p| ~ 1e3 mm), which the inverse
@@ -246,8 +245,18 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     // range of the grid-ordered array each); the next row's range is requested while this row's points are evaluated.
     // (a row's range = two entries of the cell-start array at most three cells apart in all but the widest balls:
     // ONE 16-byte load from the first of them brings both)
-    float bd = bound;                 // candidates beyond the bound cannot be the answer; at the bound they can (inclusive)
-    uint32_t bi = kNone, bk = 0;
+    // The candidate so far as ONE 64-bit number, (bits of d2, original index): d2 >= +0, so the order of the bits is the order of
+    // the distances, and "nearer, or as near with the smaller index" is one unsigned comparison.  It starts at (bound, none):
+    // candidates beyond the bound cannot be the answer; at the bound they can (inclusive).
+    unsigned long long best = ((unsigned long long)__float_as_uint(bound) << 32) | kNone;
+    // (WHERE in the grid order the winner lies is not kept: its Hilbert position, which the keys and the marks want, comes
+    // from its original index through the ordering's inverse -- one gather per query either way, three instructions less
+    // per candidate round and four registers: 62 instead of 66, the eighth wave per SIMD)
+    const uint32_t nt4 = a.nt - 4u;     // (a grid is only built for a set of four points or more)
+    auto take = [&](const float4 t) {
+      const unsigned long long cand = ((unsigned long long)__float_as_uint(gdist2<FMA>(t, q.x, q.y, q.z)) << 32) | __float_as_uint(t.w);
+      best = cand < best ? cand : best;
+    };
     auto walk_box = [&](const int wx0, const int wx1, const int wy0, const int wy1, const int wz0, const int wz1) {
       const uint32_t nxm = (uint32_t)(wx1 - wx0);
       auto row_range = [&](uint32_t row, uint32_t &s, uint32_t &e) {
@@ -275,19 +284,15 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
         }
         if (sub == 0) n_eval += e - s;
         if (G == 1) {
-          // one lane per query: the points four at a time (a short row repeats its last point: re-evaluating a point
-          // changes nothing)
+          // one lane per query: four CONSECUTIVE points per round from one address (the loads differ by their immediate offsets).
+          // A short row runs on into the points behind it -- points of the target all the same: looking at one more changes
+          // nothing (whatever lies within the bound lies in the ball's cells and is looked at anyway); only the array's end is
+          // kept clear of (the last round starts four points before it at the latest).
           for (uint32_t k = s; k < e; k += 4) {
-            const uint32_t last = e - 1u;
-            const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
-            const float4 t0 = a.gts[k], t1 = a.gts[k1], t2 = a.gts[k2], t3 = a.gts[k3];
-            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
-            const float d2 = gdist2<FMA>(t2, q.x, q.y, q.z), d3 = gdist2<FMA>(t3, q.x, q.y, q.z);
-            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w), o2 = __float_as_uint(t2.w), o3 = __float_as_uint(t3.w);
-            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
-            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
-            if (d2 < bd || (d2 == bd && o2 < bi)) { bd = d2; bi = o2; bk = k2; }
-            if (d3 < bd || (d3 == bd && o3 < bi)) { bd = d3; bi = o3; bk = k3; }
+            const uint32_t kb = min(k, nt4);
+            const float4 *__restrict__ p4 = a.gts + kb;
+            const float4 t0 = p4[0], t1 = p4[1], t2 = p4[2], t3 = p4[3];
+            take(t0); take(t1); take(t2); take(t3);
           }
         } else {
           // G lanes per query: they take CONSECUTIVE points of the row -- one instruction, one cache line per query
@@ -296,10 +301,7 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
           for (uint32_t k = s + sub; k < e; k += 2 * G) {
             const uint32_t k1 = k + G < e ? k + G : k;
             const float4 t0 = a.gts[k], t1 = a.gts[k1];
-            const float d0 = gdist2<FMA>(t0, q.x, q.y, q.z), d1 = gdist2<FMA>(t1, q.x, q.y, q.z);
-            const uint32_t o0 = __float_as_uint(t0.w), o1 = __float_as_uint(t1.w);
-            if (d0 < bd || (d0 == bd && o0 < bi)) { bd = d0; bi = o0; bk = k; }
-            if (d1 < bd || (d1 == bd && o1 < bi)) { bd = d1; bi = o1; bk = k1; }
+            take(t0); take(t1);
           }
         }
         s = s2; e = e2;
@@ -319,8 +321,8 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       const int py0 = max(cy - (fy - (float)cy < 0.5f ? 1 : 0), 0), py1 = min(py0 + 1, a.dim[1] - 1);
       const int pz0 = max(cz - (fz - (float)cz < 0.5f ? 1 : 0), 0), pz1 = min(pz0 + 1, a.dim[2] - 1);
       walk_box(px0, px1, py0, py1, pz0, pz1);
-      if (bi != kNone) {              // (bd <= the old bound: the walk only takes candidates within it)
-        ball = grid_ball(a, q, bd);
+      if ((uint32_t)best != kNone) {              // (its distance <= the old bound: the walk only takes candidates within it)
+        ball = grid_ball(a, q, __uint_as_float((uint32_t)(best >> 32)));
         rad = ball.rad;
         x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]); x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
         y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]); y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
@@ -347,16 +349,17 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       // the group's answer: the smallest (d2, index) of its lanes
 #pragma unroll
       for (int o = 1; o < G; o <<= 1) {
-        const float od = __shfl_xor(bd, o, 64);
-        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, o, 64), ok = (uint32_t)__shfl_xor((int)bk, o, 64);
-        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; bk = ok; }
+        const unsigned long long ob = __shfl_xor(best, o, 64);
+        if (ob < best) best = ob;
       }
+      const float bd = __uint_as_float((uint32_t)(best >> 32));
+      const uint32_t bi = (uint32_t)best;
       if (sub == 0) {
         const bool found = bi != kNone && bd <= cap2;
         const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
         uint32_t low = bi;
         if (found && (a.key_by_pos || a.mark)) {
-          const uint32_t hp = a.g2h[bk];              // the match's position in its set's Hilbert order
+          const uint32_t hp = a.tinv[bi];              // the match's position in its set's Hilbert order
           if (a.key_by_pos) low = hp;
           if (a.mark) __hip_atomic_store(&a.mark[hp], __float_as_uint(bd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -517,7 +520,7 @@ int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream
   std::vector<Cloud *> todo;
   for (int k = 0; k < count; ++k) {
     Cloud *cl = canon[k];
-    if (!cl || !cl->canonical || cl->n == 0 || cl->n > 0x7FFFFFFFull) continue;      // (hipCUB's sort takes an int count; such a cloud keeps the culled kernel)
+    if (!cl || !cl->canonical || cl->n < 4 || cl->n > 0x7FFFFFFFull) continue;      // (hipCUB's sort takes an int count, the walk reads four points at a time; such a cloud keeps the culled kernel)
     if (cl->grid && cl->grid->n == cl->n) continue;
     cl->grid.reset();
     auto it = c->grids.find(cl->set_id);
@@ -745,6 +748,9 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     for (int k = 0; k < kGridBatchPairs; ++k) {
       batch.p[k] = k < m ? pairs[base + k] : GridPair{};
       if (k < m && batch.p[k].nt == 0) batch.p[k].q_count = 0;
+      // what the walk takes for granted: four points or more (it reads four at a time), and the ordering's inverse where a match's position is asked for
+      if (k < m && batch.p[k].q_count != 0 && (batch.p[k].nt < 4 || ((batch.p[k].key_by_pos || batch.p[k].mark) && !batch.p[k].tinv)))
+        return set_error(c, MVR_E_ARG, "nn_grid: a target of fewer than four points, or without its ordering");
       map.sets[k] = k < m ? (uint32_t)(((size_t)batch.p[k].q_count + per_block - 1) / per_block) : 0u;
       total += map.sets[k];
     }
