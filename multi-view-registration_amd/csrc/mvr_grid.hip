@@ -182,10 +182,12 @@ __device__ __forceinline__ Ball grid_ball(const GridPair &a, const float4 q, con
   const float stretch = a.pose_dev ? a.pose_dev->stretch : a.stretch;
   const double qx = q.x, qy = q.y, qz = q.z;
   Ball b;
-  b.rx = (float)(((mi[0] * qx + mi[1] * qy) + mi[2] * qz) + mi[3]);
-  b.ry = (float)(((mi[4] * qx + mi[5] * qy) + mi[6] * qz) + mi[7]);
-  b.rz = (float)(((mi[8] * qx + mi[9] * qy) + mi[10] * qz) + mi[11]);
-  b.rad = (sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * stretch +
+  // (fused multiply-adds and the bare v_sqrt_f32 -- one ulp -- on purpose: nothing here is a result, the margins are tens of ulps
+  // wide, and the walk is bound by the vector instructions a wave issues: twenty fewer per 64 queries)
+  b.rx = (float)(__builtin_fma(mi[2], qz, __builtin_fma(mi[1], qy, mi[0] * qx)) + mi[3]);
+  b.ry = (float)(__builtin_fma(mi[6], qz, __builtin_fma(mi[5], qy, mi[4] * qx)) + mi[7]);
+  b.rz = (float)(__builtin_fma(mi[10], qz, __builtin_fma(mi[9], qy, mi[8] * qx)) + mi[11]);
+  b.rad = (__builtin_amdgcn_sqrtf(bound) * 1.00001f + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)))) * stretch +
           2.0e-6f * (fabsf(b.rx) + fabsf(b.ry) + fabsf(b.rz));
   return b;
 }
@@ -215,15 +217,16 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
   bool went_wide = false, went_cull = false;
   if (pos < nq) {
     const uint32_t qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;            // position in the query cloud's Hilbert order
+    // (the three loads that depend on nothing but the position go out together: the prologue is a chain of dependent gathers,
+    // query -> previous match -> its grid position -> its coordinates, and every link not waited for separately is a round trip less)
     const float4 q = a.qs[qpos];
+    const uint32_t start_bits = a.qbound ? a.qbound[qpos] : 0xFFFFFFFFu;
+    const uint32_t prev = a.seed_from_keys ? (uint32_t)a.keys[qpos] : kNone;
     // the bound: the cap, or a distance within which a point is KNOWN to exist (inclusive)
     float bound = cap2;
     bool seeded = false;
-    if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) { bound = __uint_as_float(v); seeded = true; } }
-    if (a.seed_from_keys) {
-      const uint32_t prev = (uint32_t)a.keys[qpos];
-      if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }      // (the same point, read from the array the walk is about to read)
-    }
+    if (start_bits <= __float_as_uint(bound)) { bound = __uint_as_float(start_bits); seeded = true; }
+    if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }      // (the same point, read from the array the walk is about to read)
     // the ball in the target's canonical frame (the mapping itself is done in double)
     Ball ball = grid_ball(a, q, bound);
     const float rx = ball.rx, ry = ball.ry, rz = ball.rz;
