@@ -1246,6 +1246,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
       if (c->cull_w == 0 && sets >= (size_t)c->n_cu * 40) c->cull_w = 1;
       int status = MVR_OK;
       if (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) status = set_error(c, MVR_E_HIP, "fork event");
+      if (status == MVR_OK) status = flush_super_boxes(c);      // (what every group may read, before the fork: a group on the culled kernel then finds its super boxes)
       if (status == MVR_OK && hipEventRecord(c->ev_fork, c->stream) != hipSuccess) status = set_error(c, MVR_E_HIP, "fork");
       int forked = 0;
       for (int phase = 1; phase <= 2; ++phase)                      // all forward searches first, then each group's remaining stages
@@ -1281,6 +1282,7 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
     return MVR_OK;
   }
   c->last_batch.clear();
+  if (int rc = flush_super_boxes(c)) return rc;      // (before the fork: the workers search these views with the culled kernel)
   if (!c->ev_fork) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   MVR_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
   int status = MVR_OK;
@@ -2458,6 +2460,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_w")) c->cull_w = value;
   else if (!std::strcmp(key, "cull_slices")) c->cull_slices = value;
   else if (!std::strcmp(key, "seed_forward")) c->seed_forward = value != 0;
+  else if (!std::strcmp(key, "lazy_super")) { if (value < 0 || value > 1) return MVR_E_ARG; c->lazy_super = value; }
   else if (!std::strcmp(key, "fused_mark")) { if (value < 0 || value > 2) return MVR_E_ARG; c->fused_mark = value; }
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
   else if (!std::strcmp(key, "seq_search")) { if (value < 0 || value > 2) return MVR_E_ARG; c->seq_search = value; }

@@ -809,6 +809,7 @@ nn_cull_list_kernel(CullBatch batch, unsigned long long *__restrict__ evals)
 
 int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma)
 {
+  if (int rc = flush_super_boxes(c)) return rc;      // (the super boxes a posing launch left to whoever reads them)
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
     CullBatch batch;
     const int m = std::min(kBatchPairs, n_pairs - base);
@@ -836,6 +837,7 @@ int launch_nn_cull_list_batch(Ctx *c, const CullPair *pairs, int n_pairs, float 
 
 int launch_nn_cull_batch(Ctx *c, const CullPair *pairs, int n_pairs, float cap2, bool fma)
 {
+  if (int rc = flush_super_boxes(c)) return rc;      // (the super boxes a posing launch left to whoever reads them)
   for (int base = 0; base < n_pairs; base += kBatchPairs) {
     CullBatch batch;
     const int m = std::min(kBatchPairs, n_pairs - base);

@@ -697,11 +697,49 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
     if (tmax == 0) continue;
     ProfScope ps(c, MVR_K_GLUE, work);
     hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tmax + 3) / 4), (unsigned)m), dim3(256), 0, c->stream, rb);
-    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64 + 1), (unsigned)m), dim3(64), 0, c->stream, rb);     // (+1: a partial range may straddle one more super box)
+    // The super boxes are read by the culled kernel alone.  Posed copies that have just got their grid-ordered coordinates are
+    // about to be searched over their grids (every pass of a registration but the first): their super boxes wait until a
+    // culled launch asks for them (flush_super_boxes) -- a launch of 4 us per pass that nothing read.
+    bool lazy = c->lazy_super != 0;
+    for (int k = 0; k < m && lazy; ++k) lazy = rb.n[k] == 0 || (rb.from[k] != nullptr && rb.gout[k] != nullptr);
+    if (!lazy) hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64 + 1), (unsigned)m), dim3(64), 0, c->stream, rb);     // (+1: a partial range may straddle one more super box)
     MVR_HIP_TRY(c, hipGetLastError());
-    for (int k = 0; k < m; ++k) { clouds[base + k]->coords_valid = true; clouds[base + k]->fresh_tiles = 0; }
+    for (int k = 0; k < m; ++k) { clouds[base + k]->coords_valid = true; clouds[base + k]->fresh_tiles = 0; clouds[base + k]->super_stale = lazy && rb.n[k] != 0; }
   }
   return MVR_OK;
+}
+
+int flush_super_boxes(Ctx *c)
+{
+  // (the clouds belong to the context the caller made; a worker -- a group of pairs on its own stream -- finds them there.  The
+  // passes that fork flush on the caller's stream BEFORE the fork, so a worker normally finds nothing stale; if it does, it
+  // refreshes on its own stream and leaves the flag: the others then do the same -- identical bytes, no order needed)
+  Ctx *owner = c->parent ? c->parent : c;
+  const bool keep_flag = owner != c;
+  Cloud *stale[kBatchClouds];
+  int m = 0;
+  auto launch = [&]() -> int {
+    if (m == 0) return MVR_OK;
+    RefreshBatch rb;
+    size_t tmax = 0;
+    for (int k = 0; k < kBatchClouds; ++k) {
+      Cloud *cl = k < m ? stale[k] : nullptr;
+      rb.tlo[k] = cl ? cl->tlo : nullptr; rb.thi[k] = cl ? cl->thi : nullptr; rb.sbox[k] = cl ? cl->sbox : nullptr;
+      rb.n[k] = cl ? cl->n : 0; rb.tile_begin[k] = 0;
+      if (cl) { tmax = std::max(tmax, (cl->n + kCullTile - 1) / kCullTile); if (!keep_flag) cl->super_stale = false; }
+    }
+    hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64 + 1), (unsigned)m), dim3(64), 0, c->stream, rb);
+    MVR_HIP_TRY(c, hipGetLastError());
+    m = 0;
+    return MVR_OK;
+  };
+  for (Cloud &cl : owner->slots) {
+    if (!cl.super_stale) continue;
+    if (!cl.tlo || !cl.sbox || cl.n == 0 || !cl.coords_valid) { if (!keep_flag) cl.super_stale = false; continue; }      // (nothing to bring up to date: the next refresh writes them)
+    stale[m++] = &cl;
+    if (m == kBatchClouds) { if (int rc = launch()) return rc; }
+  }
+  return launch();
 }
 
 int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts, char *handled)

@@ -109,6 +109,7 @@ struct Cloud {
   float4 *tlo = nullptr, *thi = nullptr; size_t tiles_cap = 0;
   float4 *cbox = nullptr;              // [tiles][4 cells][lo, hi]: AABBs of the 64-point cells of every tile
   float4 *sbox = nullptr;              // [ceil(tiles / 64)][lo, hi]: AABBs of 64 consecutive tiles
+  bool super_stale = false;            // sbox[] was NOT refreshed with the tile boxes (a posed copy about to be searched over its grid): flush_super_boxes() before a culled launch
   bool coords_valid = false;           // sorted[] / tlo / thi / cbox match pts[]
   size_t fresh_tiles = 0;              // with !coords_valid: that many LEADING tiles of sorted[] / boxes are still current (a cloud that only grew at its end: mvr_cloud_append with an extended ordering); any other change of the coordinates resets it
   void stale_coords() { coords_valid = false; fresh_tiles = 0; gcoords_valid = false; }
@@ -281,6 +282,7 @@ struct Ctx {
   // of the chain (signal_armed, set by the pass loop for hosts that end a pass with the fused sums on this stream; signal_sent
   // tells the loop that it needs no write-value operation behind the chain)
   uint32_t *done_counter = nullptr; uint32_t signal_seq = 0; bool signal_armed = false, signal_sent = false;
+  int lazy_super = 1;                // 1 (default): posed copies that get grid-ordered coordinates leave their super boxes (read by the culled kernel alone) to flush_super_boxes(); 0: refreshed with every posing launch
   int setup_first = 1;               // plain passes: 1 (default) = the grid builds (side stream) and the pipe's set-up are enqueued BEFORE the pass's own chain instead of behind it: the first pass of a registration is host-bound either way, and the grids are then ready when the second pass wants them (12 x 200k: 2.8 + 2.1 ms -> 3.7 + 0.5)
   int pose_prep_launch = 0;          // test hook (tune key): 1 = the device pose records are always filled by the launch made for that, never by the posing launch on the way
   const double *pose_in_cur = nullptr; PoseRec *pose_tab_cur = nullptr; int pose_tab_n = 0; bool pose_tab_pending = false;
@@ -450,6 +452,7 @@ int launch_nn(Ctx *c, const float4 *q, size_t q_begin, size_t q_count, const uin
 
 // Morton order + tile AABBs of a cloud, (re)built or refreshed as needed
 int ensure_index(Ctx *c, Cloud &cl);
+int flush_super_boxes(Ctx *c);                         // the super boxes the posing launches left out (lazy_super), for every cloud of the context: called by the culled launchers
 void new_point_set(Ctx *c, Cloud &cl);                 // after upload / append / clear
 void inherit_point_set(Cloud &dst, const Cloud &src);  // after copy / transform
 // dst has just grown from old_n points by the points of `src` (appended at its end): keep dst's ordering and extend it by

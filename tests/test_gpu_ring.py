@@ -164,12 +164,13 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
     dict(grid_cell_points=1), dict(grid_cell_points=40, grid_light_rows=3), dict(fused_mark=0), dict(fused_mark=2), dict(grid_sets=0), dict(grid_tail=0), dict(grid_sets=2, grid_light_rows=1, grid_cluster=1), dict(grid_sets=2, grid_cell_points=1, grid_light_rows=2, grid_cluster=2), dict(fused_mark=0, grid_lanes=4, pair_groups=1),
     dict(grid_wide_waves=1), dict(pair_groups=3, cull_slices=8),
     dict(grid_probe=0), dict(grid_probe=0, grid_light_rows=2), dict(grid_probe=1, grid_light_rows=1, grid_cluster=1), dict(setup_first=0), dict(cull_w=4), dict(cull_w=2),
+    dict(lazy_super=0), dict(lazy_super=0, grid_sets=0), dict(lazy_super=1, grid_tail=0, cull_list=0),
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
     """Every routing knob of the grid search (lanes per query, cell size, what counts as a wide ball, where the wide ones
     go, set lists, marking) only moves queries between three exact searches: six passes of the 12 x 20k ring from the
     prior give the same poses and edge tables, bit for bit, as the default settings (so do the probe for wide balls, the order of
-    the set-up of a plain pass and the waves per query set of the culled kernel)."""
+    the set-up of a plain pass, the waves per query set of the culled kernel, and who refreshes the super boxes)."""
     V, N, max_d = 12, 20000, 4.0
     sp = mvr.synth_params(V, 3)
     scans = [mvr.synth_view(sp, v, N) for v in range(V)]
@@ -189,6 +190,41 @@ def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
                 log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
             runs.append(log)
     assert runs[0] == runs[1], knobs
+
+
+def test_a_culled_pass_after_grid_passes_finds_its_super_boxes(mvr):
+    """The posing launch of a pass on the grid kernels leaves the views' super boxes (read by the culled kernel alone) stale
+    (lazy_super); a pass that then takes the culled kernel -- ring_search switched off in mid-registration, a one-pair search
+    against a posed view -- must bring them up to date first: same bits as a context that never used the grid."""
+    V, N, max_d = 12, 15000, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for switch in (False, True):
+        with mvr.Context(0) as ctx:
+            ctx.tune(ring_search=1 if switch else 0)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, log = [p.copy() for p in poses0], []
+            for k in range(7):
+                if switch and k in (4, 6):
+                    ctx.tune(ring_search=0)          # this pass: culled kernel, over boxes the grid passes did not keep up
+                elif switch:
+                    ctx.tune(ring_search=1)
+                poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin)
+                log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+            if switch:
+                ctx.tune(ring_search=1)
+            poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, max_d, origin)      # (a grid pass last when switching)
+            log.append((np.asarray(poses).tobytes(), info["rows"].tobytes()))
+            # a one-pair culled search against a posed view right after a grid pass
+            q, m, d = ctx.correspondences(3, 4, max_d)        # (posed slots 3 and 4: mvr_correspondences runs the culled kernel)
+            runs.append((log, q.tobytes(), m.tobytes(), d.tobytes()))
+    assert runs[0] == runs[1]
 
 
 @pytest.mark.parametrize("case", ["fma", "sheared_pose", "slightly_sheared_pose", "sub_ranges"])
