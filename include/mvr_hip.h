@@ -450,7 +450,9 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * behind a hipStreamWaitValue32 gate the host opens after its solve, the poses reaching the kernels through a device table,
  * once a pass has run without allocating or waiting; 0: every pass is enqueued after the previous solve; also MVR_PIPELINE);
  * "grid_probe" (1, default: a query of the grid walk whose ball is wide first looks into the 2 x 2 x 2 cells nearest to it -- a
- * point found there is a tighter, valid bound; what a pass after a large motion needs; 0: off);
+ * point found there is a tighter, valid bound; what a pass after a large motion needs; 0: off), "grid_probe_rows" (the probe is
+ * made for balls of more than this many rows of cells, at most "grid_light_rows"; a probed query whose new ball lies inside the
+ * probed cells is answered by the probe alone);
  * "lazy_super" (1, default: a posing launch that also writes a view's grid-ordered coordinates leaves its super boxes -- read by
  * the culled kernel alone -- to the first culled launch that follows, if any; 0: refreshed by every posing launch);
  * the aligns of the sequential mode: "seq_search" (mvr_icp_align of a posed scan against a model made of posed scans: 1, default:

@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     };
     int nrows = (y1 - y0 + 1) * (z1 - z0 + 1);
     bool wide = worth && nrows > batch.light_rows;
-    if (G == 1 && wide && batch.probe) {
+    if (G == 1 && worth && batch.probe && nrows > batch.probe_rows) {
       // A wide ball is a LOOSE bound more often than a far neighbour: the seed of a pass after a large motion (the first passes
       // of a registration, a restart) is the old match, a millimetre or two off, while the nearest point is where it always
       // is -- in the cell next to the query.  So before the query leaves for the slow lanes: the 2 x 2 x 2 cells nearest to it
@@ -332,6 +332,18 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
         z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]); z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
         nrows = (y1 - y0 + 1) * (z1 - z0 + 1);
         wide = nrows > batch.light_rows;       // (still wide: it goes where it would have gone without the probe)
+        // The ball of the new bound inside the cells the probe has just looked at: every point within the bound HAS been
+        // looked at, the candidate is the answer (ties and all: the same comparison chose it) -- no second walk.  A ball of
+        // half a cell edge or less always is, which is what the nearest point of a query in the overlap leaves.
+        // (the probed box is worked out AGAIN from the centre rather than kept across the probe's walk: six registers less
+        // where the kernel has two to spare below its eighth wave per SIMD)
+        float ox = rx, oy = ry, oz = rz;
+        asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
+        const int ocx = cell_of(ox, a.lo[0], a.inv_h, a.dim[0]), ocy = cell_of(oy, a.lo[1], a.inv_h, a.dim[1]), ocz = cell_of(oz, a.lo[2], a.inv_h, a.dim[2]);
+        const int qx0 = max(ocx - ((ox - a.lo[0]) * a.inv_h - (float)ocx < 0.5f ? 1 : 0), 0), qx1 = min(qx0 + 1, a.dim[0] - 1);
+        const int qy0 = max(ocy - ((oy - a.lo[1]) * a.inv_h - (float)ocy < 0.5f ? 1 : 0), 0), qy1 = min(qy0 + 1, a.dim[1] - 1);
+        const int qz0 = max(ocz - ((oz - a.lo[2]) * a.inv_h - (float)ocz < 0.5f ? 1 : 0), 0), qz1 = min(qz0 + 1, a.dim[2] - 1);
+        if (x0 >= qx0 && x1 <= qx1 && y0 >= qy0 && y1 <= qy1 && z0 >= qz0 && z1 <= qz1) worth = false;
       }
     }
     // wide balls are not walked here: without a bound they come in clusters (the rim of the overlap) and go to the culled
@@ -761,6 +773,7 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     batch.light_rows = c->grid_light_rows;
     batch.cluster = c->grid_cluster;
     batch.probe = c->grid_probe;
+    batch.probe_rows = std::min(c->grid_probe_rows, c->grid_light_rows);
     if (total == 0) continue;
     map.n_pairs = (uint32_t)m;
     unsigned grid_blocks = 0;

@@ -163,6 +163,7 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
     dict(cull_list=0), dict(cull_list_w=1), dict(cull_list_w=4, grid_cluster=1), dict(grid_cluster=65),
     dict(grid_cell_points=1), dict(grid_cell_points=40, grid_light_rows=3), dict(fused_mark=0), dict(fused_mark=2), dict(grid_sets=0), dict(grid_tail=0), dict(grid_sets=2, grid_light_rows=1, grid_cluster=1), dict(grid_sets=2, grid_cell_points=1, grid_light_rows=2, grid_cluster=2), dict(fused_mark=0, grid_lanes=4, pair_groups=1),
     dict(grid_wide_waves=1), dict(pair_groups=3, cull_slices=8),
+    dict(grid_probe_rows=1), dict(grid_probe_rows=4, grid_cell_points=1), dict(grid_probe_rows=3, grid_light_rows=64, grid_cell_points=40),
     dict(grid_probe=0), dict(grid_probe=0, grid_light_rows=2), dict(grid_probe=1, grid_light_rows=1, grid_cluster=1), dict(setup_first=0), dict(cull_w=4), dict(cull_w=2),
     dict(lazy_super=0), dict(lazy_super=0, grid_sets=0), dict(lazy_super=1, grid_tail=0, cull_list=0),
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))

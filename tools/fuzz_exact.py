@@ -35,7 +35,7 @@ while time.time() < t_end:
     origin = np.array(sp.pivot)
     edges = [(i, (i + 1) % V) for i in range(V)]
     runs = []
-    for knobs in ({}, dict(ring_search=0), dict(pipeline=0, grid_probe=0), dict(grid_light_rows=3, grid_cluster=2, cull_w=4)):
+    for knobs in ({}, dict(ring_search=0), dict(pipeline=0, grid_probe=0), dict(grid_light_rows=3, grid_cluster=2, cull_w=4), dict(grid_probe_rows=1), dict(grid_probe_rows=2, grid_light_rows=40)):
         with mvr.Context(0) as ctx:
             ctx.tune(**knobs)
             for v in range(V):
