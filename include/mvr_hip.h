@@ -459,7 +459,9 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * the reverse searches walk the source scan's cell grid; 2: the forward search goes through the merged scans' grids as well; 0:
  * the culled kernel both ways), "seq_seed" (1, default: an align's forward searches start from the distance, now, of the point
  * each query matched when the same scan was last aligned on this context -- the sweeps of registrationICP, the rounds of
- * AutoReg; 0: off, and what the aligns so far have left is forgotten);
+ * AutoReg; 0: off, and what the aligns so far have left is forgotten), "align_spin" (1, default: the last sums launch of a
+ * point-to-point iteration stores the iteration's row into mapped pinned memory itself and the host spins on a sequence word;
+ * 0: a copy behind the launch and hipStreamSynchronize);
  * multi-GPU: "wait_timeout_ms" (how long a rank waits for a pass that contains a collective before it aborts its
  * communicator), and the test hooks "inject_fail_pass" / "inject_stall_pass" (the k-th sharded pass or iteration from now:
  * this rank's local work fails / its stream stalls in front of the collective as if a peer never arrived; -1: off).

@@ -285,6 +285,45 @@ double now_ms()
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// the align's variant: the last sums launch has stored the row and then the word `seq` into mapped pinned memory itself
+// (launch_pass2's host_out); the host spins on the word, looks at the stream every few thousand rounds so that a failed
+// launch ends the wait, and gives up after wait_timeout_ms.  The row lands in h_moments, where read_moments leaves it.
+int ensure_align_row(Ctx *c)
+{
+  if (c->h_align) return MVR_OK;
+  if (hipHostMalloc(reinterpret_cast<void **>(&c->h_align), 66 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError(); c->h_align = nullptr; return MVR_E_HIP;
+  }
+  std::memset(c->h_align, 0, 66 * sizeof(double));
+  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_align), c->h_align, 0) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipHostFree(c->h_align); c->h_align = nullptr; c->d_align = nullptr; return MVR_E_HIP;
+  }
+  return MVR_OK;
+}
+
+int spin_moments(Ctx *c, uint32_t seq, size_t n_doubles)
+{
+  const uint32_t *word = reinterpret_cast<const uint32_t *>(c->h_align + 64);
+  const double t0 = now_ms();
+  for (unsigned n = 1;; ++n) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+    __builtin_ia32_pause();
+    if ((n & 0xFFFu) == 0u) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return set_error(c, MVR_E_HIP, "an iteration of mvr_icp_align failed on the device", e);
+      if (e == hipSuccess && __atomic_load_n(word, __ATOMIC_ACQUIRE) != seq) {
+        // the stream has drained and the word has not come: whatever kept the launch from running is the stream's to report
+        MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) break;
+        return set_error(c, MVR_E_HIP, "mvr_icp_align: the sums launch left no row");
+      }
+      if (now_ms() - t0 > (double)c->wait_timeout_ms) return set_error(c, MVR_E_HIP, "an iteration of mvr_icp_align did not finish in time");
+    }
+  }
+  std::memcpy(c->h_moments, c->h_align, n_doubles * sizeof(double));
+  return MVR_OK;
+}
+
 }  // namespace
 }  // namespace mvr
 
@@ -342,6 +381,7 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_PARTS_MAX_ROWS")) c->parts_max_rows = std::max(1, std::atoi(m));
   if (const char *m = std::getenv("MVR_GRID_DEBUG")) c->grid_debug = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_SEQ_SEED")) c->seq_seed = std::atoi(m) != 0;
+  if (const char *m = std::getenv("MVR_ALIGN_SPIN")) c->align_spin = std::atoi(m) != 0;      // 0: an align's iteration row by copy + synchronise
   if (const char *m = std::getenv("MVR_SEQ_SEARCH")) c->seq_search = std::max(0, std::min(2, std::atoi(m)));    // align against a target made of posed scans: 1 = through the scans' grids, 0 = culled kernel
   if (const char *m = std::getenv("MVR_RING_SEARCH")) c->ring_search = std::atoi(m);   // fused pass: 1 = grid search for bounded queries, 0 = culled kernel only
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
@@ -417,6 +457,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   if (c->gate) { if (c->gate_is_signal) (void)hipFree(c->gate); else (void)hipHostFree(c->gate); }
   if (c->h_done) (void)hipHostFree(c->h_done);
   if (c->h_moments) (void)hipHostFree(c->h_moments);
+  if (c->h_align) (void)hipHostFree(c->h_align);
   if (c->h_table) (void)hipHostFree(c->h_table);
   if (c->h_counts) (void)hipHostFree(c->h_counts);
   if (c->h_evals) (void)hipHostFree(c->h_evals);
@@ -2135,6 +2176,8 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
   const bool parts_ok = ns > 0 && tgt.n > 0 && ts != ss && prepare_parts_search(c, c->slots[ss], *curp, tgt, p->max_corr_dist);
   const bool rev_grid_ok = parts_ok || (ns > 0 && tgt.n > 0 && ts != ss && p->use_reciprocal && tgt.n <= 0xFFFFFFF0ull &&
                                         prepare_source_grid(c, c->slots[ss], *curp, p->max_corr_dist));
+  // (point-to-point: the iteration's row comes to the host from the last sums launch itself, no copy, no synchronise)
+  const bool spin = c->align_spin && !p->point_to_plane && ensure_align_row(c) == MVR_OK;
   do {
     double ev = 0.0;
     SearchPlan plan;
@@ -2145,12 +2188,14 @@ API int mvr_icp_align(mvr_ctx *ctx, int ss, int ts, int os, const mvr_icp_params
                               p->max_corr_dist * p->max_corr_dist, p->use_reciprocal != 0 && tgt.n > 0, c->match,
                               c->moments)) return rc;
     if (p->point_to_plane) { if (int rc = launch_p2plane(c, curp->pts, tgt.pts, tgt.nrm, c->match, plan.qperm, 0, ns, c->moments + 32)) return rc; }
-    else if (int rc = launch_pass2(c, curp->pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments, (st && c->nn_mode != 0) ? c->evals + kEvalRegion : nullptr)) return rc;
+    else if (int rc = launch_pass2(c, curp->pts, tgt.pts, c->match, plan.qperm, 0, ns, c->moments, (st && c->nn_mode != 0) ? c->evals + kEvalRegion : nullptr,
+                               spin ? c->d_align : nullptr, spin ? ++c->align_seq : 0u)) return rc;
     // the search kernels' running evaluation totals ride along with the moments (the statistic needs neither a wait nor a copy
     // of its own: the last sums launch adds the counters up into moments[18]; point-to-plane keeps the copy)
     if (st && c->nn_mode != 0 && p->point_to_plane)
       MVR_HIP_TRY(c, hipMemcpyAsync(c->h_evals, c->evals + kEvalRegion, kEvalRegion * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    if (int rc = read_moments(c, p->point_to_plane ? 64 : 19)) return rc;
+    if (spin) { if (int rc = spin_moments(c, c->align_seq, 19)) return rc; }
+    else if (int rc = read_moments(c, p->point_to_plane ? 64 : 19)) return rc;
     const double *h = c->h_moments;
     if (st && c->nn_mode != 0 && !p->point_to_plane) evals_total = h[18];
     fwdq += (double)ns;
@@ -2475,6 +2520,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "parts_lanes")) { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->parts_lanes = value; }
   else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
+  else if (!std::strcmp(key, "align_spin")) c->align_spin = value != 0;
   else if (!std::strcmp(key, "grid_probe")) c->grid_probe = value != 0;
   else if (!std::strcmp(key, "grid_probe_rows")) { if (value < 1) return MVR_E_ARG; c->grid_probe_rows = value; }
   else if (!std::strcmp(key, "setup_first")) c->setup_first = value != 0;

@@ -210,6 +210,11 @@ struct Ctx {
   double *partials = nullptr; size_t partials_cap = 0;
   double *moments = nullptr;                          // device: 64 doubles
   double *h_moments = nullptr;                        // pinned host: 64 doubles
+  // mvr_icp_align's one round trip per iteration: the last sums launch stores the iteration's 19 doubles into mapped pinned
+  // memory itself and then a sequence word the host spins on (align_spin; a copy packet + hipStreamSynchronize cost ~25 us)
+  double *h_align = nullptr, *d_align = nullptr;      // pinned host, 64 doubles + the word (at double 64), and the device's view of it
+  uint32_t align_seq = 0;
+  int align_spin = 1;
   // index-build scratch
   uint32_t *codes_a = nullptr, *codes_b = nullptr, *idx_a = nullptr; size_t sort_cap = 0;
   void *cub_tmp = nullptr; size_t cub_cap = 0;
@@ -656,7 +661,8 @@ int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *ke
                  int32_t *match, double *moments);
 // pass 2: sigma = (1/n) sum (q-mean_q)(p-mean_p)^T into moments[8..16]
 int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
-                 size_t q_begin, size_t q_count, double *moments, const unsigned long long *eval_totals = nullptr);
+                 size_t q_begin, size_t q_count, double *moments, const unsigned long long *eval_totals = nullptr,
+                 double *host_out = nullptr, uint32_t host_seq = 0);      // host_out: mapped pinned memory that receives moments[0..18] and, at double 64, the word host_seq
 // raw second moments about `origin` into out[0..31] (device pointer)
 int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *keys, const nnkey_t *rkeys,
                            const uint32_t *slot, const uint32_t *qperm, const uint32_t *tinv, size_t q_begin, size_t q_count,

@@ -335,20 +335,34 @@ pass2_kernel(const float4 *__restrict__ src, const float4 *__restrict__ tgt, con
 // (eval_totals, optional: the search kernels' running evaluation counters -- kEvalShards of them, kEvalStride apart; their sum
 // goes to moments[18] so that the statistic travels with the moments' copy instead of one of its own)
 __global__ void __launch_bounds__(kRT) pass2_final_kernel(const double *__restrict__ partials, int rows,
-                                                           double *__restrict__ moments, const unsigned long long *__restrict__ eval_totals)
+                                                           double *__restrict__ moments, const unsigned long long *__restrict__ eval_totals,
+                                                           double *__restrict__ host_out, uint32_t host_seq)
 {
   __shared__ double lds[9];
   double s[9];
   sum_rows<9>(partials, rows, s, lds);
+  double ev = 0.0;
   if (eval_totals && threadIdx.x < 64) {
     unsigned long long v = threadIdx.x < kEvalShards ? eval_totals[(size_t)threadIdx.x * kEvalStride] : 0ull;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (threadIdx.x == 0) moments[18] = (double)v;
+    ev = (double)v;
+    if (threadIdx.x == 0) moments[18] = ev;
   }
   if (threadIdx.x == 0) {
     const double n = moments[0];
-    for (int k = 0; k < 9; ++k) moments[8 + k] = (n > 0) ? s[k] / n : 0.0;
+    double sig[9];
+    for (int k = 0; k < 9; ++k) { sig[k] = (n > 0) ? s[k] / n : 0.0; moments[8 + k] = sig[k]; }
+    if (host_out) {
+      // the iteration's whole row goes to the host from here: no copy packet behind this launch, no wake-up from a
+      // synchronise -- the host spins on the word (one block, one fence)
+      for (int k = 0; k < 8; ++k) host_out[k] = moments[k];
+      for (int k = 0; k < 9; ++k) host_out[8 + k] = sig[k];
+      host_out[17] = moments[17];
+      host_out[18] = eval_totals ? ev : moments[18];
+      __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<uint32_t *>(host_out + 64), host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -780,14 +794,14 @@ int launch_pass1(Ctx *c, const float4 *src, const float4 *tgt, const nnkey_t *ke
 }
 
 int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const uint32_t *qperm,
-                 size_t q_begin, size_t q_count, double *moments, const unsigned long long *eval_totals)
+                 size_t q_begin, size_t q_count, double *moments, const unsigned long long *eval_totals, double *host_out, uint32_t host_seq)
 {
   const int blocks = reduce_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
   hipLaunchKernelGGL(pass2_kernel, dim3(blocks), dim3(kRT), 0, c->stream, src, tgt, match, qperm, q_begin,
                      q_count, moments, c->partials);
-  hipLaunchKernelGGL(pass2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments, eval_totals);
+  hipLaunchKernelGGL(pass2_final_kernel, dim3(1), dim3(kRT), 0, c->stream, c->partials, blocks, moments, eval_totals, host_out, host_seq);
   MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }

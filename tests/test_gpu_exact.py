@@ -205,9 +205,10 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
     # ... the same without the seeds one align of a scan leaves for the next (seq_seed: the forward searches of a sweep start from
     # the matches of the sweep before) -- three sweeps, so that seeds left by seeded searches are used as well
     seeded = []
-    for seed, mode in ((1, 1), (0, 1), (1, 2), (1, 0)):      # (the seeds serve the culled kernel and the walk through the parts' grids alike)
+    # (last arm: the iteration's row fetched by a copy and a synchronise instead of stored to the host by the sums launch itself, align_spin 0)
+    for seed, mode, spin in ((1, 1, 1), (0, 1, 1), (1, 2, 1), (1, 0, 1), (1, 1, 0)):      # (the seeds serve the culled kernel and the walk through the parts' grids alike)
         with mvr.Context(0) as ctx:
-            ctx.tune(seq_seed=seed, seq_search=mode)
+            ctx.tune(seq_seed=seed, seq_search=mode, align_spin=spin)
             for v in range(V):
                 ctx.upload(16 + v, scans[v])
             poses, log, merged = _sequential(mvr, ctx, scans, poses0, params, 3, V)
