@@ -700,8 +700,9 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
     // The super boxes are read by the culled kernel alone.  Posed copies that have just got their grid-ordered coordinates are
     // about to be searched over their grids (every pass of a registration but the first): their super boxes wait until a
     // culled launch asks for them (flush_super_boxes) -- a launch of 4 us per pass that nothing read.
-    bool lazy = c->lazy_super != 0;
-    for (int k = 0; k < m && lazy; ++k) lazy = rb.n[k] == 0 || (rb.from[k] != nullptr && rb.gout[k] != nullptr);
+    // (Every refresh leaves them, not only those: a culled launch flushes ALL stale clouds of the context in one launch -- the
+    // source and the grown model of a sequential align were two super-box launches, one behind each refresh.)
+    const bool lazy = c->lazy_super != 0;
     if (!lazy) hipLaunchKernelGGL(super_box_kernel, dim3((unsigned)((tmax + 63) / 64 + 1), (unsigned)m), dim3(64), 0, c->stream, rb);     // (+1: a partial range may straddle one more super box)
     MVR_HIP_TRY(c, hipGetLastError());
     for (int k = 0; k < m; ++k) { clouds[base + k]->coords_valid = true; clouds[base + k]->fresh_tiles = 0; clouds[base + k]->super_stale = lazy && rb.n[k] != 0; }

@@ -674,7 +674,8 @@ inline int reduce_blocks(const Ctx *c, size_t n)
   const size_t want = (n + kRT - 1) / kRT;
   // few partial rows keep the single-block final sum short; 2 blocks per CU
   // already put > 8 MB of 16-byte loads in flight
-  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu);
+  size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu);
+  if (c->reduce_rows > 0) cap = std::min<size_t>(kMaxBlocks, (size_t)c->reduce_rows);      // (tuning: "reduce_rows")
   return (int)std::max<size_t>(1, std::min(want, cap));
 }
 

@@ -10,7 +10,7 @@ mvr = importlib.import_module("multi-view-registration_amd")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
-cases = fails = 0
+cases = fails = degenerate = 0
 while time.time() < t_end:
     V = int(rng.integers(3, 10)) if rng.random() < 0.9 else int(rng.integers(17, 21))      # (now and then more views than one posing launch takes)
     sizes = [int(rng.integers(300, 30000 if V < 17 else 6000)) for _ in range(V)]
@@ -59,6 +59,15 @@ while time.time() < t_end:
                 one.append(str(e))
     if isinstance(one[0], str) or isinstance(one[1], str):
         ok = one[0] == one[1] if isinstance(one[0], str) and isinstance(one[1], str) else False
+        if not ok:
+            # ONE route refused the system as singular: with an edge of fewer than three correspondences the edge's 6 x 6 is rank
+            # deficient and whether a pivot of the solve comes out as exactly zero hangs on the last bits of the sums, which the two
+            # kernels add in different orders (PCL itself produces non-finite or arbitrary poses there) -- degenerate, counted apart
+            rows = one[1] if isinstance(one[0], str) else one[0]
+            err = one[0] if isinstance(one[0], str) else one[1]
+            if "singular" in err and float(rows[:, 0].min()) < 3.0:
+                ok = True
+                degenerate += 1
     else:
         scale = np.maximum(np.abs(one[0]), 1.0)
         ok = np.array_equal(one[0][:, 0], one[1][:, 0]) and np.all(np.abs(one[0] - one[1]) <= 1e-9 * scale * np.maximum(one[0][:, :1], 1.0))
@@ -87,5 +96,5 @@ while time.time() < t_end:
         if not all(r == seq[0] for r in seq[1:]):
             fails += 1
             print("SEQ MISMATCH V=%d sizes=%s far=%g max_d=%g: %s" % (V, sizes, far, max_d, [r == seq[0] for r in seq]), flush=True)
-print("fuzz: %d cases, %d failures" % (cases, fails))
+print("fuzz: %d cases, %d failures, %d degenerate (an edge of fewer than three correspondences, refused as singular by one summation order only)" % (cases, fails, degenerate))
 sys.exit(1 if fails else 0)

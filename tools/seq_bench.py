@@ -76,6 +76,8 @@ def main():
     out = dict(config="%d-view ring, %d pts/scan, sequential pairwise ICP vs growing target, repeat %d" % (V, N, a.repeat),
                aligns=len(order) * a.repeat)
     with mvr.Context(0) as ctx:
+        for kv in os.environ.get("MVR_SEQ_KNOBS", "").split():             # e.g. MVR_SEQ_KNOBS="lazy_super=0 align_spin=0"
+            ctx.tune(**{kv.split("=")[0]: int(kv.split("=")[1])})
         for name, mode in (("culled", 1),) + ((("brute", 0),) if not a.no_brute else ()):
             ctx.tune(nn_mode=mode)
             gpu_sweep(mvr, ctx, scans, poses0, params, order, 1)                     # warm-up (allocations, sorts)
