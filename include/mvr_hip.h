@@ -461,9 +461,9 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * each query matched when the same scan was last aligned on this context -- the sweeps of registrationICP, the rounds of
  * AutoReg; 0: off, and what the aligns so far have left is forgotten), "align_spin" (1, default: the last sums launch of a
  * point-to-point iteration stores the iteration's row into mapped pinned memory itself and the host spins on a sequence word;
- * 0: a copy behind the launch and hipStreamSynchronize), "reduce_rows" (blocks, = partial rows, of a sums launch at most; 0,
- * default: one per compute unit -- the sums are added in an order that depends on it, so two runs compare bit for bit only at the
- * same value);
+ * 0: a copy behind the launch and hipStreamSynchronize), "reduce_rows" (blocks, = partial rows, per pair of the launches that carry the 29 raw sums;
+ * 0, default: a quarter of the compute units, at least 32 -- the sums are added in an order that depends on it, so two runs
+ * compare bit for bit only at the same value);
  * multi-GPU: "wait_timeout_ms" (how long a rank waits for a pass that contains a collective before it aborts its
  * communicator), and the test hooks "inject_fail_pass" / "inject_stall_pass" (the k-th sharded pass or iteration from now:
  * this rank's local work fails / its stream stalls in front of the collective as if a peer never arrived; -1: off).

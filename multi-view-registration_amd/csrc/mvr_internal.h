@@ -175,7 +175,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int n_cu = 0;
-  int reduce_rows = 0;                                // blocks (= partial rows) of a sums launch at most; 0: one per CU
+  int reduce_rows = 0;                                // blocks (= partial rows) per pair of the launches that carry 29 sums per lane; 0: a quarter of the CUs (at least 32)
   int clock_mhz = 0;
   std::string name;
   std::string last_error;

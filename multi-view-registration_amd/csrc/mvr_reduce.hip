@@ -674,9 +674,21 @@ inline int reduce_blocks(const Ctx *c, size_t n)
   const size_t want = (n + kRT - 1) / kRT;
   // few partial rows keep the single-block final sum short; 2 blocks per CU
   // already put > 8 MB of 16-byte loads in flight
-  size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu);
-  if (c->reduce_rows > 0) cap = std::min<size_t>(kMaxBlocks, (size_t)c->reduce_rows);      // (tuning: "reduce_rows")
+  const size_t cap = std::min<size_t>(kMaxBlocks, (size_t)c->n_cu);
   return (int)std::max<size_t>(1, std::min(want, cap));
+}
+
+// the launches that carry 29 f64 sums per lane (moments2 / accept_moments2, one pair or a batch): a block's epilogue -- 29
+// wave reductions, the hop through LDS, a partial row -- costs five times what a lane's three queries cost when a 200k-query
+// pair gets a block per CU; a quarter of the rows (12 queries per lane, one round of waves for a 12-pair batch instead of
+// three) measured 5-7 us less per ring pass.  One rule for the whole family: its one-pair and batched launches add up in
+// the same order.
+inline int moments_blocks(const Ctx *c, size_t n)
+{
+  const size_t want = (n + kRT - 1) / kRT;
+  size_t cap = std::max<size_t>(32, (size_t)c->n_cu / 4);
+  if (c->reduce_rows > 0) cap = (size_t)c->reduce_rows;      // (tuning: "reduce_rows")
+  return (int)std::max<size_t>(1, std::min(want, std::min<size_t>(kMaxBlocks, cap)));
 }
 
 inline int ensure_partials(Ctx *c, size_t doubles) { return ensure(c, c->partials, c->partials_cap, doubles); }
@@ -810,7 +822,7 @@ int launch_pass2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *ma
 int launch_moments2(Ctx *c, const float4 *src, const float4 *tgt, const int32_t *match, const nnkey_t *keys, const uint32_t *qperm,
                     size_t q_begin, size_t q_count, const double origin[3], double *out)
 {
-  const int blocks = reduce_blocks(c, q_count);
+  const int blocks = moments_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   Vec3d o{origin[0], origin[1], origin[2]};
   ProfScope ps(c, MVR_K_REDUCE, 20.0 * (double)q_count);
@@ -825,7 +837,7 @@ int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const n
                            const uint32_t *slot, const uint32_t *qperm, const uint32_t *tinv, size_t q_begin, size_t q_count,
                            double max2, bool reciprocal, const double origin[3], double *out)
 {
-  const int blocks = reduce_blocks(c, q_count);
+  const int blocks = moments_blocks(c, q_count);
   if (int rc = ensure_partials(c, (size_t)kMaxBlocks * 32)) return rc;
   Vec3d o{origin[0], origin[1], origin[2]};
   ProfScope ps(c, MVR_K_REDUCE, 40.0 * (double)q_count);
@@ -836,7 +848,7 @@ int launch_accept_moments2(Ctx *c, const float4 *src, const float4 *tgt, const n
   return MVR_OK;
 }
 
-int reduce_blocks_for(const Ctx *c, size_t n) { return reduce_blocks(c, n); }
+int reduce_blocks_for(const Ctx *c, size_t n) { return moments_blocks(c, n); }
 
 int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs)
 {
