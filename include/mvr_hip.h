@@ -461,7 +461,8 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * each query matched when the same scan was last aligned on this context -- the sweeps of registrationICP, the rounds of
  * AutoReg; 0: off, and what the aligns so far have left is forgotten), "align_spin" (1, default: the last sums launch of a
  * point-to-point iteration stores the iteration's row into mapped pinned memory itself and the host spins on a sequence word;
- * 0: a copy behind the launch and hipStreamSynchronize), "reduce_rows" (blocks, = partial rows, per pair of the launches that carry the 29 raw sums;
+ * 0: a copy behind the launch and hipStreamSynchronize), "seq_rider" (1, default: mvr_seq_run has the launch that poses the next
+ * source refresh the grown model's index tail on the way; 0: a launch of its own inside the align), "reduce_rows" (blocks, = partial rows, per pair of the launches that carry the 29 raw sums;
  * 0, default: a quarter of the compute units, at least 32 -- the sums are added in an order that depends on it, so two runs
  * compare bit for bit only at the same value);
  * multi-GPU: "wait_timeout_ms" (how long a rank waits for a pass that contains a collective before it aborts its

@@ -2439,7 +2439,11 @@ API int mvr_seq_run(mvr_ctx *ctx, int n_views, const int *raw_slots, int target_
     if (int rc = mvr_cloud_transform(ctx, target_slot, raw_slots[0], poses)) return rc;       // :562
     if (int rc = mvr_cloud_reserve(ctx, target_slot, total)) return rc;
     for (int v : order) {
-      if (int rc = mvr_cloud_transform(ctx, source_slot, raw_slots[v], poses + 16 * (size_t)v)) return rc;      // :565
+      // (the model grew by the previous align's output: the launch that poses this source refreshes the model's tail on the way)
+      c->refresh_rider = c->seq_rider ? &c->slots[target_slot] : nullptr;
+      const int rct = mvr_cloud_transform(ctx, source_slot, raw_slots[v], poses + 16 * (size_t)v);              // :565
+      c->refresh_rider = nullptr;
+      if (rct != MVR_OK) return rct;
       float T[16];
       mvr_icp_stats st;
       std::memset(&st, 0, sizeof st);
@@ -2521,6 +2525,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
   else if (!std::strcmp(key, "align_spin")) c->align_spin = value != 0;
+  else if (!std::strcmp(key, "seq_rider")) c->seq_rider = value != 0;
   else if (!std::strcmp(key, "reduce_rows")) { if (value < 0 || value > 1024) return MVR_E_ARG; c->reduce_rows = value; }
   else if (!std::strcmp(key, "grid_probe")) c->grid_probe = value != 0;
   else if (!std::strcmp(key, "grid_probe_rows")) { if (value < 1) return MVR_E_ARG; c->grid_probe_rows = value; }

@@ -762,6 +762,15 @@ int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src,
     Tps.push_back((c->pose_from_table && d->pose_dev) ? &d->pose_dev->T : nullptr);      // (an address in device memory: not read here)
     if (handled) handled[k] = 1;
   }
+  // a rider: a cloud whose index the caller knows to be needed right after these posed copies (the grown model of the sequential
+  // mode: its tail is refreshed by the launch that poses the next source, not by one of its own behind it)
+  if (!todo.empty() && c->refresh_rider && std::find(todo.begin(), todo.end(), c->refresh_rider) == todo.end()) {
+    Cloud *r = c->refresh_rider;
+    bool stale = false;
+    if (r->n && r->order && prepare_index(c, *r, &stale) == MVR_OK && stale) {
+      todo.push_back(r); from.push_back(nullptr); xsrc.push_back(nullptr); Ts.insert(Ts.end(), 16, 0.0); Tps.push_back(nullptr);
+    }
+  }
   return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size(), from.data(), Ts.data(), with_pts ? xsrc.data() : nullptr, Tps.data(),
                                              c->ring_search != 0 && c->pair_fused);
 }

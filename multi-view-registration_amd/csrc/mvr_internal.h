@@ -175,6 +175,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int n_cu = 0;
+  struct Cloud *refresh_rider = nullptr;              // refresh_posed_batch: a cloud whose stale index is refreshed by the same launch (set around a call, never kept)
   int reduce_rows = 0;                                // blocks (= partial rows) per pair of the launches that carry 29 sums per lane; 0: a quarter of the CUs (at least 32)
   int clock_mhz = 0;
   std::string name;
@@ -216,6 +217,7 @@ struct Ctx {
   double *h_align = nullptr, *d_align = nullptr;      // pinned host, 64 doubles + the word (at double 64), and the device's view of it
   uint32_t align_seq = 0;
   int align_spin = 1;
+  int seq_rider = 1;                                  // mvr_seq_run: the model's tail is refreshed by the launch that poses the next source
   // index-build scratch
   uint32_t *codes_a = nullptr, *codes_b = nullptr, *idx_a = nullptr; size_t sort_cap = 0;
   void *cub_tmp = nullptr; size_t cub_cap = 0;

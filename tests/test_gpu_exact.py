@@ -208,7 +208,7 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
     # (last arm: the iteration's row fetched by a copy and a synchronise instead of stored to the host by the sums launch itself, align_spin 0)
     for seed, mode, spin in ((1, 1, 1), (0, 1, 1), (1, 2, 1), (1, 0, 1), (1, 1, 0)):      # (the seeds serve the culled kernel and the walk through the parts' grids alike)
         with mvr.Context(0) as ctx:
-            ctx.tune(seq_seed=seed, seq_search=mode, align_spin=spin)
+            ctx.tune(seq_seed=seed, seq_search=mode, align_spin=spin, lazy_super=spin)
             for v in range(V):
                 ctx.upload(16 + v, scans[v])
             poses, log, merged = _sequential(mvr, ctx, scans, poses0, params, 3, V)
@@ -216,13 +216,16 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
     for r in seeded[1:]:
         assert seeded[0][1] == r[1], case
         assert seeded[0][0] == r[0] and seeded[0][2] == r[2], case
-    # ... and the native driver of the same loop (mvr_seq_run: one call for the three sweeps)
-    with mvr.Context(0) as ctx:
-        for v in range(V):
-            ctx.upload(16 + v, scans[v])
-        nposes, nlog = ctx.seq_run([16 + v for v in range(V)], 0, 1, 2, params, poses0, repeat=3)
-        nmerged = ctx.download(0)
-    assert np.asarray(nposes).tobytes() == seeded[0][0] and nmerged.tobytes() == seeded[0][2], case
+    # ... and the native driver of the same loop (mvr_seq_run: one call for the three sweeps), with and without the model's tail
+    # refreshed by the launch that poses the next source (seq_rider)
+    for rider in (0, 1):
+        with mvr.Context(0) as ctx:
+            ctx.tune(seq_rider=rider)
+            for v in range(V):
+                ctx.upload(16 + v, scans[v])
+            nposes, nlog = ctx.seq_run([16 + v for v in range(V)], 0, 1, 2, params, poses0, repeat=3)
+            nmerged = ctx.download(0)
+        assert np.asarray(nposes).tobytes() == seeded[0][0] and nmerged.tobytes() == seeded[0][2], (case, rider)
     assert [(e["view"], e["n_corr"], e["iterations"], e["state"], e["mse"], np.asarray(e["T"], np.float32).tobytes()) for e in nlog] == \
            [(l[0], l[1], l[2], l[3], l[4], l[5]) for l in seeded[0][1]], case
     # ... and against the oracle: the first align's correspondences, one by one
