@@ -421,7 +421,10 @@ __device__ __forceinline__ void accept_moments2_body(const float4 *__restrict__ 
   // the two points), so a thread walks kUn of its queries at once: each stage issues its loads for all of them
   // before the next stage waits.  The sums are still added in the order k, k + stride, ... (same bits as a
   // one-at-a-time walk).
-  constexpr int kUn = 3;        // measured: 2 and 3 equal (68 us for the 12 pairs of the ring step), 4: 78 us, 6: 93 us (registers cost residency)
+#ifndef MVR_ACCEPT_UN
+#define MVR_ACCEPT_UN 3
+#endif
+  constexpr int kUn = MVR_ACCEPT_UN;        // measured: 2 and 3 equal (68 us for the 12 pairs of the ring step), 4: 78 us, 6: 93 us (registers cost residency)
   for (size_t k0 = (size_t)block * blockDim.x + threadIdx.x; k0 < q_count; k0 += kUn * stride) {
     size_t i[kUn];                 // key slot (BYPOS: sorted position), then the query's original index
     nnkey_t key[kUn];
