@@ -436,7 +436,8 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * match, every reverse search -- walks a pose-invariant uniform grid over the target, one thread per query; 0: the
  * culled kernel answers everything; also MVR_RING_SEARCH), with its knobs "grid_cell_points" (points per occupied
  * cell the cell edge aims at, default 4; applies to grids built afterwards), "grid_light_rows" (rows of cells a thread
- * walks itself, default 12; wider balls leave the thread-per-query walk), "grid_wide" (1, default: a wide BOUNDED query
+ * walks itself, default 24; wider balls leave the thread-per-query walk; "grid_light_rows_lone", default 12: the same in a
+ * launch of one pair), "grid_wide" (1, default: a wide BOUNDED query
  * gets a wave of its own; 0: flagged for the culled kernel), "grid_cluster" (a wave of the walk with at least this many
  * wide queries hands them all to the culled kernel, default 8; 65: never), "grid_sets" (1, default: the 64-query
  * sets that hold a flagged query are answered a block per set over the grid while a set's union of balls is a few hundred
@@ -451,7 +452,7 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * once a pass has run without allocating or waiting; 0: every pass is enqueued after the previous solve; also MVR_PIPELINE);
  * "grid_probe" (1, default: a query of the grid walk whose ball is wide first looks into the 2 x 2 x 2 cells nearest to it -- a
  * point found there is a tighter, valid bound; what a pass after a large motion needs; 0: off), "grid_probe_rows" (the probe is
- * made for balls of more than this many rows of cells, at most "grid_light_rows"; a probed query whose new ball lies inside the
+ * made for balls of more than this many rows of cells, default 12, at most "grid_light_rows"; a probed query whose new ball lies inside the
  * probed cells is answered by the probe alone);
  * "lazy_super" (1, default: a posing launch that also writes a view's grid-ordered coordinates leaves its super boxes -- read by
  * the culled kernel alone -- to the first culled launch that follows, if any; 0: refreshed by every posing launch);

@@ -1003,7 +1003,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -2524,6 +2524,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "parts_lanes")) { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->parts_lanes = value; }
   else if (!std::strcmp(key, "parts_max_rows")) { if (value < 1) return MVR_E_ARG; c->parts_max_rows = value; }
   else if (!std::strcmp(key, "grid_light_rows")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows = value; }
+  else if (!std::strcmp(key, "grid_light_rows_lone")) { if (value < 1) return MVR_E_ARG; c->grid_light_rows_lone = value; }
   else if (!std::strcmp(key, "align_spin")) c->align_spin = value != 0;
   else if (!std::strcmp(key, "seq_rider")) c->seq_rider = value != 0;
   else if (!std::strcmp(key, "reduce_rows")) { if (value < 0 || value > 1024) return MVR_E_ARG; c->reduce_rows = value; }

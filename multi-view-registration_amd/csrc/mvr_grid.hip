@@ -770,10 +770,12 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
       total += map.sets[k];
     }
     batch.cap2 = cap2;
-    batch.light_rows = c->grid_light_rows;
+    // (a lone pair's launch -- the reverse search of a sequential align, a few thousand waves -- leaves the chip room for the
+    // wave-per-query launch behind it: its wide balls go there earlier than those of a fused pass's launch, which fills the chip)
+    batch.light_rows = n_pairs == 1 ? std::min(c->grid_light_rows, c->grid_light_rows_lone) : c->grid_light_rows;
     batch.cluster = c->grid_cluster;
     batch.probe = c->grid_probe;
-    batch.probe_rows = std::min(c->grid_probe_rows, c->grid_light_rows);
+    batch.probe_rows = std::min(c->grid_probe_rows, batch.light_rows);
     if (total == 0) continue;
     map.n_pairs = (uint32_t)m;
     unsigned grid_blocks = 0;

@@ -186,7 +186,8 @@ struct Ctx {
   std::map<uint64_t, std::weak_ptr<CellGrid> > grids;     // set_id -> uniform grid (shared between posed copies)
   int grid_probe = 1;                                 // grid search: a query whose ball is wide first looks into the 2 x 2 x 2 cells nearest to it -- a point found there is a tighter (valid) bound, and most wide balls of a pass after a large motion are loose bounds, not far neighbours (0: off)
   int grid_probe_rows = 12;                           // ... the probe is made for balls of more than this many rows of cells (<= grid_light_rows; the 2 x 2 x 2 cells are four rows)
-  int grid_light_rows = 12;                           // grid search (default = kGridLightRows): rows of cells a thread walks itself; wider balls leave for a wave of their own or for the culled kernel
+  int grid_light_rows_lone = 12;                      // ... in a launch of ONE pair (measured on the sequential mode's reverse searches: 24 costs an align 8 us)
+  int grid_light_rows = 24;                           // grid search (default = kGridLightRows): rows of cells a thread walks itself; wider balls leave for a wave of their own or for the culled kernel
   // mvr_icp_align of a posed scan remembers, per point set, where each query's match sat in the target (sorted position) and
   // starts the NEXT align of that scan from the distance of that point under the current coordinates: the sweeps of the sequential
   // mode (registrator.cpp:530-577, repeat_times of them) and the rounds of AutoReg align the same scans again and again against a
@@ -550,7 +551,7 @@ struct GridPair {
 constexpr int kGridBatchPairs = 12;
 constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
 constexpr int kGridDtMax = 12;        // most dilation steps of the distance map (a grid is built with as many as the first search radius it serves needs)
-constexpr int kGridLightRows = 12;    // default number of rows of cells (x-runs) a thread walks by itself (measured on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
+constexpr int kGridLightRows = 24;    // default number of rows of cells (x-runs) a thread walks by itself (with the probe at its own threshold of 12 rows: 24 takes 0.19 ms off the first four passes of a window that restarts from the prior, settled passes equal; 32 and 48 within 2 % of it; before the probe had a threshold of its own, on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
 struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; int probe = 0; int probe_rows = 1 << 30; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
