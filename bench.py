@@ -351,11 +351,15 @@ def main():
         ctx.prof_enable(False)
         iso = dict(nn=ctx.prof_get(mvr.K_NN), rd=ctx.prof_get(mvr.K_REDUCE), gl=ctx.prof_get(mvr.K_GLUE),
                    grid=ctx.prof_get(mvr.K_NN_GRID), wide=ctx.prof_get(mvr.K_NN_WIDE), xf=ctx.prof_get(mvr.K_XFORM),
-                   ms_per_step=1e3 * iso_elapsed / args.steps)
+                   ms_per_step=1e3 * iso_elapsed / args.steps,
+                   n_corr=reg.last["n_corr"])       # the accepted correspondences of the profiled steps' last pass (NOT of the brute-force pass below)
         rd_launches, rd_ms, rd_bytes = iso["rd"]
         kern_ms = sum(iso[f][1] for f in ("nn", "rd", "gl", "grid", "wide", "xf")) / args.steps
         out["step_breakdown_ms"]["kernels_sum"] = kern_ms
         out["step_breakdown_ms"]["gpu_idle_ms"] = max(0.0, 1e3 * elapsed / args.steps - kern_ms)
+        # (the same difference inside the profiled one-stream re-run: wall time and kernel sum of the SAME steps; the figure above
+        # sets the headline window's wall time against the re-run's kernels)
+        out["step_breakdown_ms"]["gpu_idle_ms_profiled_run"] = max(0.0, iso["ms_per_step"] - kern_ms)
     # the brute-force kernel (the plain VALU-roofline kernel) on the same pairs: one extra, untimed ring pass
     bf = None
     if world == 1 and not args.no_bruteforce_pass:
@@ -385,7 +389,7 @@ def main():
         # 12 Ns + 12 Nt + 8 Ns; reverse search K3 = 12 Nt' + 12 Ns + 4 Nt' + 4 Ns with Nt' = the matched targets (taken as the
         # accepted correspondences: a lower bound).  One launch = all V pairs of a step in one direction; mean of the two.
         Ns = Nt = float(N)
-        Ntp = reg.last["n_corr"] / float(V)
+        Ntp = iso["n_corr"] / float(V)
         fwd_bytes, rev_bytes = V * (12 * Ns + 12 * Nt + 8 * Ns), V * (12 * Ntp + 12 * Ns + 4 * Ntp + 4 * Ns)
         launches_per_step = gl_ / float(args.steps)          # 2 while one fused launch holds all pairs (V <= 12), more beyond
         alg_bytes = (fwd_bytes + rev_bytes) / launches_per_step
@@ -505,6 +509,8 @@ def main():
                          "registrationICP runs them, target grows to %d points in each)" % (V, N, sweeps, len(seq_order), V * N),
                "ms_per_align": 1e3 * seq_dt / (sweeps * len(seq_order)), "queries_per_s": N * sweeps * len(seq_order) / seq_dt,
                "ms_per_align_by_sweep": [1e3 * t / len(seq_order) for t in seq_dts],
+               "ms_per_align_first_sweep": 1e3 * seq_dts[0] / len(seq_order),      # unseeded: the figure that is like for like with cpu_oracle_ms_per_align (one unseeded sweep)
+               "ms_per_align_is": "the mean over %d sweeps, %d of them seeded by the sweep before" % (sweeps, sweeps - 1),
                "note": "one native call per sweep (mvr_seq_run); sweep 1 searches unseeded, from sweep 2 on every forward search starts from the "
                        "scan's match of the sweep before (seq_seed); n_corr and the oracle comparison are sweep 1's",
                "n_corr": seq_ncorr}

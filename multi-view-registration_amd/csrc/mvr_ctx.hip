@@ -442,6 +442,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
                   c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  if (c->stage_stat) (void)hipFree(c->stage_stat);
   if (c->d_parts) (void)hipFree(c->d_parts);
   if (c->h_parts) (void)hipHostFree(c->h_parts);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
@@ -790,7 +791,9 @@ API int mvr_cloud_transform_batch(mvr_ctx *ctx, int count, const int *dst, const
     if (!in[k]) continue;
     c->slots[dst[k]].n = n[k];
     const bool src_canon = c->slots[src[k]].canonical;
-    if (dst[k] != src[k]) inherit_point_set(c->slots[dst[k]], c->slots[src[k]]);
+    // (the destination takes the source's segment table with the point set, as the one-cloud path does: a slot that WAS a shard
+    // must not keep its stale table -- mvr_cloud_append, provenance() and seg_table() all read it)
+    if (dst[k] != src[k]) { inherit_point_set(c->slots[dst[k]], c->slots[src[k]]); c->slots[dst[k]].segs = c->slots[src[k]].segs; }
     else c->slots[dst[k]].forget_pose();
     c->slots[dst[k]].stale_coords();
     if (c->pose_from_table && c->slots[dst[k]].pose_dev && dst[k] != src[k]) {
@@ -1003,7 +1006,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_stage = c->grid_stage; w->grid_stage_lone = c->grid_stage_lone; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -1546,6 +1549,11 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
   auto pass_done = [&]() { const double t = now_ms(); c->pass_ms.push_back(t - t_prev); t_prev = t; };
   auto pipe_possible = [&]() {
     if (!c->pipeline || c->nn_mode == 0 || !c->pair_fused || c->grid_debug || V < 2) return false;
+    // A pass that contains a collective over MORE THAN ONE rank is never queued behind the gate: RCCL's enqueue may synchronise
+    // with the stream, and a stream parked behind a gate only this host thread can open would then hold the rank inside
+    // ncclAllReduce, outside every bounded wait.  A communicator of one rank has no peer to wait for and stays
+    // pipelined; `pipeline_multi_rank` = 1 lifts the rule (to be set only once a recorded two-GPU run has shown it safe).
+    if (c->comm && c->comm_world > 1 && !c->pipeline_multi_rank) return false;
     for (int v = 0; v < V; ++v) {
       if (L.posed_slots[v] == L.raw_slots[v] || c->slots[L.raw_slots[v]].has_normals) return false;
       for (int u = 0; u < v; ++u) if (L.posed_slots[u] == L.posed_slots[v]) return false;
@@ -2540,9 +2548,17 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "cull_list_w")) { if (value != 1 && value != 2 && value != 4) return MVR_E_ARG; c->cull_list_w = value; }
   else if (!std::strcmp(key, "grid_cluster")) { if (value < 1) return MVR_E_ARG; c->grid_cluster = value; }
   else if (!std::strcmp(key, "grid_wide_waves")) { if (value < 1 || value > 64) return MVR_E_ARG; c->grid_wide_waves = value; }
+  else if (!std::strcmp(key, "grid_stage")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_stage = value; }
+  else if (!std::strcmp(key, "grid_stage_lone")) c->grid_stage_lone = value != 0;
+  else if (!std::strcmp(key, "grid_stage_stat")) {
+    if (value && !c->stage_stat) { MVR_HIP_TRY(c, hipMalloc(&c->stage_stat, 64 * 64 * sizeof(unsigned long long))); }
+    if (c->stage_stat) { MVR_HIP_TRY(c, hipStreamSynchronize(c->stream)); MVR_HIP_TRY(c, hipMemset(c->stage_stat, 0, 64 * 64 * sizeof(unsigned long long))); }
+    if (!value && c->stage_stat) { (void)hipFree(c->stage_stat); c->stage_stat = nullptr; }
+  }
   else if (!std::strcmp(key, "grid_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->grid_lanes = value; }
   else if (!std::strcmp(key, "grid_cell_points")) { if (value < 1) return MVR_E_ARG; c->grid_cell_points = value; }
   else if (!std::strcmp(key, "pipeline")) c->pipeline = value != 0;
+  else if (!std::strcmp(key, "pipeline_multi_rank")) c->pipeline_multi_rank = value != 0;
   else if (!std::strcmp(key, "wait_timeout_ms")) { if (value < 1) return MVR_E_ARG; c->wait_timeout_ms = value; }
   else if (!std::strcmp(key, "inject_fail_pass")) { c->inject_fail_at = value; c->dist_pass = 0; }
   else if (!std::strcmp(key, "inject_stall_pass")) { c->inject_stall_at = value; c->dist_pass = 0; }
@@ -2572,6 +2588,19 @@ API int mvr_ctx_stat(mvr_ctx *ctx, const char *key, double *value)
   else if (!std::strcmp(key, "fused_passes")) *value = (double)c->fused_passes;
   else if (!std::strcmp(key, "blocking_events")) *value = (double)c->blocking_events;
   else if (!std::strcmp(key, "pipeline")) *value = (double)c->pipeline;
+  else if (!std::strncmp(key, "stage_", 6) && c->stage_stat) {      // staged walk diagnostics: waves by outcome since grid_stage_stat was set
+    unsigned long long h[64] = {0};
+    std::vector<unsigned long long> raw(64 * 64);
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MVR_HIP_TRY(c, hipMemcpy(raw.data(), c->stage_stat, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int sh = 0; sh < 64; ++sh) for (int k = 0; k < 64; ++k) h[k] += raw[(size_t)sh * 64 + k];
+    if (!std::strncmp(key, "stage_raw_", 10)) { const int k = std::atoi(key + 10); if (k < 0 || k > 63) return MVR_E_ARG; *value = (double)h[k]; }
+    else if (!std::strcmp(key, "stage_staged")) *value = (double)(h[1] + h[9]);
+    else if (!std::strcmp(key, "stage_rows")) *value = (double)(h[2] + h[10]);
+    else if (!std::strcmp(key, "stage_width")) *value = (double)(h[3] + h[11]);
+    else if (!std::strcmp(key, "stage_points")) *value = (double)(h[4] + h[12]);
+    else return MVR_E_ARG;
+  }
   else return MVR_E_ARG;
   return MVR_OK;
 }

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <iterator>
+#include <type_traits>
 #include <vector>
 
 #include "mvr_internal.h"
@@ -121,10 +122,11 @@ struct ReverseU32 {
   __host__ __device__ bool operator<(const ReverseU32 &o) const { return last > o.last; }
 };
 inline ReverseU32 thrust_like_reverse(uint32_t *p, size_t len) { return ReverseU32{p + (len ? len - 1 : 0)}; }
-// the four entries behind start[cells] (the walk reads four consecutive starts with one load): all n
+// the eight entries behind start[cells] (the walk reads four consecutive starts with one load, the staged walk eight with two): all n
+constexpr size_t kStartPad = 8;
 __global__ void pad_start_kernel(uint32_t *__restrict__ start, size_t cells, uint32_t n)
 {
-  if (threadIdx.x < 4) start[cells + 1 + threadIdx.x] = n;
+  if (threadIdx.x < kStartPad) start[cells + 1 + threadIdx.x] = n;
 }
 
 __global__ void grid_gather_kernel(const float4 *__restrict__ p, const uint32_t *__restrict__ gperm, size_t n, float4 *__restrict__ graw)
@@ -198,13 +200,88 @@ constexpr int kGridThreads = 256;
 #endif
 struct __attribute__((packed, aligned(4))) Start4 { uint32_t a, b, c, d; };      // four consecutive cell starts, 4-byte aligned (the array is padded by four entries)
 
+// ---- wave-wide reductions and scans without the LDS crossbar: DPP row shifts inside the rows of 16 lanes, the four row results
+// read as scalars (a __shfl_* is a ds_bpermute: it takes the LDS's issue slots, which the staged walk below needs for its points)
+template <int CTRL> __device__ __forceinline__ int dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }      // lanes without a source keep v
+template <int CTRL> __device__ __forceinline__ int dpp_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }       // ... get 0
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+  v = min(v, dpp_keep<0x111>(v)); v = min(v, dpp_keep<0x112>(v)); v = min(v, dpp_keep<0x114>(v)); v = min(v, dpp_keep<0x118>(v));      // lane 15 of a row: the row's minimum
+  return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+  v = max(v, dpp_keep<0x111>(v)); v = max(v, dpp_keep<0x112>(v)); v = max(v, dpp_keep<0x114>(v)); v = max(v, dpp_keep<0x118>(v));
+  return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+// inclusive prefix sum over the 64 lanes (Hillis-Steele inside the rows, then the row totals carried across: three scalar adds)
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t x, uint32_t *total)
+{
+  int v = (int)x;
+  v += dpp_zero<0x111>(v); v += dpp_zero<0x112>(v); v += dpp_zero<0x114>(v); v += dpp_zero<0x118>(v);
+  const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+  const int row = (int)(threadIdx.x & 63) >> 4;
+  v += row == 0 ? 0 : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2;
+  *total = (uint32_t)(r0 + r1 + r2 + r3);
+  return (uint32_t)v;
+}
+
+// ---- the STAGED walk (round 4).  What bounds the plain walk below is not bytes and not cache lines but the NUMBER of vector
+// memory instructions a wave issues: every 16-byte-per-lane load costs the CU's texture-address path ~19 cycles whatever its
+// lanes touch (tools/exp_ta.hip; TA_TA_BUSY / SQ_INSTS_VMEM_RD = 19.6 cycles in the walk), and a wave of the settled ring step
+// issues ~90 of them: a range load per row of cells and four point loads per round, for as many rounds as its LONGEST lane needs.
+// The 64 queries of a wave are neighbours on a surface (Hilbert order), so the cells their balls overlap lie in one small box.
+// With STAGE the wave
+//   0. lets every lane ask for the ranges of its first rows of cells at once (they depend on its own ball only);
+//   1. reduces the walking lanes' cell boxes to their hull [X0, X1] x [Y0, Y1] x [Z0, Z1]  (six DPP reductions);
+//   2. marks, per row of that box, the cells some lane wants (an LDS OR per lane and row: the hull is mostly air -- a surface runs
+//      through it at an angle) and reads where each row's wanted cells begin and end: two 4-byte loads per lane for the whole wave;
+//   3. prefix-sums the rows' lengths and copies their points -- a row's wanted cells are one contiguous range of the grid-ordered
+//      array -- into LDS by LDS-DMA loads (global_load_lds_dwordx4: per-lane source, 64 consecutive staged positions per
+//      instruction, no registers, no ds_write), with a table row -> {grid position, staged position} of its first point;
+//   4. every lane then walks ONLY ITS OWN cells, row by row as before, but from LDS: a ds_read_b64 turns a row's range into staged
+//      positions, four ds_read_b128 per round of four points -- the LDS serves a wave's 16-byte read in 4 cycles, not 19.
+// Rows are staged in order while they fit (kStagePts points, kStageRows rows): a row behind that is walked from global memory by
+// the lanes that want it -- the staging degrades row by row, there is no cliff.  Same candidates (a lane's own cells, or real
+// target points behind a short row as before), same `take`, same 64-bit candidate, same tie rule: bit-identical to the plain
+// walk (tests/test_gpu_ring.py, test_gpu_exact.py with grid_stage 0 / 1 / 2).  The probe and the wide / listed routes are
+// untouched.  registrator.cpp:644-649 is what this answers.
+// What it buys, what it does not (profiles/r04_*): the forward launch of the 12 x 200k ring 113 -> 96 us (vector memory
+// instructions 3.3e6 -> 1.1e6 per launch, TA busy -50 %), at 40 % MORE vector ALU instructions (the staging) and 7 instead of 8
+// waves per SIMD; a wave's chain of dependent round trips (query -> seed -> seed point -> rows -> points -> walk -> match's
+// position) is what is left, ~37 k cycles per wave, and every step to shorten the walk itself that was built on top -- the rounds
+// of all lanes dealt evenly through a list in LDS (the dealt walk took 4 k cycles instead of 12 k, making the list 13 k), more
+// points per wave at fewer waves per SIMD (256 / 320 / 448 points: 98 / 122 / 141 us) -- lost more in occupancy or in
+// bookkeeping than it won.  The REVERSE launch's queries are 2.4 x sparser (the matched targets): its waves want ~350 points,
+// 14 % of them fit, and it stays with the plain walk (70 us against 72 staged).
+#ifndef MVR_STAGE_PTS
+#define MVR_STAGE_PTS 192
+#endif
+#ifndef MVR_STAGE_ROWS
+#define MVR_STAGE_ROWS 64
+#endif
+#ifndef MVR_STAGE_BURST
+#define MVR_STAGE_BURST 4
+#endif
+constexpr int kStageRows = MVR_STAGE_ROWS;     // rows of cells of a wave's box: one or two per lane
+constexpr int kStagePts = MVR_STAGE_PTS;       // points a wave stages at most (16 bytes each; + the table: ~7.5 KB of LDS per wave at 384)
+
 // G lanes share a query: lane `sub` of the group walks rows sub, sub + G, ... of the ball's rows of cells, the group's
 // answers meet in log2(G) shuffles.  (One lane per query leaves a wave waiting for its widest ball -- rows times points
 // of dependent round trips; dealing the rows to G lanes cuts that chain G-fold and the spread between lanes with it.
 // The query, its seed and its cell range are loaded by all G lanes from the same addresses: one request.)
-template <bool FMA, int G>
-__global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, XcdMap map, unsigned long long *__restrict__ evals)
+#ifndef MVR_STAGE_WAVES
+#define MVR_STAGE_WAVES 0
+#endif
+#if MVR_STAGE_WAVES
+#define MVR_GRID_OCC __attribute__((amdgpu_waves_per_eu(MVR_STAGE_WAVES, MVR_STAGE_WAVES)))
+#else
+#define MVR_GRID_OCC
+#endif
+template <bool FMA, int G, bool STAGE>
+__global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(GridBatch batch, XcdMap map, unsigned long long *__restrict__ evals, unsigned long long *__restrict__ stage_stat)
 {
+  static_assert(!STAGE || G == 1, "the staged walk is the one-lane-per-query walk");
   constexpr uint32_t kPerBlock = kGridThreads / G;
   uint32_t pair = 0, set = 0;
   if (!xcd_map_block(map, blockIdx.x, &pair, &set)) return;
@@ -215,11 +292,92 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
   const uint32_t pos = set * kPerBlock + threadIdx.x / G;
   unsigned long long n_eval = 0;
   bool went_wide = false, went_cull = false;
-  if (pos < nq) {
-    const uint32_t qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;            // position in the query cloud's Hilbert order
+#ifdef MVR_STAGE_CLOCK
+  // diagnostics build: shader-clock stamps between the phases of a wave, summed per outcome into stage_stat[16 + 8 * outcome + phase]
+  // (phases: 0 prologue, 1 box + rows + table, 2 point staging, 3 walk, 4 epilogue; [.. + 7] = waves)
+  long long ck[6]; int ckn = 0;
+#define MVR_CK() do { ck[ckn++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define MVR_CK() do { } while (0)
+#endif
+  MVR_CK();
+  // (per-lane state that outlives the prologue: the staged walk is a WAVE-wide step, so it cannot sit inside `if (pos < nq)`)
+  const bool live = pos < nq;
+  bool walks = false, answers = false;
+  uint32_t qpos = 0;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+  unsigned long long best = ~0ull;
+  const uint32_t nt4 = a.nt - 4u;     // (a grid is only built for a set of four points or more)
+  // The candidate so far as ONE 64-bit number, (bits of d2, original index): d2 >= +0, so the order of the bits is the order of
+  // the distances, and "nearer, or as near with the smaller index" is one unsigned comparison.  It starts at (bound, none):
+  // candidates beyond the bound cannot be the answer; at the bound they can (inclusive).
+  // (WHERE in the grid order the winner lies is not kept: its Hilbert position, which the keys and the marks want, comes
+  // from its original index through the ordering's inverse -- one gather per query either way, three instructions less
+  // per candidate round and four registers: 62 instead of 66, the eighth wave per SIMD)
+  auto take = [&](const float4 t) {
+    const unsigned long long cand = ((unsigned long long)__float_as_uint(gdist2<FMA>(t, q.x, q.y, q.z)) << 32) | __float_as_uint(t.w);
+    best = cand < best ? cand : best;
+  };
+  // the walk of a box of cells [x0, x1] x [y0, y1] x [z0, z1]: rows of cells (x-runs: ONE contiguous
+  // range of the grid-ordered array each); the next row's range is requested while this row's points are evaluated.
+  // (a row's range = two entries of the cell-start array at most three cells apart in all but the widest balls:
+  // ONE 16-byte load from the first of them brings both)
+  auto walk_box = [&](const int wx0, const int wx1, const int wy0, const int wy1, const int wz0, const int wz1) {
+    const uint32_t nxm = (uint32_t)(wx1 - wx0);
+    auto row_range = [&](uint32_t row, uint32_t &s, uint32_t &e) {
+#if MVR_GRID_ROW4
+      const Start4 v = *reinterpret_cast<const Start4 *>(a.start + row + (uint32_t)wx0);
+      s = v.a;
+      e = nxm == 0u ? v.b : nxm == 1u ? v.c : v.d;
+      if (nxm > 2u) e = a.start[row + (uint32_t)wx1 + 1u];
+#else
+      s = a.start[row + (uint32_t)wx0]; e = a.start[row + (uint32_t)wx1 + 1u];
+#endif
+    };
+    const int ny = wy1 - wy0 + 1, nrows = ny * (wz1 - wz0 + 1);
+    uint32_t s, e;
+    uint32_t row = (uint32_t)((wz0 * a.dim[1] + wy0) * a.dim[0]);          // rows in y-major order: the next one is dim[0] further, or at the next z
+    const uint32_t row_step = (uint32_t)a.dim[0], z_step = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
+    int yy = 0;
+    row_range(row, s, e);
+    for (int it = 0; it < nrows; ++it) {
+      uint32_t s2 = 0, e2 = 0;
+      if (it + 1 < nrows) {
+        row += row_step;
+        if (++yy == ny) { yy = 0; row += z_step; }
+        row_range(row, s2, e2);
+      }
+      if (sub == 0) n_eval += e - s;
+      if (G == 1) {
+        // one lane per query: four CONSECUTIVE points per round from one address (the loads differ by their immediate offsets).
+        // A short row runs on into the points behind it -- points of the target all the same: looking at one more changes
+        // nothing (whatever lies within the bound lies in the ball's cells and is looked at anyway); only the array's end is
+        // kept clear of (the last round starts four points before it at the latest).
+        for (uint32_t k = s; k < e; k += 4) {
+          const uint32_t kb = min(k, nt4);
+          const float4 *__restrict__ p4 = a.gts + kb;
+          const float4 t0 = p4[0], t1 = p4[1], t2 = p4[2], t3 = p4[3];
+          take(t0); take(t1); take(t2); take(t3);
+        }
+      } else {
+        // G lanes per query: they take CONSECUTIVE points of the row -- one instruction, one cache line per query
+        // (what a gather costs in the L1 is the number of distinct lines its lanes touch, not the bytes per lane:
+        // tools/exp_ta.hip), two rounds in flight
+        for (uint32_t k = s + sub; k < e; k += 2 * G) {
+          const uint32_t k1 = k + G < e ? k + G : k;
+          const float4 t0 = a.gts[k], t1 = a.gts[k1];
+          take(t0); take(t1);
+        }
+      }
+      s = s2; e = e2;
+    }
+  };
+  if (live) {
+    qpos = a.qlist ? a.qlist[pos] : a.q_begin + pos;            // position in the query cloud's Hilbert order
     // (the three loads that depend on nothing but the position go out together: the prologue is a chain of dependent gathers,
     // query -> previous match -> its grid position -> its coordinates, and every link not waited for separately is a round trip less)
-    const float4 q = a.qs[qpos];
+    q = a.qs[qpos];
     const uint32_t start_bits = a.qbound ? a.qbound[qpos] : 0xFFFFFFFFu;
     const uint32_t prev = a.seed_from_keys ? (uint32_t)a.keys[qpos] : kNone;
     // the bound: the cap, or a distance within which a point is KNOWN to exist (inclusive)
@@ -231,9 +389,9 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     Ball ball = grid_ball(a, q, bound);
     const float rx = ball.rx, ry = ball.ry, rz = ball.rz;
     float rad = ball.rad;
-    int x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]), x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
-    int y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]), y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
-    int z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]), z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
+    x0 = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]); x1 = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
+    y0 = cell_of(ry - rad, a.lo[1], a.inv_h, a.dim[1]); y1 = cell_of(ry + rad, a.lo[1], a.inv_h, a.dim[1]);
+    z0 = cell_of(rz - rad, a.lo[2], a.inv_h, a.dim[2]); z1 = cell_of(rz + rad, a.lo[2], a.inv_h, a.dim[2]);
     bool worth = true;
     if (!seeded) {
       // nothing known: is any target point near at all?  The query's own cell (clamped into the grid) is dt cells from the
@@ -244,72 +402,7 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       const float least = (d == 255u ? (float)a.dt_max : (float)d - 1.f) * a.h;
       worth = !(least > rad);
     }
-    // the candidate so far and the walk of a box of cells [x0, x1] x [y0, y1] x [z0, z1]: rows of cells (x-runs: ONE contiguous
-    // range of the grid-ordered array each); the next row's range is requested while this row's points are evaluated.
-    // (a row's range = two entries of the cell-start array at most three cells apart in all but the widest balls:
-    // ONE 16-byte load from the first of them brings both)
-    // The candidate so far as ONE 64-bit number, (bits of d2, original index): d2 >= +0, so the order of the bits is the order of
-    // the distances, and "nearer, or as near with the smaller index" is one unsigned comparison.  It starts at (bound, none):
-    // candidates beyond the bound cannot be the answer; at the bound they can (inclusive).
-    unsigned long long best = ((unsigned long long)__float_as_uint(bound) << 32) | kNone;
-    // (WHERE in the grid order the winner lies is not kept: its Hilbert position, which the keys and the marks want, comes
-    // from its original index through the ordering's inverse -- one gather per query either way, three instructions less
-    // per candidate round and four registers: 62 instead of 66, the eighth wave per SIMD)
-    const uint32_t nt4 = a.nt - 4u;     // (a grid is only built for a set of four points or more)
-    auto take = [&](const float4 t) {
-      const unsigned long long cand = ((unsigned long long)__float_as_uint(gdist2<FMA>(t, q.x, q.y, q.z)) << 32) | __float_as_uint(t.w);
-      best = cand < best ? cand : best;
-    };
-    auto walk_box = [&](const int wx0, const int wx1, const int wy0, const int wy1, const int wz0, const int wz1) {
-      const uint32_t nxm = (uint32_t)(wx1 - wx0);
-      auto row_range = [&](uint32_t row, uint32_t &s, uint32_t &e) {
-#if MVR_GRID_ROW4
-        const Start4 v = *reinterpret_cast<const Start4 *>(a.start + row + (uint32_t)wx0);
-        s = v.a;
-        e = nxm == 0u ? v.b : nxm == 1u ? v.c : v.d;
-        if (nxm > 2u) e = a.start[row + (uint32_t)wx1 + 1u];
-#else
-        s = a.start[row + (uint32_t)wx0]; e = a.start[row + (uint32_t)wx1 + 1u];
-#endif
-      };
-      const int ny = wy1 - wy0 + 1, nrows = ny * (wz1 - wz0 + 1);
-      uint32_t s, e;
-      uint32_t row = (uint32_t)((wz0 * a.dim[1] + wy0) * a.dim[0]);          // rows in y-major order: the next one is dim[0] further, or at the next z
-      const uint32_t row_step = (uint32_t)a.dim[0], z_step = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
-      int yy = 0;
-      row_range(row, s, e);
-      for (int it = 0; it < nrows; ++it) {
-        uint32_t s2 = 0, e2 = 0;
-        if (it + 1 < nrows) {
-          row += row_step;
-          if (++yy == ny) { yy = 0; row += z_step; }
-          row_range(row, s2, e2);
-        }
-        if (sub == 0) n_eval += e - s;
-        if (G == 1) {
-          // one lane per query: four CONSECUTIVE points per round from one address (the loads differ by their immediate offsets).
-          // A short row runs on into the points behind it -- points of the target all the same: looking at one more changes
-          // nothing (whatever lies within the bound lies in the ball's cells and is looked at anyway); only the array's end is
-          // kept clear of (the last round starts four points before it at the latest).
-          for (uint32_t k = s; k < e; k += 4) {
-            const uint32_t kb = min(k, nt4);
-            const float4 *__restrict__ p4 = a.gts + kb;
-            const float4 t0 = p4[0], t1 = p4[1], t2 = p4[2], t3 = p4[3];
-            take(t0); take(t1); take(t2); take(t3);
-          }
-        } else {
-          // G lanes per query: they take CONSECUTIVE points of the row -- one instruction, one cache line per query
-          // (what a gather costs in the L1 is the number of distinct lines its lanes touch, not the bytes per lane:
-          // tools/exp_ta.hip), two rounds in flight
-          for (uint32_t k = s + sub; k < e; k += 2 * G) {
-            const uint32_t k1 = k + G < e ? k + G : k;
-            const float4 t0 = a.gts[k], t1 = a.gts[k1];
-            take(t0); take(t1);
-          }
-        }
-        s = s2; e = e2;
-      }
-    };
+    best = ((unsigned long long)__float_as_uint(bound) << 32) | kNone;
     int nrows = (y1 - y0 + 1) * (z1 - z0 + 1);
     bool wide = worth && nrows > batch.light_rows;
     if (G == 1 && worth && batch.probe && nrows > batch.probe_rows) {
@@ -359,27 +452,202 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
     went_cull = to_cull;
     // (a wide query that goes on with a bound from the probe: the launch that answers it starts from the start bound or the
     // seed again -- it finds the probe's point itself; what the probe saves there is nothing, what it costs is four short rows)
-    if (!to_cull && !to_wave) {
-      if (worth) walk_box(x0, x1, y0, y1, z0, z1);
-      // the group's answer: the smallest (d2, index) of its lanes
+    answers = !to_cull && !to_wave;
+    walks = answers && worth;
+  }
+  bool staged = false;
+  MVR_CK();
+  if constexpr (STAGE) {
+    static_assert(kStageRows == 64, "one row of the box per lane");
+    constexpr int kMarkBytes = (kStagePts + 3 + 63) / 64 * 64 < 256 ? 256 : (kStagePts + 3 + 63) / 64 * 64;      // (at least the 64 words the lanes clear with one store each)
+    __shared__ float4 s_pts[kGridThreads / 64][kStagePts + 4];
+    __shared__ uint2 s_rows[kGridThreads / 64][kStageRows];          // per row of the box: {grid position of its first staged point, staged position of that point} ({~0, ~0}: not staged)
+    __shared__ uint32_t s_mask[kGridThreads / 64][kStageRows];       // per row of the box: the cells (bit c = cell X0 + c) some lane's ball overlaps
+    __shared__ uint32_t s_mark[kGridThreads / 64][kMarkBytes / 4];   // per staged position (a byte each): row + 1 where a row's points begin, else 0
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4 *const pts = s_pts[wv];
+    uint2 *const rowtab = s_rows[wv];
+    uint32_t *const rmask = s_mask[wv];
+    uint8_t *const mark = reinterpret_cast<uint8_t *>(s_mark[wv]);
+    // ---- 0. every walking lane asks for the ranges of its first rows of cells NOW (they depend on its own ball only): the
+    // answers travel while the wave stages.  Rows in y-major order, as the plain walk takes them.
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    const uint32_t nxm = (uint32_t)(x1 - x0);
+    auto row_range = [&](uint32_t row, uint32_t &rs_, uint32_t &re_) {
+      const Start4 v = *reinterpret_cast<const Start4 *>(a.start + row + (uint32_t)x0);
+      rs_ = v.a;
+      re_ = nxm == 0u ? v.b : nxm == 1u ? v.c : v.d;
+      if (nxm > 2u) re_ = a.start[row + (uint32_t)x1 + 1u];
+    };
+    uint32_t row_g = (uint32_t)((z0 * a.dim[1] + y0) * a.dim[0]);
+    const uint32_t row_step = (uint32_t)a.dim[0], z_step_g = (uint32_t)((a.dim[1] - ny) * a.dim[0]);
+    int yy = 0;
+    constexpr int kBurst = MVR_STAGE_BURST;
+    uint32_t bs[kBurst], be[kBurst];
 #pragma unroll
-      for (int o = 1; o < G; o <<= 1) {
-        const unsigned long long ob = __shfl_xor(best, o, 64);
-        if (ob < best) best = ob;
-      }
-      const float bd = __uint_as_float((uint32_t)(best >> 32));
-      const uint32_t bi = (uint32_t)best;
-      if (sub == 0) {
-        const bool found = bi != kNone && bd <= cap2;
-        const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
-        uint32_t low = bi;
-        if (found && (a.key_by_pos || a.mark)) {
-          const uint32_t hp = a.tinv[bi];              // the match's position in its set's Hilbert order
-          if (a.key_by_pos) low = hp;
-          if (a.mark) __hip_atomic_store(&a.mark[hp], __float_as_uint(bd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = 0; u < kBurst; ++u) { bs[u] = 0; be[u] = 0; }
+    if (walks) {
+#pragma unroll
+      for (int u = 0; u < kBurst; ++u)
+        if (u < nrows) {
+          row_range(row_g, bs[u], be[u]);
+          row_g += row_step;
+          if (++yy == ny) { yy = 0; row_g += z_step_g; }
         }
-        a.keys[ord] = found ? (((nnkey_t)__float_as_uint(bd) << 32) | low) : kKeyInit;
+    }
+    // ---- 1. the box of the walking lanes' cells
+    const int X0 = wave_min_i32(walks ? x0 : 0x7FFFFFFF), X1 = wave_max_i32(walks ? x1 : -1);
+    uint32_t why = 0;      // diagnostics: 1 staged in full, 2 more rows than the table holds (the rows behind it from global memory), 3 too wide, 4 more points than fit (the rows behind from global memory)
+    if (X1 >= X0) {
+      const int Y0 = wave_min_i32(walks ? y0 : 0x7FFFFFFF), Y1 = wave_max_i32(walks ? y1 : -1);
+      const int Z0 = wave_min_i32(walks ? z0 : 0x7FFFFFFF), Z1 = wave_max_i32(walks ? z1 : -1);
+      const int NY = Y1 - Y0 + 1, R = NY * (Z1 - Z0 + 1), W = X1 - X0 + 1;
+      if (W > 32) why = 3u;
+      else {
+        const int Rs = min(R, kStageRows);          // rows of the box that get a table entry: the first Rs in y-major order
+        // ---- 2a. which cells of which rows are wanted at all: every lane ORs the x-range of its ball into the masks of its rows
+        // (the box is the hull of the balls -- a surface runs through it at an angle, most of its cells are nobody's)
+        rmask[lane] = 0u;
+        reinterpret_cast<uint32_t *>(mark)[lane] = 0u;
+        if (kMarkBytes > 256) { for (int i = 64 + lane; i < kMarkBytes / 4; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t z_step_r = (uint32_t)(NY - ny);
+        if (walks) {
+          const uint32_t bits = ((nxm >= 31u ? 0xFFFFFFFFu : ((2u << nxm) - 1u))) << (uint32_t)(x0 - X0);
+          uint32_t ridx = (uint32_t)((z0 - Z0) * NY + (y0 - Y0));
+          int ry = 0;
+          for (int k = 0; k < nrows; ++k) {
+            if (ridx < (uint32_t)kStageRows) __hip_atomic_fetch_or(&rmask[ridx], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            ridx += 1u;
+            if (++ry == ny) { ry = 0; ridx += z_step_r; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- 2b. the rows of the box, a lane each (row `lane` = (Y0 + lane % NY, Z0 + lane / NY)): where its wanted cells
+        // [first, last] begin and end in the grid-ordered array
+        uint32_t sA = 0, len = 0, P = 0;
+        const uint32_t m = lane < Rs ? rmask[lane] : 0u;
+        if (m) {
+          const int zq = (int)(((float)lane + 0.5f) * (1.0f / (float)NY)), yq = lane - zq * NY;      // (lane / NY: the float quotient is off by 1e-5 at most, the true one sits 1 / (2 NY) from an integer)
+          const uint32_t base = (uint32_t)(((Z0 + zq) * a.dim[1] + (Y0 + yq)) * a.dim[0] + X0);
+          const uint32_t first = (uint32_t)__builtin_ctz(m), last = 31u - (uint32_t)__builtin_clz(m);
+          sA = a.start[base + first];
+          len = a.start[base + last + 1u] - sA;
+        }
+        const uint32_t off = wave_scan_incl_u32(len, &P) - len;
+        // rows are staged in order while they fit: a row that does not fit any more (and every row behind it) is walked from
+        // global memory by the lanes that want it -- the staging degrades row by row instead of failing for the wave
+        staged = true;
+        const bool fits = off + len <= (uint32_t)kStagePts;
+        why = P > (uint32_t)kStagePts ? 4u : R > kStageRows ? 2u : 1u;
+        rowtab[lane] = fits ? make_uint2(sA, off) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (fits && len) mark[off] = (uint8_t)(lane + 1);
+        uint32_t Ps = P;
+        if (P > (uint32_t)kStagePts) {      // (what is staged: the rows before the first that does not fit -- `fits` is monotone)
+          const int nfit = __popcll(__ballot(fits));
+          Ps = nfit ? (uint32_t)__builtin_amdgcn_readlane((int)(off + len), nfit - 1) : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MVR_CK();
+        // ---- 3. the points: staged position j <- the row whose range holds it: the last row that begins at or before j -- a
+        // running maximum over the positions' marks (row + 1 where a row begins), 64 positions at a time; three more positions
+        // repeat the last point, so that a round of four never reads what was not staged.  64 consecutive positions per
+        // instruction, and the instruction is an LDS-DMA load (global_load_lds_dwordx4: per-lane source address, destination
+        // = a wave-uniform LDS address + 16 x lane): no registers for the data, no ds_write, ALL of a wave's point loads in
+        // flight at once.
+        if (Ps) {
+          const uint32_t Pm1 = Ps - 1u, n_stage = Ps + 3u;
+          int carry = 0;
+#pragma unroll
+          for (int c = 0; c < (kStagePts + 3 + 63) / 64; ++c) {
+            if ((uint32_t)(c * 64) < n_stage) {          // (uniform)
+              const uint32_t j = (uint32_t)(c * 64 + lane), jj = min(j, Pm1);
+              int v = j <= Pm1 ? (int)mark[j] : 0;
+              v = max(v, dpp_keep<0x111>(v)); v = max(v, dpp_keep<0x112>(v)); v = max(v, dpp_keep<0x114>(v)); v = max(v, dpp_keep<0x118>(v));      // running maximum inside the rows of 16 lanes
+              const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+              const int q4 = lane >> 4;
+              const int before = q4 == 0 ? carry : q4 == 1 ? max(carry, r0) : q4 == 2 ? max(carry, max(r0, r1)) : max(carry, max(max(r0, r1), r2));
+              v = max(v, before);
+              carry = max(max(carry, max(r0, r1)), max(r2, r3));
+              const uint2 t = rowtab[v - 1];          // (v >= 1: position 0 is the beginning of the first row with points)
+              if (j < n_stage)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.gts + (t.x + (jj - t.y))),
+                                                 (__attribute__((address_space(3))) void *)(pts + c * 64), 16, 0, 0);
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA writes count as vector memory operations of this wave
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MVR_CK();
+        // ---- 4. every lane walks its own cells: a row's range in the grid-ordered array (asked for above, kBurst rows at a
+        // time) becomes a range of staged positions through the row's table entry -- or stays what it is for a row that was
+        // not staged
+        if (walks) {
+          uint32_t ridx = (uint32_t)((z0 - Z0) * NY + (y0 - Y0));
+          int ry = 0;
+          for (int k0 = 0; k0 < nrows; k0 += kBurst) {
+            if (k0) {
+#pragma unroll
+              for (int u = 0; u < kBurst; ++u)
+                if (k0 + u < nrows) {
+                  row_range(row_g, bs[u], be[u]);
+                  row_g += row_step;
+                  if (++yy == ny) { yy = 0; row_g += z_step_g; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBurst; ++u)
+              if (k0 + u < nrows) {
+                uint2 t = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (ridx < (uint32_t)kStageRows) t = rowtab[ridx];
+                ridx += 1u;
+                if (++ry == ny) { ry = 0; ridx += z_step_r; }
+                n_eval += be[u] - bs[u];
+                if (t.y != 0xFFFFFFFFu) {
+                  const uint32_t ka = t.y + (bs[u] - t.x), kb = t.y + (be[u] - t.x);
+                  for (uint32_t k = ka; k < kb; k += 4) {
+                    const float4 *p4 = pts + k;
+                    const float4 t0 = p4[0], t1 = p4[1], t2 = p4[2], t3 = p4[3];
+                    take(t0); take(t1); take(t2); take(t3);
+                  }
+                } else {
+                  for (uint32_t k = bs[u]; k < be[u]; k += 4) {
+                    const float4 *__restrict__ p4 = a.gts + min(k, nt4);
+                    const float4 t0 = p4[0], t1 = p4[1], t2 = p4[2], t3 = p4[3];
+                    take(t0); take(t1); take(t2); take(t3);
+                  }
+                }
+              }
+          }
+        }
       }
+    }
+    if (stage_stat && lane == 0 && why) atomicAdd(stage_stat + (size_t)((blockIdx.x * 4u + (uint32_t)wv) & 63u) * 64u + why + (a.qlist ? 8u : 0u), 1ull);      // (64 shards of 64 counters; + 8: a launch over a compacted query list, i.e. the reverse searches)
+  }
+#ifdef MVR_STAGE_CLOCK
+  if (!staged) { while (ckn < 4) { ck[ckn] = (long long)__builtin_readcyclecounter(); ++ckn; } }      // (a wave that was not staged: phases 1 / 2 hold whatever the attempt cost)
+#endif
+  if (walks && !staged) walk_box(x0, x1, y0, y1, z0, z1);
+  MVR_CK();
+  if (answers) {
+    // the group's answer: the smallest (d2, index) of its lanes
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+      const unsigned long long ob = __shfl_xor(best, o, 64);
+      if (ob < best) best = ob;
+    }
+    const float bd = __uint_as_float((uint32_t)(best >> 32));
+    const uint32_t bi = (uint32_t)best;
+    if (sub == 0) {
+      const bool found = bi != kNone && bd <= cap2;
+      const uint32_t ord = a.qlist ? pos : (a.key_by_pos ? qpos : __float_as_uint(q.w));
+      uint32_t low = bi;
+      if (found && (a.key_by_pos || a.mark)) {
+        const uint32_t hp = a.tinv[bi];              // the match's position in its set's Hilbert order
+        if (a.key_by_pos) low = hp;
+        if (a.mark) __hip_atomic_store(&a.mark[hp], __float_as_uint(bd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      a.keys[ord] = found ? (((nnkey_t)__float_as_uint(bd) << 32) | low) : kKeyInit;
     }
   }
   if (G == 1 && a.cull_sets) {   // a wave = one 64-query set of the culled kernel: listed if any of its queries was flagged
@@ -404,6 +672,15 @@ __global__ void __launch_bounds__(kGridThreads) nn_grid_kernel(GridBatch batch, 
       atomicAdd(s + kEvalRegion, n_eval);
     }
   }
+#ifdef MVR_STAGE_CLOCK
+  MVR_CK();
+  if (STAGE && stage_stat && (threadIdx.x & 63) == 0) {
+    unsigned long long *o = stage_stat + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u) * 64u + 16 + (staged ? 8 : 0);
+    for (int k = 0; k < 5; ++k) atomicAdd(o + k, (unsigned long long)(ck[k + 1] - ck[k]));
+    atomicAdd(o + 7, 1ull);
+  }
+#endif
+#undef MVR_CK
 }
 
 // ---- the wide bounded queries: ONE WAVE per query.  The rows of cells its ball overlaps are dealt to the lanes (one
@@ -609,7 +886,7 @@ int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream
     g->h = (float)h; g->inv_h = (float)(1.0 / h);
     const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2];
     cells_max = std::max(cells_max, cells);
-    const size_t o_start = 0, o_gperm = o_start + align256((cells + 1 + 4) * 4), o_graw = o_gperm + align256(n * 4), o_g2h = o_graw + align256(n * sizeof(float4)),
+    const size_t o_start = 0, o_gperm = o_start + align256((cells + 1 + kStartPad) * 4), o_graw = o_gperm + align256(n * 4), o_g2h = o_graw + align256(n * sizeof(float4)),
                  o_h2g = o_g2h + align256(n * 4), o_dt = o_h2g + align256(n * 4), total = o_dt + align256(cells);
     if (hipMalloc(&g->block, total) != hipSuccess) { (void)hipGetLastError(); return set_error(c, MVR_E_NOMEM, "grid build: out of device memory"); }
     g->start = reinterpret_cast<uint32_t *>(g->block + o_start); g->gperm = reinterpret_cast<uint32_t *>(g->block + o_gperm);
@@ -639,7 +916,7 @@ int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream
     while (((size_t)1 << bits) < cells) ++bits;
     size_t b1 = cub_bytes;
     MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(cub, b1, cid_a, cid_b, idx_a, g.gperm, (int)n, 0, bits, on));
-    MVR_HIP_TRY(c, hipMemsetAsync(g.start, 0xFF, (cells + 1 + 4) * 4, on));
+    MVR_HIP_TRY(c, hipMemsetAsync(g.start, 0xFF, (cells + 1 + kStartPad) * 4, on));
     hipLaunchKernelGGL(cell_first_kernel, dim3(nb), dim3(256), 0, on, cid_b, n, cells, g.start);
     auto rit = thrust_like_reverse(g.start, cells + 1);
     size_t b2 = cub_bytes;
@@ -783,7 +1060,15 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
     ProfScope ps(c, MVR_K_NN_GRID, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
-#define MVR_GRID_LAUNCH(F, GG) hipLaunchKernelGGL((nn_grid_kernel<F, GG>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals)
+#define MVR_GRID_LAUNCH(F, GG) hipLaunchKernelGGL((nn_grid_kernel<F, GG, false>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals, (unsigned long long *)nullptr)
+#define MVR_GRID_LAUNCH_STAGED(F) hipLaunchKernelGGL((nn_grid_kernel<F, 1, true>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals, c->stage_stat)
+    // (the staged walk for launches over a scan's OWN query order -- the forward searches; a launch over a compacted list, the
+    // reverse searches, has queries 2.4 x sparser and boxes that do not fit: measured equal or slower there.  grid_stage = 2: both)
+    bool listed = false;
+    for (int k = 0; k < m; ++k) listed = listed || (batch.p[k].q_count != 0 && batch.p[k].qlist != nullptr);
+    const bool stage = lanes == 1 && c->grid_stage && (c->grid_stage == 2 || !listed) && (n_pairs > 1 || c->grid_stage_lone);
+    if (stage) { if (fma) MVR_GRID_LAUNCH_STAGED(true); else MVR_GRID_LAUNCH_STAGED(false); }
+    else
     switch (lanes) {
       case 1: if (fma) MVR_GRID_LAUNCH(true, 1); else MVR_GRID_LAUNCH(false, 1); break;
       case 2: if (fma) MVR_GRID_LAUNCH(true, 2); else MVR_GRID_LAUNCH(false, 2); break;
@@ -791,6 +1076,7 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
       default: if (fma) MVR_GRID_LAUNCH(true, 4); else MVR_GRID_LAUNCH(false, 4); break;
     }
 #undef MVR_GRID_LAUNCH
+#undef MVR_GRID_LAUNCH_STAGED
     MVR_HIP_TRY(c, hipGetLastError());
   }
   return MVR_OK;

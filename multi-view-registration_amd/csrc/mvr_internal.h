@@ -254,6 +254,12 @@ struct Ctx {
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint32_t *bwide = nullptr; size_t bwide_cap = 0;       // [sources + targets of all pairs] grid search: ordinals of the wide bounded queries
   int grid_cell_points = 4;                              // points per occupied cell the grid's cell edge aims at (grids built from then on)
+  // the STAGED walk (mvr_grid.hip): a wave of the one-lane-per-query walk copies the box of its lanes' cells into LDS with a few
+  // coalesced loads and every lane walks its own cells there -- the walk is bound by the number of vector memory instructions a
+  // wave issues, not by bytes.  0: the plain walk; 1 (default): launches over a scan's own query order (the forward searches); 2: every
+  // launch, compacted query lists too (measured equal or slower there).  A lone pair's launch has its own switch.
+  int grid_stage = 1, grid_stage_lone = 1;
+  unsigned long long *stage_stat = nullptr;              // diagnostics (tune key grid_stage_stat = 1): device counters [64 shards][64] of the staged walk's waves: [1] staged, [2] too many rows, [3] too wide, [4] too many points
   int grid_lanes = 1;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
   int grid_cluster = 8;                                  // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
   int grid_wide_waves = 32;                              // waves per CU of the wave-per-query launch
@@ -279,6 +285,7 @@ struct Ctx {
   // ---- pipelined ring run (ring_passes, mvr_ctx.hip): pass k+1's whole launch chain is enqueued while pass k runs, behind
   // a gate the host opens after its solve; the poses reach the kernels through a device table instead of kernel arguments
   int pipeline = 1;                                   // 0: every pass is enqueued after the previous solve (round-2 behaviour)
+  int pipeline_multi_rank = 0;                        // 1: passes with a collective over more than one rank may be queued behind the gate too (off until a recorded two-GPU run says so)
   bool no_sync = false;                               // a gated chain is being enqueued: nothing may wait for the stream or reallocate (may_block)
   unsigned long long blocking_events = 0;             // how often something did wait / reallocate (a pass without any is in steady state)
   bool single_group = false;                          // the fused pass runs its pairs as ONE group for the whole ring run: a run that may queue passes ahead must not change the layout of its work buffers (and of the seeds in them) when it starts to

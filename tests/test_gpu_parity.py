@@ -86,6 +86,35 @@ def test_grown_target_searches_like_a_fresh_upload(gpu, orc, mvr):
     assert np.array_equal(si, oi) and np.array_equal(bits(sd), bits(od))      # duplicates sit at higher indices: the lowest index wins
 
 
+def test_posed_copy_into_a_former_shard_slot_drops_its_segments(gpu, orc):
+    """A slot that was a SHARD (mvr_cloud_set_global_base / append_range: the target-sharded sequential mode) and is then reused
+    as the destination of a plain posed copy must lose its segment table with the old points (the batch path of
+    mvr_cloud_transform kept it).  Otherwise every append takes the shard branch -- a segment per append until 'too many
+    segments' -- and the growing model's ordering is rebuilt at every align.  Here: shard slot 3, pose a plain scan into it,
+    append scans to it more often than a segment table has room for, and search it like a fresh upload of the same points."""
+    rng = np.random.default_rng(1206)
+    a = rand_cloud(rng, 2500, scale=20)
+    gpu.upload(0, a)
+    gpu.upload(3, rand_cloud(rng, 700, scale=20)); gpu.set_global_base(3, 12345)          # slot 3 is a shard now
+    gpu.append_range(3, 0, 100, 50, 99000)
+    T = np.eye(4); T[:3, 3] = (0.25, -0.5, 0.125)
+    gpu.transform(3, 0, T)                                                                # plain posed copy into the former shard
+    whole = gpu.download(3)
+    assert np.array_equal(whole, orc.transform_f64(T, a))
+    gpu.reserve(3, 2500 + 80 * 40)
+    for k in range(70):                                                                   # more appends than kMaxSegs
+        p = rand_cloud(rng, 40, scale=20)
+        gpu.upload(1, p); gpu.append(3, 1)
+        whole = np.concatenate([whole, p])
+    q = rand_cloud(rng, 3000, scale=20); gpu.upload(5, q)
+    gi, gd = gpu.nn(5, 3)
+    gpu.upload(2, whole)
+    fi, fd = gpu.nn(5, 2)
+    assert gpu.size(3) == len(whole) and np.array_equal(gi, fi) and np.array_equal(bits(gd), bits(fd))
+    oi, od = orc.nn(q, whole, kdtree=True)
+    assert np.array_equal(gi, oi) and np.array_equal(bits(gd), bits(od))
+
+
 def test_transforms_bit_exact(gpu, orc):
     rng = np.random.default_rng(101)
     pts = rand_cloud(rng, 5000)

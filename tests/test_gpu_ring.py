@@ -166,6 +166,10 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
     dict(grid_probe_rows=1), dict(grid_probe_rows=4, grid_cell_points=1), dict(grid_probe_rows=3, grid_light_rows=64, grid_cell_points=40),
     dict(grid_probe=0), dict(grid_probe=0, grid_light_rows=2), dict(grid_probe=1, grid_light_rows=1, grid_cluster=1), dict(setup_first=0), dict(cull_w=4), dict(cull_w=2),
     dict(lazy_super=0), dict(lazy_super=0, grid_sets=0), dict(lazy_super=1, grid_tail=0, cull_list=0),
+    # the staged walk (round 4): off, for the reverse launches too, with tiny cells (more rows in a wave's box than its table holds),
+    # with huge cells and wide balls walked in-thread (more points than a wave's LDS holds: the rows behind are walked from global memory)
+    dict(grid_stage=0), dict(grid_stage=2), dict(grid_stage=2, grid_cell_points=1), dict(grid_stage=2, grid_cell_points=40, grid_light_rows=64),
+    dict(grid_stage=2, grid_light_rows=64, grid_probe=0), dict(grid_stage=1, grid_cell_points=2, grid_light_rows=64, grid_probe=0), dict(grid_stage=2, grid_cell_points=12, grid_wide=0),
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
     """Every routing knob of the grid search (lanes per query, cell size, what counts as a wide ball, where the wide ones

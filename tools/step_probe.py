@@ -38,4 +38,7 @@ with mvr.Context(0) as ctx:
     print(json.dumps(dict(views=V, n=n, steps=steps, warm=warm, knobs=knobs, lib=os.environ.get("MVR_LIB_VARIANT", "default"), ms_per_step=1e3 * dt / steps, nn_launches=launches, nn_ms=ms,
                           nn_evals=evals, ms_per_launch=ms / max(launches, 1), evals_per_launch=evals / max(launches, 1),
                           n_corr=sum(info["pair_n"]), timing_ms=[t / steps for t in info["timing_ms"]],
-                          **({"pass_ms": [round(v, 4) for v in ctx.pass_log()], "piped": ctx.stat("piped_passes")} if os.environ.get("MVR_PROBE_PASSLOG") else {}))))
+                          **({"pass_ms": [round(v, 4) for v in ctx.pass_log()], "piped": ctx.stat("piped_passes")} if os.environ.get("MVR_PROBE_PASSLOG") else {}),
+                          **({"stage_waves": {k: ctx.stat("stage_" + k) for k in ("staged", "rows", "width", "points")},
+                              "stage_waves_fwd_rev": [[ctx.stat("stage_raw_%d" % (o + k)) for k in (1, 2, 3, 4)] for o in (0, 8)]} if knobs.get("grid_stage_stat") == "1" else {}),
+                          **({"stage_clock": {o: [ctx.stat("stage_raw_%d" % (16 + 8 * i + k)) for k in range(8)] for i, o in enumerate(("fallback", "staged"))}} if knobs.get("grid_stage_stat") == "1" and os.environ.get("MVR_LIB_VARIANT") else {}))))
