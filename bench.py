@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip cold_registration and secondary_sequential (they launch the same kernels on other shapes: a rocprofv3 --stats "
                          "average over the run then covers the ring step's launches only)")
+    ap.add_argument("--no-projection", action="store_true", help="skip projected_scaling (one rank's share per world size, measured on this GPU)")
+    ap.add_argument("--no-stress", action="store_true", help="skip secondary_stress_36x1M (a few passes of the 36-view x 1M-point ring)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed K-step window is repeated this many times after the headline one: min/median/max as extra keys")
     args = ap.parse_args()
@@ -472,6 +474,83 @@ def main():
                         "on the seeded grid search; pipelined once a pass has run without allocating" % (V, Kc)}
         finally:
             cold_ctx.close()
+
+    # What ONE rank of a world of 2 / 4 / 8 would do per pass, measured on this one GPU (tools/rank_share_bench.py): a PROJECTION of
+    # the multi-GPU critical path (the rank's chain, the pass's ncclAllReduce really issued on a communicator of one rank, the
+    # absent peers' rows added behind it, the replicated solve) -- not a scaling run: the fabric and the ranks' skew are not in it
+    if world == 1 and not args.no_secondary and not args.no_projection:
+        import importlib.util as _ilu
+        spec = _ilu.spec_from_file_location("rank_share_bench", os.path.join(ROOT, "tools", "rank_share_bench.py"))
+        rsb = _ilu.module_from_spec(spec); spec.loader.exec_module(rsb)
+        pctx = mvr.Context(local_rank)
+        try:
+            pctx.tune(nn_mode=args.nn_mode)
+            for v in range(V):
+                pctx.upload(V + v, scans[v])
+            try:
+                pctx.comm_init(mvr.comm_unique_id(), 0, 1)
+                prccl = list(pctx.comm_info())
+            except Exception as e:
+                prccl = "no communicator (%s): the projection has no collective in it" % e
+            posed_p, raw_p = list(range(V)), [V + v for v in range(V)]
+            poses_c, _ = pctx.ring_run_sharded(posed_p, raw_p, reg.edges, [p.copy() for p in poses0], args.max_dist, origin, steps=40)
+            proj = rsb.project(mvr, pctx, V, reg.edges, posed_p, raw_p, poses_c, origin, args.max_dist, [1, 2, 4, 8], max(args.steps, 10), 6)
+            out["projected_scaling"] = {
+                "is": "a PROJECTION measured on one GPU, not a multi-GPU run: per world size the slowest rank's ms per pass when this context plays "
+                      "each rank in turn (mvr_ctx_project: its share of the queries by mvr_ring_segments, the all-reduce issued on a one-rank "
+                      "communicator, the peers' rows added behind it, the replicated solve); passes continue from converged poses",
+                "rccl": prccl, "workload": "%d-view ring x %d pts" % (V, N),
+                "ms_per_step": {w: {"unpipelined": v["ms_per_step_pipeline0"], "pipelined": v["ms_per_step_pipeline1"]} for w, v in proj.items()},
+                "rank0_timing_ms_unpipelined": {w: v["ranks"][0]["timing_ms_pipeline0"] for w, v in proj.items()},
+                "note": "unpipelined is what a world of more than one rank runs today (a pass with a multi-rank collective is not queued "
+                        "ahead of its poses: ADVICE r3); pipelined is what lifting that rule would give; timing = {enqueue, wait for the GPU, host solve}"}
+        finally:
+            pctx.close()
+
+    # BASELINE configs[4]'s shape (36 views x 1M points: the working set is far beyond the caches) as a short leg of the default line,
+    # so that the driver's record carries a number for it: a few timed passes on one GPU and the roofline fraction of the walk launches
+    if world == 1 and not args.no_secondary and not args.no_stress and V == 12 and N == 200000:
+        Vs, Ns_ = 36, 1000000
+        sctx = mvr.Context(local_rank)
+        try:
+            sctx.tune(nn_mode=args.nn_mode)
+            sps = mvr.synth_params(Vs, 5)
+            pivs, axs = mvr.synth_prior(sps)
+            for v in range(Vs):
+                sctx.upload(Vs + v, mvr.synth_view(sps, v, Ns_))
+            sposes0 = [np.eye(4)] + [mvr.axis_rotation(pivs, axs, mvr.turntable_angle(v, Vs)) for v in range(1, Vs)]
+            sedges = [(v, (v + 1) % Vs) for v in range(Vs)]
+            sposed, sraw = list(range(Vs)), [Vs + v for v in range(Vs)]
+            sorigin = np.array(sps.pivot)
+            sctx.ring_step(sposed, sraw, sedges, sposes0, args.max_dist, sorigin, fma=bool(args.fma), steps=3)      # orderings, grids, seeds
+            sctx.sync()
+            Ks = 4
+            ts0 = time.perf_counter()
+            _, sinfo = sctx.ring_step(sposed, sraw, sedges, sposes0, args.max_dist, sorigin, fma=bool(args.fma), steps=Ks)
+            sctx.sync()
+            sdt = time.perf_counter() - ts0
+            sctx.tune(pair_streams=1, pair_groups=1)
+            sctx.ring_step(sposed, sraw, sedges, sposes0, args.max_dist, sorigin, fma=bool(args.fma), steps=2); sctx.sync()
+            sctx.prof_reset(); sctx.prof_enable(1)
+            _, sinfo2 = sctx.ring_step(sposed, sraw, sedges, sposes0, args.max_dist, sorigin, fma=bool(args.fma), steps=Ks)
+            sctx.sync(); sctx.prof_enable(False)
+            gl2, gms2, gev2 = sctx.prof_get(mvr.K_NN_GRID)
+            ncs = float(sum(sinfo2["pair_n"]))
+            sfwd, srev = Vs * (12.0 * Ns_ + 12.0 * Ns_ + 8.0 * Ns_), Vs * (16.0 * (ncs / Vs) + 16.0 * Ns_)
+            stress = {"workload": "%d-view ring x %d pts, 1 GPU (BASELINE configs[4]'s shape)" % (Vs, Ns_), "steps": Ks,
+                      "ms_per_step": 1e3 * sdt / Ks, "value": Vs * Ns_ * Ks / sdt, "unit": "correspondences/s",
+                      "accepted_correspondences": float(sum(sinfo["pair_n"])), "timing_ms": [t / Ks for t in sinfo["timing_ms"]]}
+            if gl2:
+                lps = gl2 / float(Ks)
+                stress["roofline"] = {"kernel": "nn_grid_kernel (walk launches, forward + reverse)", "bound": "hbm", "launches_per_step": lps,
+                                      "avg_launch_ms": gms2 / gl2, "algorithmic_bytes_per_launch": (sfwd + srev) / lps,
+                                      "achieved": (sfwd + srev) / lps / (gms2 / gl2 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": (sfwd + srev) / lps / (gms2 / gl2 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                      "traffic": traffic_of("nn_grid_traffic_36x1M.json", "mvr_grid.hip")[0],
+                                      "measured": "%d profiled steps (HIP events per launch, one stream) after the timed ones" % Ks}
+            out["secondary_stress_36x1M"] = stress
+        finally:
+            sctx.close()
 
     # BASELINE configs[2] beside the headline: the SEQUENTIAL mode (Registrator::registrationICP, registrator.cpp:526-588:
     # views 1, V-1, 2, ... each aligned to the growing merged target), device-resident, same scans -- ms per align

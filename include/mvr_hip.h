@@ -377,6 +377,13 @@ int  mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *pos
 int  mvr_ring_rows_sharded(mvr_ctx *ctx, int rank, int world, int n_views, const int *posed_slots, const int *raw_slots, int ne,
                            const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                            const double *poses, double *rows);
+/* PROJECTION of one rank's share on ONE GPU (measurement aid, tools/rank_share_bench.py; no reference counterpart): after
+ * mvr_ctx_project(ctx, world, rank, peer_rows, ne) mvr_ring_run_sharded plans and runs as `rank` of `world` -- its share of the
+ * queries of registrator.cpp:640-651's edges, the collective of the context's communicator (a world of one) really issued --
+ * and adds peer_rows ([ne][32], what the absent ranks would contribute: the sum of their mvr_ring_rows_sharded tables at the
+ * poses the run starts from) to the table behind the all-reduce, so that the solve sees a whole table.  What it times is a
+ * rank's critical path (its chain, the collective's launch, the replicated solve), NOT the fabric.  world <= 1: off. */
+int  mvr_ctx_project(mvr_ctx *ctx, int world, int rank, const double *peer_rows, int ne);
 /* (b) ONE process, all GPUs: n_dev contexts (device_ids NULL: 0 .. n_dev-1) + ncclCommInitAll;
  *     mvr_world_ring_run drives one host thread per device through mvr_ring_run_sharded and checks that every rank
  *     arrived at bit-identical poses.  mvr_world_upload puts a cloud into the same slot of every rank. */

@@ -177,6 +177,7 @@ SIGNATURES = {
     "mvr_ring_run_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                        C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
                                        C.POINTER(C.c_int), _dp, _dp]),
+    "mvr_ctx_project": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
     "mvr_ring_rows_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mvr_world_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)]),
@@ -587,6 +588,15 @@ class Context:
         """ncclCommInitRank on this context's device (collective: every rank calls it with rank 0's unique id)."""
         assert len(unique_id) == 128
         _chk(_lib.mvr_ctx_comm_init(self._h, unique_id, int(rank), int(world)), self._h)
+
+    def project(self, world, rank=0, peer_rows=None):
+        """mvr_ctx_project: ring_run_sharded then runs as `rank` of `world` on this one GPU, the absent peers' rows added behind
+        the all-reduce (peer_rows: (ne, 32) float64); world <= 1 switches it off"""
+        if world <= 1:
+            _chk(_lib.mvr_ctx_project(self._h, 0, 0, None, 0), self._h)
+            return
+        rows = np.ascontiguousarray(peer_rows, np.float64)
+        _chk(_lib.mvr_ctx_project(self._h, int(world), int(rank), _p(rows, C.c_double), rows.shape[0]), self._h)
 
     def comm_destroy(self):
         _chk(_lib.mvr_ctx_comm_destroy(self._h), self._h)

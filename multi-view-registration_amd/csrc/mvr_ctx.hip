@@ -443,6 +443,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
                   c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->stage_stat) (void)hipFree(c->stage_stat);
+  if (c->proj_rows) (void)hipFree(c->proj_rows);
   if (c->d_parts) (void)hipFree(c->d_parts);
   if (c->h_parts) (void)hipHostFree(c->h_parts);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }

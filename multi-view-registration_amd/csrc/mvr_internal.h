@@ -314,6 +314,11 @@ struct Ctx {
   void *comm = nullptr; bool comm_owned = false; int comm_rank = 0, comm_world = 1;
   void **comm_lender = nullptr;                       // a world's communicator is lent: where the world keeps it (cleared when it is aborted here)
   bool comm_broken = false;                           // the communicator was aborted (a peer failed or never arrived): the multi-GPU entry points refuse until a new one is set
+  // PROJECTION of a rank's share on one GPU (mvr_ctx_project; tools/rank_share_bench.py): mvr_ring_run_sharded then plans as
+  // rank project_rank of project_world whatever the communicator says (a world of one: the collective is really issued, its
+  // peers are not there), and the rows the absent peers would have contributed are added to the table behind the all-reduce
+  int project_world = 0, project_rank = 0;
+  double *proj_rows = nullptr; size_t proj_rows_cap = 0, proj_rows_n = 0;
   int wait_timeout_ms = 60000;                        // how long a rank waits for a pass that contains a collective before it declares its peers lost
   // failure injection (tests; mvr_ctx_tune): the dist_pass-th sharded pass / iteration since the knob was set
   long long dist_pass = 0, inject_fail_at = -1, inject_stall_at = -1;
@@ -636,6 +641,7 @@ struct GlueBatch {
 int launch_flag_matched_batch(Ctx *c, const GlueBatch &b, int n_pairs);
 int launch_compact_flags_batch(Ctx *c, const GlueBatch &b, int n_pairs);      // flags -> ordered list / slot / count, 3 launches for all pairs
 int launch_accept_moments2_batch(Ctx *c, const GlueBatch &b, int n_pairs);
+int launch_add_f64(Ctx *c, double *dst, const double *src, size_t n);      // dst[i] += src[i] (one small launch)
 int reduce_blocks_for(const Ctx *c, size_t n);
 
 // the same flags compacted (ordered) into list[] with count and the inverse slot[] (sorted position -> list position)

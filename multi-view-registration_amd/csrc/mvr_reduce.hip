@@ -909,4 +909,19 @@ int launch_fitness(Ctx *c, const nnkey_t *keys, size_t n, double max_range, doub
   return MVR_OK;
 }
 
+namespace {
+__global__ void add_f64_kernel(double *__restrict__ dst, const double *__restrict__ src, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+}  // namespace
+int launch_add_f64(Ctx *c, double *dst, const double *src, size_t n)
+{
+  if (n == 0) return MVR_OK;
+  hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dst, src, n);
+  MVR_HIP_TRY(c, hipGetLastError());
+  return MVR_OK;
+}
+
 }  // namespace mvr

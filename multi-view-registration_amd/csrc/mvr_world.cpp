@@ -373,6 +373,21 @@ bool ring_args_ok(int n_views, const int *posed_slots, const int *raw_slots, int
 }
 }  // namespace
 
+API int mvr_ctx_project(mvr_ctx *ctx, int world, int rank, const double *peer_rows, int ne)
+{
+  if (!ctx) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  if (world <= 1) { c->project_world = 0; c->project_rank = 0; c->proj_rows_n = 0; return MVR_OK; }
+  if (rank < 0 || rank >= world || ne < 0 || (ne && !peer_rows)) return MVR_E_ARG;
+  MVR_HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = (size_t)ne * 32;
+  if (int rc = ensure(c, c->proj_rows, c->proj_rows_cap, std::max(n, (size_t)32))) return rc;
+  MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (n) MVR_HIP_TRY(c, hipMemcpy(c->proj_rows, peer_rows, n * sizeof(double), hipMemcpyHostToDevice));
+  c->proj_rows_n = n; c->project_world = world; c->project_rank = rank;
+  return MVR_OK;
+}
+
 API int mvr_ring_rows_sharded(mvr_ctx *ctx, int rank, int world, int n_views, const int *posed_slots, const int *raw_slots, int ne,
                               const int *edge_src, const int *edge_tgt, double max_dist, int reciprocal, int fma, const double origin[3],
                               const double *poses, double *rows)
@@ -425,6 +440,8 @@ struct RankRun {
       MVR_HIP_TRY(c, hipMemcpyAsync(c->dist_table + (size_t)r.ne * 32 + 1 + (size_t)(r.rank % 31), flag + 1, sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
     if (int rc = comm_allreduce(c, c->dist_table, table_n, kReduceSumF64)) return rc;
+    // (projection of one rank's share, mvr_ctx_project: what the absent peers would have added)
+    if (c->project_world > 1 && c->proj_rows_n == (size_t)r.ne * 32) { if (int rc = launch_add_f64(c, c->dist_table, c->proj_rows, c->proj_rows_n)) return rc; }
     MVR_HIP_TRY(c, hipMemcpyAsync(c->h_table, c->dist_table, table_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return MVR_OK;
   }
@@ -455,7 +472,11 @@ API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *
   Ctx *c = CTX(ctx);
   MVR_HIP_TRY(c, hipSetDevice(c->device));
   if (c->comm_broken) return set_error(c, MVR_E_RCCL, "the communicator of this context was aborted");
-  const int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  int world = c->comm ? c->comm_world : 1, rank = c->comm ? c->comm_rank : 0;
+  if (c->project_world > 1) {      // a projection: this context plays ONE rank of a larger world (the communicator, if any, stays what it is)
+    if (world != 1) return set_error(c, MVR_E_ARG, "mvr_ctx_project needs a context that is a world of one");
+    world = c->project_world; rank = c->project_rank;
+  }
   Rccl &r = rccl();
   if (c->comm && !r.lib) return set_error(c, MVR_E_RCCL, r.error.c_str());
   // everything that can fail for local reasons and is known up front happens BEFORE the first collective: the plan,
