@@ -305,6 +305,19 @@ def main():
         except Exception:
             return None, "no profiles/%s" % fname
 
+    def traffic_of_other(kernel_name):
+        """the step's other kernels (posing, tail launch, filter + sums) from the same counter passes: profiles/nn_grid_traffic.json
+        ["other_kernels"], reported while the source file each was measured on is unchanged"""
+        import hashlib
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "nn_grid_traffic.json")))["other_kernels"][kernel_name]
+            now = hashlib.sha256(open(os.path.join(ROOT, g.PKG, "csrc", rec["source_file"]), "rb").read()).hexdigest()
+            if now != rec["source_sha256"]:
+                return None, "profiles/nn_grid_traffic.json is stale for %s (measured on another version of %s)" % (kernel_name, rec["source_file"])
+            return rec["hbm_bytes_per_launch"], "profiles/nn_grid_traffic.json other_kernels[%s] (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)" % kernel_name
+        except Exception:
+            return None, "no counter pass for %s in profiles/nn_grid_traffic.json" % kernel_name
+
     def hbm_roofline(kernel, launches, ms, evals, alg_bytes_per_launch, traffic, extra=None):
         """the roof that binds a search over a few candidates per query: SURVEY 8(d)'s compulsory bytes per launch against
         the HBM peak (intensity ~3 flop/B, far left of the 19.7 flop/B ridge); the executed-flop fraction rides along"""
@@ -414,7 +427,7 @@ def main():
         if wl_:
             out["roofline_stragglers"] = nn_roofline("nn_grid_tail_kernel (wide bounded queries, a wave each, and the listed 64-query sets, a block "
                                                      "each over the grid, in one launch; nn_grid_wide_kernel alone for the reverse pass)",
-                                                     wl_, wms, wev, (None, "not measured"))
+                                                     wl_, wms, wev, traffic_of_other("nn_grid_tail_kernel"))
         if cl_:
             out["roofline_culled"] = nn_roofline(kname, cl_, cms, cev, ktraffic, {"measured": "the culled launches among the same steps (none once every query has a bound)"})
     elif iso and iso["nn"][0]:
@@ -442,9 +455,12 @@ def main():
             "kernel": "pass1 + moments2 reductions (K5/K8)", "bound": "hbm",
             "achieved": rd_bytes / (rd_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": rd_bytes / (rd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "launches": rd_launches,
-            "avg_launch_ms": rd_ms / rd_launches, "traffic": None,
-            "note": "bytes are MODELLED (the launchers' algorithmic byte counts), not counters; launch-latency bound at "
-                    "200k points per scan (4 MB per launch); one-stream pass",
+            "avg_launch_ms": rd_ms / rd_launches, "traffic": traffic_of_other("accept_moments2_batch_kernel")[0],
+            "traffic_source": traffic_of_other("accept_moments2_batch_kernel")[1],
+            "traffic_refresh_sorted_kernel": traffic_of_other("refresh_sorted_kernel")[0],
+            "note": "`achieved` prices the launchers' MODELLED algorithmic bytes over the family's launches (filter + sums and its final launch); "
+                    "`traffic` is the counter figure of the filter + sums launch (accept_moments2_batch_kernel) alone; launch-latency bound at "
+                    "200k points per scan; one-stream pass",
         }
     out["pcie"] = {"h2d_s": h2d, "h2d_bytes": V * N * 16}
 

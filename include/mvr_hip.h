@@ -486,6 +486,8 @@ int  mvr_ctx_pass_log(mvr_ctx *ctx, double *ms, int cap, int *n);
  * enqueued ahead of their poses, see "pipeline"), "fused_passes" (fused pair batches run so far), "blocking_events"
  * (times the library waited for its stream or re-allocated a buffer: a pass without any is in steady state) */
 int  mvr_ctx_stat(mvr_ctx *ctx, const char *key, double *value);
+/* diagnostics: the ordering of the cloud in `slot` (sorted position -> original index); *n = its length (0: none yet) */
+int  mvr_debug_order(mvr_ctx *ctx, int slot, uint32_t *perm, size_t cap, size_t *n);
 /* diagnostics of the culled kernel: {pair evaluations of the last launch,
  * running total, max tiles processed by one wave, max tiles tested by one wave} */
 int  mvr_debug_counters(mvr_ctx *ctx, uint64_t out[4], int reset);

@@ -178,6 +178,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _fp, _dp, _dp,
                                        C.POINTER(C.c_int), _dp, _dp]),
     "mvr_ctx_project": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
+    "mvr_debug_order": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mvr_ring_rows_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.c_double, C.c_int, C.c_int, _dp, _dp, _dp]),
     "mvr_world_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int)]),
@@ -597,6 +598,16 @@ class Context:
             return
         rows = np.ascontiguousarray(peer_rows, np.float64)
         _chk(_lib.mvr_ctx_project(self._h, int(world), int(rank), _p(rows, C.c_double), rows.shape[0]), self._h)
+
+    def debug_order(self, slot):
+        """diagnostics: the ordering of the cloud in `slot` (sorted position -> original index), or None while it has none"""
+        n = C.c_size_t()
+        _chk(_lib.mvr_debug_order(self._h, int(slot), None, 0, C.byref(n)), self._h)
+        if n.value == 0:
+            return None
+        buf = np.zeros(n.value, np.uint32)
+        _chk(_lib.mvr_debug_order(self._h, int(slot), buf.ctypes.data, n.value, C.byref(n)), self._h)
+        return buf
 
     def comm_destroy(self):
         _chk(_lib.mvr_ctx_comm_destroy(self._h), self._h)

@@ -387,6 +387,8 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PIPELINE")) c->pipeline = std::atoi(m) != 0;      // 0: no pass is enqueued ahead of its poses
+  if (const char *m = std::getenv("MVR_GRID_INDEX")) c->grid_index = std::max(0, std::min(2, std::atoi(m)));      // 0 dense cell starts, 1 compact, 2 by size (default)
+  if (const char *m = std::getenv("MVR_GRID_STAGE")) c->grid_stage = std::max(0, std::min(2, std::atoi(m)));      // the staged walk: 0 off, 1 forward launches (default), 2 all
   if (const char *m = std::getenv("MVR_POSED_REFRESH")) c->posed_refresh = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PAIR_GROUPS")) c->pair_groups = std::max(1, std::min(8, std::atoi(m)));
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
@@ -444,6 +446,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->stage_stat) (void)hipFree(c->stage_stat);
   if (c->proj_rows) (void)hipFree(c->proj_rows);
+  if (c->oscratch) (void)hipFree(c->oscratch);
   if (c->d_parts) (void)hipFree(c->d_parts);
   if (c->h_parts) (void)hipHostFree(c->h_parts);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
@@ -519,8 +522,11 @@ API int mvr_cloud_upload(mvr_ctx *ctx, int slot, const float *xyz, size_t n, siz
       (void)hipFree(tmp);
       if (rc) return rc;
     }
-    // the caller keeps ownership of xyz and may change it right after return
-    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the caller keeps ownership of xyz and may change it right after return: the upload waits for its copy anyway -- and
+    // brings the cloud's bounding box back with it (two small launches behind the copy): the grid build of a registration's
+    // first pass then starts without a round trip of its own (0.4 ms of a host-bound pass)
+    if (c->nn_mode != 0 && n >= 4 && cloud_bbox(c, cl.pts, n, cl.bbox) == MVR_OK) cl.bbox_set = cl.set_id;
+    else MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   cl.n = n;
   cl.canonical = true;            // these are the point set's canonical coordinates (the grid search's frame of reference)
@@ -2004,7 +2010,7 @@ static bool prepare_parts_search(Ctx *c, const Cloud &posed_src, Cloud &cur, Clo
     const GridPart &gp = tgt.parts[k];
     const CellGrid &g = *gp.grid;
     PartDesc &d = c->h_parts[k];
-    d.gts = tgt.gsorted + gp.base; d.start = g.start; d.dt = g.dt;
+    d.gts = tgt.gsorted + gp.base; d.start = g.start; d.dir = g.dir; d.recs = g.recs; d.dt_shift = g.dt_shift; for (int k3 = 0; k3 < 3; ++k3) d.dtdim[k3] = g.dtdim[k3]; d.dt = g.dt;
     for (int j = 0; j < 3; ++j) { d.lo[j] = g.lo[j]; d.dim[j] = g.dim[j]; }
     d.inv_h = g.inv_h; d.h = g.h; d.dt_max = g.dt_steps; d.base = (uint32_t)gp.base; d.n = (uint32_t)gp.n;
     // canonical -> posed: the f64 pose, then (kind 2) the align's f32 matrix
@@ -2556,7 +2562,9 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
     if (c->stage_stat) { MVR_HIP_TRY(c, hipStreamSynchronize(c->stream)); MVR_HIP_TRY(c, hipMemset(c->stage_stat, 0, 64 * 64 * sizeof(unsigned long long))); }
     if (!value && c->stage_stat) { (void)hipFree(c->stage_stat); c->stage_stat = nullptr; }
   }
+  else if (!std::strcmp(key, "order_batch")) c->order_batch = value != 0;
   else if (!std::strcmp(key, "grid_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->grid_lanes = value; }
+  else if (!std::strcmp(key, "grid_index")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_index = value; }
   else if (!std::strcmp(key, "grid_cell_points")) { if (value < 1) return MVR_E_ARG; c->grid_cell_points = value; }
   else if (!std::strcmp(key, "pipeline")) c->pipeline = value != 0;
   else if (!std::strcmp(key, "pipeline_multi_rank")) c->pipeline_multi_rank = value != 0;
@@ -2569,6 +2577,19 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "inplace_ratio")) c->inplace_ratio = value;
   else if (!std::strcmp(key, "pair_streams")) c->pair_streams = value < 1 ? 1 : (value > 16 ? 16 : value);
   else return MVR_E_ARG;
+  return MVR_OK;
+}
+
+API int mvr_debug_order(mvr_ctx *ctx, int slot, uint32_t *perm, size_t cap, size_t *n)
+{
+  if (!ctx || !slot_ok(slot) || !n) return MVR_E_ARG;
+  Ctx *c = CTX(ctx);
+  const Cloud &cl = c->slots[slot];
+  *n = cl.order ? cl.order->n : 0;
+  if (cl.order && perm && cap >= cl.order->n) {
+    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MVR_HIP_TRY(c, hipMemcpy(perm, cl.order->perm, cl.order->n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
   return MVR_OK;
 }
 

@@ -58,6 +58,7 @@ void OrderPool::close()
 
 Order::~Order()
 {
+  if (arena) return;                    // (perm / inv live in a block shared by a batch of orderings: the last owner frees it)
   if (pool) { pool->give(perm, perm_bytes); pool->give(inv, inv_bytes); }
   else { if (perm) (void)hipFree(perm); if (inv) (void)hipFree(inv); }
 }
@@ -556,6 +557,165 @@ bool extend_point_set(Ctx *c, Cloud &dst, size_t old_n, const Cloud &src)
   return true;
 }
 
+// ---- the orderings of SEVERAL point sets in one go (a registration's first pass needs one per scan: twelve times bounding box ->
+// codes -> radix sort -> inverse was ~180 launches and 24 allocations, 1.2 ms of a host-bound 3.7 ms pass).  The clouds' codes
+// are sorted TOGETHER under a composite key, (cloud << 30) | 30-bit Hilbert code, on the bits [kSortLoBit, 30 + bits of the cloud
+// number): the radix sort is stable, so inside a cloud the order is exactly the one the per-cloud sort gives (same bits compared,
+// ties in input order) -- the permutations are bit-identical to the one-at-a-time build.
+namespace {
+struct OrderBatchArgs { const float4 *pts[kBatchClouds]; unsigned long long n[kBatchClouds], off[kBatchClouds]; uint32_t *perm[kBatchClouds], *inv[kBatchClouds]; };
+__global__ void bbox_many_kernel(OrderBatchArgs a, float *__restrict__ part /* [cloud][64 blocks][6] */)
+{
+  const int cl = blockIdx.y;
+  const float4 *p = a.pts[cl];
+  const size_t cnt = (size_t)a.n[cl];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    lo[0] = fminf(lo[0], v.x); lo[1] = fminf(lo[1], v.y); lo[2] = fminf(lo[2], v.z);
+    hi[0] = fmaxf(hi[0], v.x); hi[1] = fmaxf(hi[1], v.y); hi[2] = fmaxf(hi[2], v.z);
+  }
+  __shared__ float sh[4][6];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; ++k) { sh[threadIdx.x >> 6][k] = lo[k]; sh[threadIdx.x >> 6][3 + k] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) for (int k = 0; k < 3; ++k) { sh[0][k] = fminf(sh[0][k], sh[w][k]); sh[0][3 + k] = fmaxf(sh[0][3 + k], sh[w][3 + k]); }
+    for (int k = 0; k < 6; ++k) part[((size_t)cl * gridDim.x + blockIdx.x) * 6 + k] = sh[0][k];
+  }
+}
+// codes of all clouds: the bounding box of a cloud from its 64 partial rows (every block folds them itself: 384 floats from the L2),
+// then exactly morton_kernel's arithmetic
+__global__ void hilbert_many_kernel(OrderBatchArgs a, const float *__restrict__ part, int part_blocks, unsigned long long *__restrict__ key, uint32_t *__restrict__ idx)
+{
+  const int cl = blockIdx.y;
+  __shared__ float bb[6];
+  if (threadIdx.x < 6) {
+    const bool is_hi = threadIdx.x >= 3;
+    float v = is_hi ? -3.0e38f : 3.0e38f;
+    for (int b = 0; b < part_blocks; ++b) { const float w = part[((size_t)cl * part_blocks + b) * 6 + threadIdx.x]; v = is_hi ? fmaxf(v, w) : fminf(v, w); }
+    bb[threadIdx.x] = v;
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)a.n[cl]) return;
+  const float4 v = a.pts[cl][i];
+  const float c[3] = {v.x, v.y, v.z};
+  uint32_t q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float ext = bb[3 + k] - bb[k];
+    float f = ext > 0.f ? (c[k] - bb[k]) / ext : 0.f;
+    f = fminf(fmaxf(f, 0.f), 1.f);
+    q[k] = (uint32_t)(f * 1023.0f);
+  }
+  uint32_t X[3] = {q[0], q[1], q[2]};
+  for (uint32_t Qb = 1u << 9; Qb > 1; Qb >>= 1) {
+    const uint32_t P = Qb - 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (X[k] & Qb) X[0] ^= P;
+      else { const uint32_t t = (X[0] ^ X[k]) & P; X[0] ^= t; X[k] ^= t; }
+    }
+  }
+  X[1] ^= X[0]; X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Qb = 1u << 9; Qb > 1; Qb >>= 1) if (X[2] & Qb) t ^= Qb - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  const uint32_t code = (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
+  key[(size_t)a.off[cl] + i] = ((unsigned long long)cl << 30) | code;
+  idx[(size_t)a.off[cl] + i] = (uint32_t)i;
+}
+__global__ void finish_many_kernel(OrderBatchArgs a, const uint32_t *__restrict__ sorted_idx)
+{
+  const int cl = blockIdx.y;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (size_t)a.n[cl]) return;
+  const uint32_t o = sorted_idx[(size_t)a.off[cl] + k];
+  a.perm[cl][k] = o;
+  a.inv[cl][o] = (uint32_t)k;
+}
+size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+// clouds that have no ordering yet (and none in the context's cache) get one, all together; the others are left alone.
+// Failure is not fatal: prepare_index builds what is still missing, one by one.
+static int build_orders_batch(Ctx *c, Cloud *const *clouds, int count)
+{
+  std::vector<Cloud *> todo;
+  for (int k = 0; k < count; ++k) {
+    Cloud *cl = clouds[k];
+    if (!cl || cl->n == 0 || cl->n > 0x3FFFFFFFull) continue;
+    if (cl->order && cl->order->n == cl->n) continue;
+    auto it = c->orders.find(cl->set_id);
+    if (it != c->orders.end()) { auto o = it->second.lock(); if (o && o->n == cl->n) continue; }
+    bool dup = false;
+    for (Cloud *t : todo) dup = dup || t->set_id == cl->set_id;
+    if (!dup) todo.push_back(cl);
+  }
+  if (todo.size() < 2 || !c->order_batch) return MVR_OK;
+  MVR_MAY_BLOCK(c, "point sets have no ordering yet");
+  constexpr int kBoxBlocks = 64;
+  for (size_t base = 0; base < todo.size(); base += kBatchClouds) {
+    const int m = (int)std::min<size_t>(kBatchClouds, todo.size() - base);
+    OrderBatchArgs a;
+    size_t total = 0, nmax = 0, arena_bytes = 0;
+    std::vector<size_t> want((size_t)m);
+    for (int k = 0; k < kBatchClouds; ++k) { a.pts[k] = nullptr; a.n[k] = 0; a.off[k] = 0; a.perm[k] = a.inv[k] = nullptr; }
+    for (int k = 0; k < m; ++k) {
+      Cloud *cl = todo[base + (size_t)k];
+      a.pts[k] = cl->pts; a.n[k] = cl->n; a.off[k] = total;
+      total += cl->n; nmax = std::max(nmax, cl->n);
+      want[(size_t)k] = up256(std::max(cl->n, cl->cap) * sizeof(uint32_t));      // sized for the cloud's CAPACITY, as the one-by-one build does
+      arena_bytes += 2 * want[(size_t)k];
+    }
+    if (total > 0x7FFFFFFFull) return MVR_OK;      // (hipCUB takes an int count: such a batch is built one by one)
+    int hi_bit = 30;
+    while ((1 << (hi_bit - 30)) < m) ++hi_bit;
+    size_t cub_bytes = 0;
+    { unsigned long long *zk = nullptr; uint32_t *zv = nullptr;
+      MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, zk, zk, zv, zv, (int)total, kSortLoBit, hi_bit, c->stream)); }
+    const size_t o_part = 0, o_ka = o_part + up256((size_t)m * kBoxBlocks * 6 * sizeof(float)), o_kb = o_ka + up256(total * 8), o_ia = o_kb + up256(total * 8),
+                 o_ib = o_ia + up256(total * 4), o_cub = o_ib + up256(total * 4), need = o_cub + up256(cub_bytes + 256);
+    if (int rc = ensure(c, c->oscratch, c->oscratch_cap, need)) return rc;
+    char *block = nullptr;
+    if (hipMalloc(&block, arena_bytes) != hipSuccess) { (void)hipGetLastError(); return MVR_OK; }
+    std::shared_ptr<char> arena(block, [](char *p) { if (p) (void)hipFree(p); });
+    std::vector<std::shared_ptr<Order> > ords((size_t)m);
+    size_t at = 0;
+    for (int k = 0; k < m; ++k) {
+      auto ord = std::make_shared<Order>();
+      ord->arena = arena; ord->n = todo[base + (size_t)k]->n;
+      ord->perm = reinterpret_cast<uint32_t *>(block + at); at += want[(size_t)k];
+      ord->inv = reinterpret_cast<uint32_t *>(block + at); at += want[(size_t)k];
+      ord->perm_bytes = ord->inv_bytes = want[(size_t)k];
+      a.perm[k] = ord->perm; a.inv[k] = ord->inv;
+      ords[(size_t)k] = ord;
+    }
+    float *part = reinterpret_cast<float *>(c->oscratch + o_part);
+    unsigned long long *ka = reinterpret_cast<unsigned long long *>(c->oscratch + o_ka), *kb = reinterpret_cast<unsigned long long *>(c->oscratch + o_kb);
+    uint32_t *ia = reinterpret_cast<uint32_t *>(c->oscratch + o_ia), *ib = reinterpret_cast<uint32_t *>(c->oscratch + o_ib);
+    ProfScope ps(c, MVR_K_GLUE, 40.0 * (double)total);
+    const unsigned nb = (unsigned)((nmax + 255) / 256);
+    hipLaunchKernelGGL(bbox_many_kernel, dim3(kBoxBlocks, (unsigned)m), dim3(256), 0, c->stream, a, part);
+    hipLaunchKernelGGL(hilbert_many_kernel, dim3(nb, (unsigned)m), dim3(256), 0, c->stream, a, part, kBoxBlocks, ka, ia);
+    size_t cb = cub_bytes;
+    MVR_HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->oscratch + o_cub, cb, ka, kb, ia, ib, (int)total, kSortLoBit, hi_bit, c->stream));
+    hipLaunchKernelGGL(finish_many_kernel, dim3(nb, (unsigned)m), dim3(256), 0, c->stream, a, ib);
+    MVR_HIP_TRY(c, hipGetLastError());
+    for (int k = 0; k < m; ++k) {
+      Cloud *cl = todo[base + (size_t)k];
+      cl->order = ords[(size_t)k];
+      c->orders[cl->set_id] = ords[(size_t)k];
+      for (Cloud &o : c->slots) if (&o != cl && o.set_id == cl->set_id && o.n == cl->n && !o.order) o.order = ords[(size_t)k];      // every resident copy of the set shares it
+      cl->stale_coords();
+    }
+  }
+  for (auto it = c->orders.begin(); it != c->orders.end();) it = it->second.expired() ? c->orders.erase(it) : std::next(it);
+  return MVR_OK;
+}
+
 // ordering (once per point set) and buffers; *stale = the sorted copy / boxes must be refreshed
 static int prepare_index(Ctx *c, Cloud &cl, bool *stale)
 {
@@ -746,6 +906,22 @@ int flush_super_boxes(Ctx *c)
 int refresh_posed_batch(Ctx *c, int count, Cloud *const *dst, Cloud *const *src, const double *T, bool with_pts, char *handled)
 {
   std::vector<Cloud *> todo; std::vector<const float4 *> from, xsrc; std::vector<double> Ts; std::vector<const Mat44d *> Tps;
+  {   // what the loop below would build one by one, together first: the orderings of the sets that have none (from the POSED copies,
+      // see below), then the sources' sorted copies in one refresh launch
+    std::vector<Cloud *> ds, ss;
+    for (int k = 0; k < count; ++k) {
+      Cloud *d = dst[k], *s = src[k];
+      if (!d || !s || d == s || d->n == 0 || d->n != s->n || d->set_id != s->set_id) continue;
+      ds.push_back(d); ss.push_back(s);
+    }
+    if (ds.size() >= 2) {
+      if (int rc = build_orders_batch(c, ds.data(), (int)ds.size())) return rc;
+      // (only the sources whose set HAS its ordering by now: one that has none gets it in the loop below, from its posed copy)
+      std::vector<Cloud *> ready;
+      for (size_t k = 0; k < ss.size(); ++k) if (ds[k]->order && ds[k]->order->n == ds[k]->n && ss[k]->order == ds[k]->order) ready.push_back(ss[k]);
+      if (ready.size() >= 2) { if (int rc = ensure_index_batch(c, ready.data(), (int)ready.size())) return rc; }
+    }
+  }
   for (int k = 0; k < count; ++k) {
     Cloud *d = dst[k], *s = src[k];
     if (handled) handled[k] = 0;
@@ -786,6 +962,7 @@ int ensure_index(Ctx *c, Cloud &cl)
 
 int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
 {
+  if (count >= 2) { if (int rc = build_orders_batch(c, clouds, count)) return rc; }
   std::vector<Cloud *> todo;
   for (int k = 0; k < count; ++k) {
     Cloud *cl = clouds[k];

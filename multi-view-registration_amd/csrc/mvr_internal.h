@@ -38,6 +38,7 @@ struct Order {
   size_t n = 0;
   size_t perm_bytes = 0, inv_bytes = 0;
   std::shared_ptr<OrderPool> pool;
+  std::shared_ptr<char> arena;         // set: perm / inv are carved out of this block, shared with the other orderings of one batched build (freed with the last of them)
   ~Order();
 };
 
@@ -52,6 +53,15 @@ struct CellGrid {
   float h = 1.f, inv_h = 1.f;            // cell edge
   int dim[3] = {1, 1, 1};                // cells per axis; cell id = (z * dim[1] + y) * dim[0] + x
   uint32_t *start = nullptr;             // [cells + 1] first grid position of every cell (points sorted by cell id)
+  // COMPACT form of the same table (round 4; `start` is then null): the cell ids are cut into segments of 32 consecutive ids; an
+  // occupied segment has a record of its 32 starts in recs[], an empty one -- all its cells begin at the same position -- is the
+  // directory entry itself: dir[seg] = slot | 0x80000000 or that position.  A 200k-point scan occupies ~1/20 of its 375k segments:
+  // 1.5 MB of directory + 2.5 MB of records instead of 48 MB of which a walk touched a 128-byte line per row for three entries.
+  uint32_t *dir = nullptr, *recs = nullptr;
+  uint32_t nseg = 0;
+  bool via_compact = false;              // a DENSE table that was built through the compact form and expanded (the default)
+  int dt_shift = 0;                      // the distance map is kept per cube of 2^dt_shift cells per axis (compact form: 1 -- an eighth of the bytes and of the build)
+  int dtdim[3] = {1, 1, 1};              // its dimensions
   uint32_t *gperm = nullptr;             // [n] grid position -> original index
   float4 *graw = nullptr;                // [n] canonical coordinates in grid order, w = bits(original index)
   uint32_t *g2h = nullptr;               // [n] grid position -> position in the set's Hilbert ordering (what the fused pass's keys carry)
@@ -134,6 +144,7 @@ struct Cloud {
   bool fin_known = false; float fin[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::vector<GridPart> parts;         // non-empty: this cloud is exactly the concatenation of these posed scans (see GridPart)
   void forget_pose() { canonical = false; pose_known = false; fin_known = false; pose_stretch = 1.0; grid.reset(); parts.clear(); }
+  float bbox[6] = {0, 0, 0, 0, 0, 0}; uint64_t bbox_set = 0;      // with bbox_set == set_id (and canonical): the bounding box of pts[], taken when the cloud was uploaded (the grid build then needs no round trip for it)
   bool pts_stale = false;              // pts[] were left out by the last (pipelined) pose of this cloud: sorted[] / gsorted[] are current, pts[] are written when the run leaves the pipe
   bool posed_by_table = false;         // ... and the last transform of this cloud did read it (its host-side pose is filled in when the run leaves the pipe)
 };
@@ -224,6 +235,8 @@ struct Ctx {
   void *cub_tmp = nullptr; size_t cub_cap = 0;
   struct PartDesc *d_parts = nullptr, *h_parts = nullptr; size_t parts_cap = 0;      // the part table of a composite target: device copy and pinned staging
   char *scratch = nullptr; size_t scratch_cap = 0;    // temporaries of the grid builds (grows, never shrinks)
+  char *oscratch = nullptr; size_t oscratch_cap = 0;  // temporaries of a batched ordering build (its own buffer: the grid builds use `scratch` on the side stream meanwhile)
+  int order_batch = 1;                                // 1 (default): the orderings a call needs for several point sets are built together (one sort); 0: one set after the other
   hipStream_t side_stream = nullptr;                  // set-up work that may overlap a pass (grid builds)
   hipEvent_t side_after = nullptr;                    // recorded on the main stream before the pass the side stream's work overlaps
   hipEvent_t scratch_event = nullptr; hipStream_t scratch_stream = nullptr;      // the last user of `scratch`
@@ -254,6 +267,7 @@ struct Ctx {
   nnkey_t *brkeys = nullptr; size_t brkeys_cap = 0;
   uint32_t *bwide = nullptr; size_t bwide_cap = 0;       // [sources + targets of all pairs] grid search: ordinals of the wide bounded queries
   int grid_cell_points = 4;                              // points per occupied cell the grid's cell edge aims at (grids built from then on)
+  int grid_index = 2;                                    // a grid's cell-start table (grids built from then on): 2 (default) = DENSE, built through the compact form (all scans sorted at once, distance map per 2 x 2 x 2 cells) and expanded; 1 = COMPACT (segment directory + records of the occupied segments: a tenth of the bytes, walks 8-11 % slower); 0 = dense by the round-3 build (a sort, a scan over all cells and a per-cell distance map per grid)
   // the STAGED walk (mvr_grid.hip): a wave of the one-lane-per-query walk copies the box of its lanes' cells into LDS with a few
   // coalesced loads and every lane walks its own cells there -- the walk is bound by the number of vector memory instructions a
   // wave issues, not by bytes.  0: the plain walk; 1 (default): launches over a scan's own query order (the forward searches); 2: every
@@ -541,6 +555,8 @@ struct GridPair {
   const float4 *gts = nullptr;                // target: posed coordinates in GRID order (w = original index)
   const float4 *ts = nullptr;                 // target in Hilbert order (only to price the seed: the previous match's position)
   const uint32_t *start = nullptr, *g2h = nullptr, *h2g = nullptr, *tinv = nullptr;      // (tinv: original index -> Hilbert position in the searched cloud)
+  const uint32_t *dir = nullptr, *recs = nullptr;      // the compact form of the cell starts (CellGrid): used when dir is set
+  int dt_shift = 0, dtdim[3] = {1, 1, 1};
   const uint8_t *dt = nullptr;
   float lo[3] = {0, 0, 0}, inv_h = 1.f, h = 1.f;
   int dim[3] = {1, 1, 1};
@@ -601,6 +617,7 @@ GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cl
 // ---- a composite target searched part by part (mvr_grid.hip: nn_parts_kernel)
 struct PartDesc {
   const float4 *gts; const uint32_t *start; const uint8_t *dt;
+  const uint32_t *dir, *recs; int dt_shift, dtdim[3];
   float lo[3], inv_h, h, stretch; int dim[3], dt_max;
   double minv[12];
   uint32_t base, n;

@@ -85,6 +85,26 @@ def ring_fixture():
         print("      %-5s pivot-point error (mm): max %.3f mean %.3f" % (name, max(err), np.mean(err)))
 
 
+def ring36_fixture():
+    """BASELINE configs[4]'s shape in small: 36-view turntable ring (10 degrees apart), 768 pts/scan, THREE outer passes of
+    registrationLUM (registrator.cpp:625-664) from the mis-calibrated prior -- the poses, the LUM poses and the per-edge
+    correspondence counts after every pass."""
+    V, N, passes = 36, 768, 3
+    sp = mvr.synth_params(V, 5)
+    scans = [mvr.synth_view(sp, v, N) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses = ref_driver.init_poses(orc, V, piv, ax)
+    out = dict(scans=np.stack(scans), prior_pivot=piv, prior_axis=ax, poses0=np.stack(poses), origin=np.array(sp.pivot))
+    P_all, n_all, poses_all, its_all = [], [], [], []
+    for _ in range(passes):
+        poses, P, corrs, its = ref_driver.lum_pass(orc, scans, poses, 8.0, 16)
+        P_all.append(P); n_all.append([len(c) for c in corrs]); poses_all.append(np.stack(poses)); its_all.append(its)
+    out.update(lum_poses=np.stack(poses_all), lum_P=np.stack(P_all), lum_ncorr=np.array(n_all), lum_its=np.array(its_all))
+    np.savez_compressed(os.path.join(OUT, "ring_36x768.npz"), **out)
+    print("ring36: n_corr per pass", [int(np.sum(n)) for n in n_all], "its", its_all)
+
+
 if __name__ == "__main__":
     pair_fixture()
     ring_fixture()
+    ring36_fixture()

@@ -38,6 +38,77 @@ def test_ring_step_matches_oracle_lum_pass(mvr, ring):
         be.close()
 
 
+def test_golden_ring_36_views_three_passes(mvr):
+    """the committed 36-view fixture (tests/golden/ring_36x768.npz: BASELINE configs[4]'s shape in small, made by the oracle's
+    registrationLUM pass, registrator.cpp:625-664): three outer passes from the prior through mvr_ring_step -- per-edge
+    correspondence counts equal, the LUM poses to 1e-6, the views' poses within 1e-5 / 1e-4 mm after every pass.  A fixture
+    rather than a fresh oracle run: an oracle that drifted together with the product would still be caught."""
+    g = load_golden("ring_36x768.npz")
+    scans, poses = list(g["scans"]), [p.copy() for p in g["poses0"]]
+    V = len(scans)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(V + v, scans[v])
+        for k in range(g["lum_poses"].shape[0]):
+            poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, poses, 8.0, g["origin"])
+            assert [int(n) for n in info["pair_n"]] == list(g["lum_ncorr"][k]), k
+            assert info["lum_iterations"] == int(g["lum_its"][k])
+            assert np.abs(np.asarray(info["lum_pose"]) - g["lum_P"][k]).max() < 1e-6
+            for v in range(V):
+                assert np.abs(poses[v][:3, :3] - g["lum_poses"][k][v][:3, :3]).max() < 1e-5
+                assert np.abs(poses[v][:3, 3] - g["lum_poses"][k][v][:3, 3]).max() < 1e-4
+
+
+def test_golden_sequential_sweeps(mvr):
+    """the committed 12-view fixture's SEQUENTIAL record (two sweeps of registrationICP, registrator.cpp:526-588, by the oracle
+    driver): mvr_seq_run, the native loop, align by align -- views in the reference's order, correspondence counts equal, mean
+    squared distances to 1e-9, every align's transformation and the final poses within 1e-5 / 1e-4 mm."""
+    g = load_golden("ring_12x2048.npz")
+    scans, poses0 = list(g["scans"]), [p.copy() for p in g["poses0"]]
+    V = len(scans)
+    RAW, TARGET, SOURCE, OUT = V, 2 * V, 2 * V + 1, 2 * V + 2
+    with mvr.Context(0) as ctx:
+        for v in range(V):
+            ctx.upload(RAW + v, scans[v])
+        poses, log = ctx.seq_run([RAW + v for v in range(V)], TARGET, SOURCE, OUT, mvr.icp_params(max_dist=8.0, max_iter=1000), poses0, repeat=2)
+    assert [e["view"] for e in log] == list(g["seq_view"])
+    assert [e["n_corr"] for e in log] == list(g["seq_ncorr"])
+    for e, T, mse in zip(log, g["seq_T"], g["seq_mse"]):
+        assert abs(e["mse"] - mse) < 1e-9
+        assert np.abs(e["T"][:3, :3] - T[:3, :3]).max() < 1e-5 and np.abs(e["T"][:3, 3] - T[:3, 3]).max() < 1e-4
+    for v in range(V):
+        assert np.abs(poses[v][:3, :3] - g["seq_poses"][v][:3, :3]).max() < 1e-5
+        assert np.abs(poses[v][:3, 3] - g["seq_poses"][v][:3, 3]).max() < 1e-4
+
+
+def test_batched_orderings_are_the_one_by_one_orderings(mvr):
+    """A registration's first pass builds the orderings of all its scans in ONE composite sort ((scan << 30) | Hilbert code,
+    stable: round 4) -- the permutations must be the ones the one-scan-at-a-time build gives (the sums of a pass are taken in
+    this order: any difference shows in the last bits of a pose), built from the POSED copies either way."""
+    V, N = 12, 9000
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, N + 17 * v) for v in range(V)]          # ragged sizes
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    perms = []
+    for kn in (dict(order_batch=1), dict(order_batch=0)):
+        with mvr.Context(0) as ctx:
+            ctx.tune(**kn)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], 4.0, np.array(sp.pivot))
+            perms.append([ctx.debug_order(v) for v in range(V)])
+            raw = [ctx.debug_order(V + v) for v in range(V)]
+            for v in range(V):                      # a scan and its posed copy share one ordering
+                assert np.array_equal(raw[v], perms[-1][v])
+    for v in range(V):
+        assert perms[0][v] is not None and len(perms[0][v]) == len(scans[v])
+        assert np.array_equal(np.sort(perms[0][v]), np.arange(len(scans[v]), dtype=np.uint32))
+        assert np.array_equal(perms[0][v], perms[1][v]), v
+
+
 def test_one_call_step_equals_three_call_step(mvr, ring):
     """mvr_ring_step (posing, searches, reductions, table copy and host solve in one native call) walks exactly the
     poses of the step driven from Python through mvr_cloud_transform_batch / mvr_pair_moments2_batch /
@@ -169,6 +240,10 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
     # the staged walk (round 4): off, for the reverse launches too, with tiny cells (more rows in a wave's box than its table holds),
     # with huge cells and wide balls walked in-thread (more points than a wave's LDS holds: the rows behind are walked from global memory)
     dict(grid_stage=0), dict(grid_stage=2), dict(grid_stage=2, grid_cell_points=1), dict(grid_stage=2, grid_cell_points=40, grid_light_rows=64),
+    dict(order_batch=0), dict(order_batch=0, grid_stage=0),
+    # the compact cell-start tables (round 4): forced for these small grids, with the staged walk everywhere, with tiny / huge cells, dense forced
+    dict(grid_index=1), dict(grid_index=1, grid_stage=2), dict(grid_index=1, grid_cell_points=1), dict(grid_index=1, grid_cell_points=40, grid_light_rows=64, grid_probe=0),
+    dict(grid_index=1, grid_stage=0, grid_lanes=4), dict(grid_index=1, grid_sets=2, grid_light_rows=1, grid_cluster=1), dict(grid_index=0),
     dict(grid_stage=2, grid_light_rows=64, grid_probe=0), dict(grid_stage=1, grid_cell_points=2, grid_light_rows=64, grid_probe=0), dict(grid_stage=2, grid_cell_points=12, grid_wide=0),
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):

@@ -30,6 +30,32 @@ def per_dispatch(counter):
     return vals[2 * max(WARM, 1):]            # forward + reverse per step; the warm-up steps come first
 
 
+def other_kernels():
+    """the step's other kernels from the same two passes: HBM-side bytes per launch (FETCH_SIZE doubled + WRITE_SIZE), mean over
+    the last STEPS launches of each (one launch of each per step with MVR_PAIR_GROUPS=1 and up to 12 pairs)"""
+    names = {"refresh_sorted_kernel": "mvr_index.hip", "accept_moments2_batch_kernel": "mvr_reduce.hip", "nn_grid_tail_kernel": "mvr_grid.hip",
+             "nn_grid_wide_kernel": "mvr_grid.hip", "count_flags": "mvr_reduce.hip", "compact_flags": "mvr_reduce.hip", "moments2_final": "mvr_reduce.hip"}
+    acc = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in glob.glob(os.path.join(d, counter, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != counter: continue
+                for nm in names:
+                    if nm in r["Kernel_Name"]:
+                        acc.setdefault(nm, {}).setdefault(counter, {}).setdefault(int(r["Dispatch_Id"]), 0.0)
+                        acc[nm][counter][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    out = {}
+    for nm, c in acc.items():
+        f = [c.get("FETCH_SIZE", {})[k] for k in sorted(c.get("FETCH_SIZE", {}))][-STEPS:]
+        w = [c.get("WRITE_SIZE", {})[k] for k in sorted(c.get("WRITE_SIZE", {}))][-STEPS:]
+        if not f or not w: continue
+        fk, wk = sum(f) / len(f), sum(w) / len(w)
+        src_ = os.path.join(ROOT, "multi-view-registration_amd", "csrc", names[nm])
+        out[nm] = {"hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024, "fetch_size_kb": fk, "write_size_kb": wk, "launches_averaged": len(f),
+                   "source_file": names[nm], "source_sha256": hashlib.sha256(open(src_, "rb").read()).hexdigest()}
+    return out
+
+
 fetch, write = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
 assert len(fetch) == 2 * STEPS and len(write) == 2 * STEPS, (len(fetch), len(write))
 kb = lambda v: sum(v) / len(v)
@@ -67,6 +93,9 @@ out = {
     "algorithmic_bytes_forward": alg_fwd, "algorithmic_bytes_reverse": alg_rev, "algorithmic_bytes_per_launch": 0.5 * (alg_fwd + alg_rev),
     "ratio_to_algorithmic": 0.5 * (fwd + rev) / (0.5 * (alg_fwd + alg_rev)),
     "kernel_source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(),
+    "memory_side_note": ("at 12 x 200k the working set (~100 MB of posed points and index lines) sits in the 256 MB Infinity Cache: these counters tally "
+                         "L2 <-> fabric requests, MALL hits included -- they are an upper bound of the HBM bytes there; at 36 x 1M (1.7 GB) they are HBM traffic"),
+    "other_kernels": (other_kernels() if GRID else None),
     "probe": probe,
 }
 print(json.dumps(out, indent=1))
