@@ -143,9 +143,29 @@ void cloud_free(Cloud &cl)
 
 // dst = T * src was just computed by the f64 transform kernel: remember the pose when src holds its set's canonical
 // coordinates and T is a rigid motion (what the grid search needs to walk the set's pose-invariant grid)
+// an upper bound (mm) of | Tnew p - Told p | over the points p of the box [lo, hi] (bbox = lo xyz, hi xyz): with c the box's centre,
+// r its half diagonal and D = Anew - Aold: | D c + (tnew - told) | + |D|_F r.  Affine poses only (else < 0).
+double pose_motion_bound(const double *Told, const double *Tnew, const float bbox[6])
+{
+  for (const double *T : {Told, Tnew}) if (T[3] != 0.0 || T[7] != 0.0 || T[11] != 0.0 || T[15] != 1.0) return -1.0;
+  double cb[3], r2 = 0.0, f2 = 0.0, v[3];
+  for (int k = 0; k < 3; ++k) { cb[k] = 0.5 * ((double)bbox[k] + (double)bbox[3 + k]); const double hd = 0.5 * ((double)bbox[3 + k] - (double)bbox[k]); r2 += hd * hd; }
+  for (int i = 0; i < 3; ++i) {
+    v[i] = Tnew[12 + i] - Told[12 + i];
+    for (int k = 0; k < 3; ++k) { const double d = Tnew[4 * k + i] - Told[4 * k + i]; v[i] += d * cb[k]; f2 += d * d; }
+  }
+  const double b = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + std::sqrt(f2) * std::sqrt(r2);
+  return std::isfinite(b) ? b * (1.0 + 1e-9) + 1e-12 : -1.0;
+}
+
 void note_pose(Cloud &dst, const Cloud &src, bool src_canonical, const double T[16])
 {
   dst.canonical = false; dst.pose_known = false; dst.fin_known = false; dst.parts.clear();
+  // how far the copy moves with this pose (seed_delta): from the pose it had last, if that was a pose of the same point set
+  const bool chain = src_canonical && &dst != &src && dst.last_pose_set == src.set_id && dst.last_pose_set != 0 && dst.moved >= 0.0 && src.bbox_set == src.set_id;
+  const double step = chain ? pose_motion_bound(dst.last_pose, T, src.bbox) : -1.0;
+  dst.moved = (chain && step >= 0.0) ? dst.moved + step : -1.0;
+  dst.last_pose_set = 0;
   if (!src_canonical || &dst == &src) return;
   if (T[3] != 0.0 || T[7] != 0.0 || T[11] != 0.0 || T[15] != 1.0) return;
   // NEARLY rigid: the poses of a registration are products with PCL-style float 4x4s (lum.getTransformation is an
@@ -167,6 +187,7 @@ void note_pose(Cloud &dst, const Cloud &src, bool src_canonical, const double T[
   dst.pose_stretch = 1.0 / std::sqrt(1.0 - e);
   dst.pose_known = true;
   std::memcpy(dst.pose, T, 16 * sizeof(double));
+  std::memcpy(dst.last_pose, T, 16 * sizeof(double)); dst.last_pose_set = src.set_id;
   dst.grid = src.grid;
 }
 
@@ -1013,7 +1034,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_stage = c->grid_stage; w->grid_stage_lone = c->grid_stage_lone; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_stage = c->grid_stage; w->grid_stage_lone = c->grid_stage_lone; w->seed_delta_um = c->seed_delta_um; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -1118,6 +1139,11 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       if (qn[k] == 0) { gfwd[k] = GridPair(); grev[k] = GridPair(); continue; }
       gfwd[k] = make_grid_pair(s, qb[k], qn[k], t, w->bkeys + off_s[k]);
       gfwd[k].key_by_pos = 1; gfwd[k].seed_from_keys = 1; gfwd[k].mark = fwd[k].mark;
+      // seed_delta: how far the pair has moved since the searches that left the keys -- from the device records of a pass that
+      // is enqueued ahead of its poses, else from what note_pose() has added up since both clouds were last searched
+      gfwd[k].qpose_dev = s.pose_dev;
+      gfwd[k].delta = (s.moved >= 0.0 && t.moved >= 0.0 && s.last_pose_set == s.set_id && t.last_pose_set == t.set_id)
+                          ? std::nextafterf((float)((s.moved + t.moved) * (1.0 + 1e-6)), INFINITY) : -1.f;
       gfwd[k].heavy = w->bheavy + off_s[k];      // wide balls are left to the culled kernel: same keys, same marks
       grev[k] = make_grid_pair(t, 0, std::min(qn[k], t.n), s, w->brkeys + off_t[k]);
       grev[k].qlist = rev[k].qlist; grev[k].qcount = rev[k].qcount; grev[k].qbound = rev[k].qbound;
@@ -1324,6 +1350,9 @@ API int mvr_pair_moments2_batch(mvr_ctx *ctx, int n_pairs, const int *src, const
       if (status != MVR_OK) return status;
     }
     host_mark("  batch: searches and sums enqueued");
+    // (seed_delta: the keys these searches leave belong to the clouds' poses of NOW -- what they move from here on counts from zero)
+    for (int k = 0; k < n_pairs; ++k)
+      for (int sl : {src[k], dst[k]}) { Cloud &cl = c->slots[sl]; if (cl.pose_known && cl.last_pose_set == cl.set_id && !cl.posed_by_table) cl.moved = 0.0; }
     if (out) {
       std::vector<double> h((size_t)n_pairs * 32);
       MVR_HIP_TRY(c, hipMemcpyAsync(h.data(), table, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1447,7 +1476,9 @@ __global__ void pose_prep_kernel(const double *__restrict__ in, PoseRec *__restr
   if (v >= n_views) return;
   double T[16];
   for (int j = 0; j < 16; ++j) T[j] = in[16 * v + j];
-  make_pose_rec(T, out + v);
+  const float delta = (float)T[3];      // (see refresh_sorted_kernel: the table's element [3] carries the cloud's motion since the pass before)
+  T[3] = 0.0;
+  make_pose_rec(T, delta, out + v);
 }
 
 }  // namespace
@@ -1625,9 +1656,21 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
     const size_t cap = c->pose_tab_cap;
     int parity = 0;
     std::vector<double> last_in((size_t)V * 16);
+    // (seed_delta: how far every view moves from the poses written last to these, an upper bound over the scan's bounding box,
+    // travels in the pinned table's always-zero element [3] of the view's pose; the posing launch moves it into the device record.
+    // The first poses of a stretch have no predecessor in the table: 1e30 = unknown, the searches gather their seeds as before.)
+    bool have_last = false;
     auto write_poses = [&](int par, const double *P) {
-      std::memcpy(c->h_pose_in + (size_t)par * cap * 16, P, (size_t)V * 16 * sizeof(double));
+      double *dstp = c->h_pose_in + (size_t)par * cap * 16;
+      std::memcpy(dstp, P, (size_t)V * 16 * sizeof(double));
+      for (int v = 0; v < V; ++v) {
+        const Cloud &raw = c->slots[L.raw_slots[v]];
+        double d = -1.0;
+        if (have_last && raw.bbox_set == raw.set_id && raw.bbox_set != 0) d = pose_motion_bound(last_in.data() + 16 * (size_t)v, P + 16 * (size_t)v, raw.bbox);
+        dstp[16 * (size_t)v + 3] = d >= 0.0 ? (double)std::nextafterf((float)(d * (1.0 + 1e-6)), INFINITY) : 1.0e30;
+      }
       std::memcpy(last_in.data(), P, (size_t)V * 16 * sizeof(double));
+      have_last = true;
     };
     auto open_gate = [&](uint32_t seq) { __atomic_store_n(c->gate, seq, __ATOMIC_RELEASE); };
     auto enqueue_chain = [&](int par, bool gated, uint32_t *seq_out) -> int {
@@ -1658,6 +1701,7 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
         const bool was_known = d.pose_known;
         d.posed_by_table = false;
         note_pose(d, c->slots[L.raw_slots[v]], was_known, last_in.data() + 16 * (size_t)v);
+        if (d.pose_known && d.last_pose_set == d.set_id) d.moved = 0.0;      // (the last queued pass searched the view at exactly this pose)
         if (d.pts_stale) {                               // the points in original order, left out while the passes were queued ahead
           in.push_back(c->slots[L.raw_slots[v]].pts); out.push_back(d.pts); nn.push_back(d.n);
           Ts.insert(Ts.end(), last_in.begin() + 16 * (size_t)v, last_in.begin() + 16 * (size_t)v + 16);
@@ -2563,6 +2607,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
     if (!value && c->stage_stat) { (void)hipFree(c->stage_stat); c->stage_stat = nullptr; }
   }
   else if (!std::strcmp(key, "order_batch")) c->order_batch = value != 0;
+  else if (!std::strcmp(key, "seed_delta_um")) { if (value < 0) return MVR_E_ARG; c->seed_delta_um = value; }
   else if (!std::strcmp(key, "grid_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->grid_lanes = value; }
   else if (!std::strcmp(key, "grid_index")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_index = value; }
   else if (!std::strcmp(key, "grid_cell_points")) { if (value < 1) return MVR_E_ARG; c->grid_cell_points = value; }

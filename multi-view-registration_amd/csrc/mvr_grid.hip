@@ -427,11 +427,28 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
     // query -> previous match -> its grid position -> its coordinates, and every link not waited for separately is a round trip less)
     q = a.qs[qpos];
     const uint32_t start_bits = a.qbound ? a.qbound[qpos] : 0xFFFFFFFFu;
-    const uint32_t prev = a.seed_from_keys ? (uint32_t)a.keys[qpos] : kNone;
+    const unsigned long long pkey = a.seed_from_keys ? a.keys[qpos] : kKeyInit;
+    const uint32_t prev = (uint32_t)pkey;
     // the bound: the cap, or a distance within which a point is KNOWN to exist (inclusive)
     float bound = cap2;
     if (start_bits <= __float_as_uint(bound)) { bound = __uint_as_float(start_bits); seeded = true; }
-    if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; seeded = true; } }      // (the same point, read from the array the walk is about to read)
+    if (prev < a.nt) {
+      // the query's match of the pass before is still a point of the target: its distance NOW bounds the nearest point's.
+      // seed_delta: while the two clouds have moved by little since (delta: an upper bound from the poses, through the device
+      // records or by value) that distance is at most the old one + delta -- no need to gather the point's coordinates (two
+      // dependent gathers at the head of every wave).  What the slack covers: the float roundings of the four posed points
+      // involved (half an ulp per coordinate at their magnitude: the 4e-6 |q|_1 term, as in grid_ball), of the two distance
+      // formulas and of the square root (the 1.000001 factors); the old and the new distance are compared as real numbers.
+      const float delta = a.pose_dev ? a.pose_dev->delta + (a.qpose_dev ? a.qpose_dev->delta : 1.0e30f) : a.delta;
+      if (delta >= 0.f && delta <= batch.delta_max) {
+        const float b = __builtin_amdgcn_sqrtf(__uint_as_float((uint32_t)(pkey >> 32))) * 1.000001f + delta + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
+        const float b2 = b * b * 1.000001f;
+        if (b2 <= bound) { bound = b2; seeded = true; }
+      } else {
+        const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z);      // (the same point, read from the array the walk is about to read)
+        if (d <= bound) { bound = d; seeded = true; }
+      }
+    }
     // the ball in the target's canonical frame (the mapping itself is done in double)
     const Ball ball = grid_ball(a, q, bound);
     rx = ball.rx; ry = ball.ry; rz = ball.rz;
@@ -1367,6 +1384,7 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     batch.cluster = c->grid_cluster;
     batch.probe = c->grid_probe;
     batch.probe_rows = std::min(c->grid_probe_rows, batch.light_rows);
+    batch.delta_max = 1.0e-3f * (float)c->seed_delta_um;
     if (total == 0) continue;
     map.n_pairs = (uint32_t)m;
     unsigned grid_blocks = 0;

@@ -199,9 +199,11 @@ __global__ void __launch_bounds__(256) refresh_sorted_kernel(RefreshBatch rb)
   const double *tin = rb.Tin[cloud];
   if (rb.from[cloud]) {
     const double *tsrc = tin ? tin : (rb.Tp[cloud] ? rb.Tp[cloud]->m : nullptr);
-    if (threadIdx.x < 16) s_T.m[threadIdx.x] = tsrc ? tsrc[threadIdx.x] : rb.T[cloud].m[threadIdx.x];
+    // (a pose that comes from the host's pinned table carries, in the slot of its always-zero element [3], how far the cloud has
+    // moved since the pass before -- ring_passes puts it there; it goes into the device record and the element is zero again)
+    if (threadIdx.x < 16) s_T.m[threadIdx.x] = (tin && threadIdx.x == 3) ? 0.0 : (tsrc ? tsrc[threadIdx.x] : rb.T[cloud].m[threadIdx.x]);
     __syncthreads();
-    if (tin && blockIdx.x == 0 && threadIdx.x == 0) make_pose_rec(s_T.m, reinterpret_cast<PoseRec *>(const_cast<Mat44d *>(rb.Tp[cloud])));
+    if (tin && blockIdx.x == 0 && threadIdx.x == 0) make_pose_rec(s_T.m, (float)tin[3], reinterpret_cast<PoseRec *>(const_cast<Mat44d *>(rb.Tp[cloud])));
   }
   const float4 *__restrict__ pts = rb.pts[cloud];
   const uint32_t *__restrict__ perm = rb.perm[cloud];

@@ -93,7 +93,7 @@ struct Mat44d { double m[16]; };
 struct PoseRec {
   Mat44d T;                 // the pose (column-major 4 x 4)
   double minv[12];          // its inverse affine map, row-major 3 x 4: posed frame -> canonical frame
-  float stretch, pad_;      // bound of how much the inverse lengthens a distance (1 for a rigid pose)
+  float stretch, delta;     // bound of how much the inverse lengthens a distance (1 for a rigid pose); how far (mm, upper bound) any point of the cloud has moved since the pass before (1e30: unknown)
 };
 
 // One merged scan inside a cloud that is a CONCATENATION of posed copies of scans -- the growing target of the sequential
@@ -144,6 +144,10 @@ struct Cloud {
   bool fin_known = false; float fin[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::vector<GridPart> parts;         // non-empty: this cloud is exactly the concatenation of these posed scans (see GridPart)
   void forget_pose() { canonical = false; pose_known = false; fin_known = false; pose_stretch = 1.0; grid.reset(); parts.clear(); }
+  // how far this posed copy has moved since it was last searched (seed_delta, mvr_grid.hip): `moved` (mm, an upper bound over the
+  // cloud's points; < 0: unknown) accumulates over the poses note_pose() records, from `last_pose`; a fused pass that searches the
+  // cloud puts it back to 0.  Valid while last_pose_set == set_id.
+  double last_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, moved = -1.0; uint64_t last_pose_set = 0;
   float bbox[6] = {0, 0, 0, 0, 0, 0}; uint64_t bbox_set = 0;      // with bbox_set == set_id (and canonical): the bounding box of pts[], taken when the cloud was uploaded (the grid build then needs no round trip for it)
   bool pts_stale = false;              // pts[] were left out by the last (pipelined) pose of this cloud: sorted[] / gsorted[] are current, pts[] are written when the run leaves the pipe
   bool posed_by_table = false;         // ... and the last transform of this cloud did read it (its host-side pose is filled in when the run leaves the pipe)
@@ -247,6 +251,14 @@ struct Ctx {
   int cull_q = 0;                                     // culled kernel: queries per lane (0 = auto)
   int cull_w = 0;                                     // culled kernel: waves sharing one query set (1, 2, 4; 0 = by launch size)
   int cull_slices = 0;                                // culled kernel: interleaved slices a pair's query sets are dealt to the XCDs in (1, 2, 4, 8; 0 = 8 / gcd(pairs, 8))
+  // seed_delta (round 4): a forward search of the grid walk that has the previous pass's key at hand takes its start bound from THAT
+  // distance plus how far the two clouds have moved since (an upper bound from the poses and the scan's bounding box) instead of
+  // gathering the old match's coordinates (two dependent gathers at the head of every wave) -- while the motion is below
+  // seed_delta_um micrometres (0: never, the default).  Any bound within which a point is known to exist is a valid start: results do
+  // not change (tests/test_gpu_ring.py) -- and, measured, neither does the time: 0.339 / 0.329 ms per settled pass with it against
+  // 0.336 / 0.330 without (same box, 50 um): the two gathers it removes are latency other waves cover.  Kept as a knob; the
+  // per-view motion bound it rests on (PoseRec::delta, Cloud::moved) is what a certificate for the rim queries would need too.
+  int seed_delta_um = 0;
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
   int fused_mark = 1;                                 // fused pass: the forward launches themselves record the matched targets' start bounds -- 1: when they are the grid walk, 2: always, 0: never (a separate launch re-reads the keys)
   bool marked_in_search = false;                      // ... what this pass does (decided with its forward launches)
@@ -425,7 +437,7 @@ __device__ __forceinline__ float4 pose_point_f64(const Mat44d &T, const float4 p
 }
 // the device record of a pose (PoseRec) from its 16 doubles: inverse of x -> A x + t by cofactors, in double, as make_grid_pair
 // does on the host; the stretch for ANY invertible matrix (the host has checked e <= 1e-3 before it released the pass: note_pose's bar)
-__device__ __forceinline__ void make_pose_rec(const double *T, PoseRec *out)
+__device__ __forceinline__ void make_pose_rec(const double *T, float delta, PoseRec *out)
 {
   PoseRec r;
   for (int j = 0; j < 16; ++j) r.T.m[j] = T[j];
@@ -449,7 +461,7 @@ __device__ __forceinline__ void make_pose_rec(const double *T, PoseRec *out)
     }
   const double e = fmin(sqrt(e2), 0.5);
   r.stretch = __double2float_ru((1.0 / sqrt(1.0 - e)) * (1.0 + 1e-6));
-  r.pad_ = 0.f;
+  r.delta = delta;
   *out = r;
 }
 struct RefreshBatch {
@@ -568,6 +580,8 @@ struct GridPair {
   uint32_t *mark = nullptr;                   // optional: start bounds of the reverse searches, by the match's Hilbert position
   uint32_t key_by_pos = 0, seed_from_keys = 0;
   const PoseRec *pose_dev = nullptr;     // optional: minv / stretch are read from here (device-visible) instead of the two by-value members
+  const PoseRec *qpose_dev = nullptr;    // ... and the QUERY cloud's record (for its `delta`)
+  float delta = -1.f;                    // without records: how far the two clouds have moved against each other since the searches that left keys[] (mm, upper bound; < 0: unknown)
   float stretch = 1.f;                   // distances in the searched cloud's canonical frame are at most this times the posed ones (Cloud::pose_stretch, rounded up)
   int dt_max = 12;                       // what dt == 255 stands for (the grid's dt_steps)
   // a BOUNDED query whose ball is wide (scattered among the others: a match that moved far, a long correspondence) is
@@ -580,7 +594,7 @@ constexpr int kGridBatchPairs = 12;
 constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
 constexpr int kGridDtMax = 12;        // most dilation steps of the distance map (a grid is built with as many as the first search radius it serves needs)
 constexpr int kGridLightRows = 24;    // default number of rows of cells (x-runs) a thread walks by itself (with the probe at its own threshold of 12 rows: 24 takes 0.19 ms off the first four passes of a window that restarts from the prior, settled passes equal; 32 and 48 within 2 % of it; before the probe had a threshold of its own, on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
-struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; int probe = 0; int probe_rows = 1 << 30; };
+struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; int probe = 0; int probe_rows = 1 << 30; float delta_max = 0.f; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the two launches below in one
