@@ -294,14 +294,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t x, uint32_t *tot
 // target points behind a short row as before), same `take`, same 64-bit candidate, same tie rule: bit-identical to the plain
 // walk (tests/test_gpu_ring.py, test_gpu_exact.py with grid_stage 0 / 1 / 2).  The probe and the wide / listed routes are
 // untouched.  registrator.cpp:644-649 is what this answers.
-// What it buys, what it does not (profiles/r04_*): the forward launch of the 12 x 200k ring 113 -> 96 us (vector memory
-// instructions 3.3e6 -> 1.1e6 per launch, TA busy -50 %), at 40 % MORE vector ALU instructions (the staging) and 7 instead of 8
-// waves per SIMD; a wave's chain of dependent round trips (query -> seed -> seed point -> rows -> points -> walk -> match's
-// position) is what is left, ~37 k cycles per wave, and every step to shorten the walk itself that was built on top -- the rounds
-// of all lanes dealt evenly through a list in LDS (the dealt walk took 4 k cycles instead of 12 k, making the list 13 k), more
-// points per wave at fewer waves per SIMD (256 / 320 / 448 points: 98 / 122 / 141 us) -- lost more in occupancy or in
-// bookkeeping than it won.  The REVERSE launch's queries are 2.4 x sparser (the matched targets): its waves want ~350 points,
-// 14 % of them fit, and it stays with the plain walk (70 us against 72 staged).
+// What it buys, what it does not (profiles/r04_*): the forward launch of the 12 x 200k ring 113 -> 96-100 us (vector memory
+// instructions 3.3e6 -> 1.4e6 per launch, L1 accesses 4.8e7 -> 2.4e7, TA busy 93 % -> 63 % of the CU-busy cycles), at 45 % MORE
+// vector ALU instructions (the staging: 4.9e7 -> 7.1e7, the VALUs now 57 % busy) and 16.6 KB of LDS per block (eight waves per SIMD
+// still: 62 registers).  No unit is saturated any more; what is left is a wave's chain of ~40 dependent steps times what the CU
+// can keep resident.  Built on top, measured, NOT kept: the rounds of all lanes dealt evenly through a list in LDS
+// (the dealt rounds took 4 k cycles per wave instead of 12 k -- making the list cost 13 k, slot allocation by LDS atomics or by a
+// prefix sum alike); more points per wave at fewer waves per SIMD (256 / 320 / 448 points: 98 / 122 / 141 us); a per-cell table
+// in LDS instead of the lanes' own range loads (a box of up to 7 cells along x: 20 % of the waves are wider); the probe as part
+// of the staged step (97 -> 113 us); start bounds without the seed's two gathers (seed_delta: exact, equal).  The REVERSE
+// launch's queries are 2.4 x sparser (the matched targets): its waves want ~350 points, 14 % of them fit, and it stays with the
+// plain walk (70 us against 72 staged).  Memory-side traffic is unchanged (286 MB per forward launch): a wave's lines were
+// shared through the L1 / L2 before, they are fetched once per wave now -- the misses are the same lines.
 #ifndef MVR_STAGE_PTS
 #define MVR_STAGE_PTS 192
 #endif
