@@ -463,7 +463,7 @@ API int mvr_ctx_destroy(mvr_ctx *ctx)
   c->orders.clear(); c->grids.clear();
   if (c->order_pool) c->order_pool->close();          // orderings that outlive the context free their buffers themselves
   void *bufs[] = {c->keys, c->rkeys, c->slot, c->list, c->match, c->flags, c->count, c->evals, c->partials, c->moments,
-                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
+                  c->codes_a, c->codes_b, c->idx_a, c->cub_tmp, c->bbox, c->batch_table, c->bcert, c->bkeys, c->brkeys, c->bbound, c->bound, c->dn_arena, c->bpartials, c->blist, c->bslot, c->bchunks, c->dist_table, c->bheavy, c->bwide, c->bwide_count, c->bcull_sets};
   for (void *b : bufs) if (b) (void)hipFree(b);
   if (c->stage_stat) (void)hipFree(c->stage_stat);
   if (c->proj_rows) (void)hipFree(c->proj_rows);
@@ -1034,7 +1034,7 @@ static int get_worker(Ctx *c, size_t k, Ctx **out)
   }
   Ctx *w = c->workers[k];
   w->nn_mode = c->nn_mode; w->nn_q = c->nn_q; w->nn_sub = c->nn_sub; w->nn_blocks_per_cu = c->nn_blocks_per_cu;
-  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_stage = c->grid_stage; w->grid_stage_lone = c->grid_stage_lone; w->seed_delta_um = c->seed_delta_um; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
+  w->cull_q = c->cull_q; w->cull_w = c->cull_w; w->cull_slices = c->cull_slices; w->ring_search = c->ring_search; w->grid_light_rows = c->grid_light_rows; w->grid_light_rows_lone = c->grid_light_rows_lone; w->grid_probe = c->grid_probe; w->grid_probe_rows = c->grid_probe_rows; w->reduce_rows = c->reduce_rows; w->grid_wide = c->grid_wide; w->grid_lanes = c->grid_lanes; w->grid_stage = c->grid_stage; w->grid_stage_lone = c->grid_stage_lone; w->seed_delta_um = c->seed_delta_um; w->rim_cert_um = c->rim_cert_um; w->grid_cluster = c->grid_cluster; w->grid_sets = c->grid_sets; w->grid_tail = c->grid_tail; w->cull_list_w = c->cull_list_w; w->grid_wide_waves = c->grid_wide_waves; w->grid_cell_points = c->grid_cell_points; w->prof = c->prof; w->prof_mask = c->prof_mask; w->prof_totals = c->prof_totals;
   if (!w->ev_join && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)
     return set_error(c, MVR_E_HIP, "worker event");
   *out = w;
@@ -1130,6 +1130,11 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       MVR_HIP_TRY(w, hipMemsetAsync(w->bwide_count, 0, 3 * kWideCounters * sizeof(uint32_t), w->stream));
     }
     if (int rc = ensure(w, w->bcull_sets, w->bcull_sets_cap, off_s[n_pairs] / 64 + (size_t)n_pairs)) return rc;      // the forward sets that hold a flagged query
+    if (c->rim_cert_um > 0) {          // rim certificates: one float per forward query, kept from pass to pass like the keys
+      const float *before = w->bcert;
+      if (int rc = ensure(w, w->bcert, w->bcert_cap, off_s[n_pairs])) return rc;
+      if (w->bcert != before) w->bcert_zero = false;
+    }
     if (n_pairs > kWideCounters) grid_ok = false;
   }
   if (grid_ok) {
@@ -1142,6 +1147,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       // seed_delta: how far the pair has moved since the searches that left the keys -- from the device records of a pass that
       // is enqueued ahead of its poses, else from what note_pose() has added up since both clouds were last searched
       gfwd[k].qpose_dev = s.pose_dev;
+      if (c->rim_cert_um > 0 && w->bcert) gfwd[k].cert = w->bcert + off_s[k];
       gfwd[k].delta = (s.moved >= 0.0 && t.moved >= 0.0 && s.last_pose_set == s.set_id && t.last_pose_set == t.set_id)
                           ? std::nextafterf((float)((s.moved + t.moved) * (1.0 + 1e-6)), INFINITY) : -1.f;
       gfwd[k].heavy = w->bheavy + off_s[k];      // wide balls are left to the culled kernel: same keys, same marks
@@ -1164,6 +1170,11 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   if (w->marked_in_search)
     for (int k = 0; k < n_pairs; ++k) if (qn[k]) { fwd[k].mark = w->bbound + off_t[k]; if (grid_ok) gfwd[k].mark = fwd[k].mark; }
   if (phases & 1) {
+    // (the certificates belong to the searches the keys belong to: another set of searches, or none before, starts without any)
+    if (w->bcert && (!seed || !w->bcert_zero || w->bcert_cap2 != cap2)) {      // (... or searches with another cap)
+      MVR_HIP_TRY(w, hipMemsetAsync(w->bcert, 0, w->bcert_cap * sizeof(float), w->stream));
+      w->bcert_zero = true; w->bcert_cap2 = cap2;
+    }
     if (reciprocal && !w->bbound_clean) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, w->bbound_cap * sizeof(uint32_t), w->stream));
     if (reciprocal) w->bbound_clean = false;        // dirty until this pass's moments launch has put it back
     if (grid_ok && seed) {
@@ -2607,6 +2618,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
     if (!value && c->stage_stat) { (void)hipFree(c->stage_stat); c->stage_stat = nullptr; }
   }
   else if (!std::strcmp(key, "order_batch")) c->order_batch = value != 0;
+  else if (!std::strcmp(key, "rim_cert_um")) { if (value < 0) return MVR_E_ARG; c->rim_cert_um = value; }
   else if (!std::strcmp(key, "seed_delta_um")) { if (value < 0) return MVR_E_ARG; c->seed_delta_um = value; }
   else if (!std::strcmp(key, "grid_lanes")) { if (value != 1 && value != 2 && value != 4 && value != 8) return MVR_E_ARG; c->grid_lanes = value; }
   else if (!std::strcmp(key, "grid_index")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_index = value; }

@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
     // the bound: the cap, or a distance within which a point is KNOWN to exist (inclusive)
     float bound = cap2;
     if (start_bits <= __float_as_uint(bound)) { bound = __uint_as_float(start_bits); seeded = true; }
+    const float pdelta = (a.seed_from_keys || a.cert) ? (a.pose_dev ? a.pose_dev->delta + (a.qpose_dev ? a.qpose_dev->delta : 1.0e30f) : a.delta) : -1.f;
     if (prev < a.nt) {
       // the query's match of the pass before is still a point of the target: its distance NOW bounds the nearest point's.
       // seed_delta: while the two clouds have moved by little since (delta: an upper bound from the poses, through the device
@@ -443,7 +444,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
       // dependent gathers at the head of every wave).  What the slack covers: the float roundings of the four posed points
       // involved (half an ulp per coordinate at their magnitude: the 4e-6 |q|_1 term, as in grid_ball), of the two distance
       // formulas and of the square root (the 1.000001 factors); the old and the new distance are compared as real numbers.
-      const float delta = a.pose_dev ? a.pose_dev->delta + (a.qpose_dev ? a.qpose_dev->delta : 1.0e30f) : a.delta;
+      const float delta = pdelta;
       if (delta >= 0.f && delta <= batch.delta_max) {
         const float b = __builtin_amdgcn_sqrtf(__uint_as_float((uint32_t)(pkey >> 32))) * 1.000001f + delta + (1.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z)));
         const float b2 = b * b * 1.000001f;
@@ -467,6 +468,17 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
       // however far the query itself lies outside the grid
       const int cx = cell_of(rx, a.lo[0], a.inv_h, a.dim[0]), cy = cell_of(ry, a.lo[1], a.inv_h, a.dim[1]), cz = cell_of(rz, a.lo[2], a.inv_h, a.dim[2]);
       worth = !(dt_least_of(a, dt_of(a, cx, cy, cz)) > rad);
+    }
+    if (a.cert) {
+      // a rim certificate: an earlier pass proved that NO target point lies within the cap + a margin of this query, and the two
+      // clouds have moved by less than what is left of that margin since: there is still none within the cap -- no distance map,
+      // no probe, no listed set.  (What is left must stay above what the float roundings of the posed points can amount to.)
+      const float cm = a.cert[qpos];
+      if (cm > 0.f) {
+        float rem = (!seeded && pdelta >= 0.f) ? cm - pdelta : 0.f;
+        if (rem > 2.0e-3f + 4.0e-6f * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z))) worth = false; else rem = 0.f;
+        a.cert[qpos] = rem;
+      }
     }
     best = ((unsigned long long)__float_as_uint(bound) << 32) | kNone;
     const int nrows = (y1 - y0 + 1) * (z1 - z0 + 1);
@@ -1450,7 +1462,7 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
   for (uint32_t si = bx; si < n_sets; si += nbx) {
     const uint32_t set = a.cull_sets[si];
     // ---- the set's queries (wave 0): bound, ball in cells, union of the flagged ones
-    bool valid = false;
+    bool valid = false, grant = false;
     uint32_t qpos = 0;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wv == 0) {
@@ -1463,11 +1475,17 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
       }
       if (valid) {
         q = a.qs[qpos];
-        if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) bound = __uint_as_float(v); }
+        bool bounded = false;
+        if (a.qbound) { const uint32_t v = a.qbound[qpos]; if (v <= __float_as_uint(bound)) { bound = __uint_as_float(v); bounded = true; } }
         if (a.seed_from_keys) {
           const uint32_t prev = (uint32_t)a.keys[qpos];
-          if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) bound = d; }
+          if (prev < a.nt) { const float d = gdist2<FMA>(a.gts[a.h2g[prev]], q.x, q.y, q.z); if (d <= bound) { bound = d; bounded = true; } }
         }
+        // rim certificates: a query without any bound is searched a margin BEYOND the cap -- nothing within that earns it a
+        // certificate (the walk then leaves it alone while the clouds move by less); what it finds between the cap and the margin
+        // is no match (the key below takes matches within the cap only) and no certificate
+        grant = a.cert != nullptr && !bounded && batch.cert_margin > 0.f;
+        if (grant) { const float cm = __builtin_amdgcn_sqrtf(cap2) * 1.000001f + batch.cert_margin; bound = cm * cm * 1.000001f; }
         const Ball ball = grid_ball(a, q, bound);
         const float rad = ball.rad, rx = ball.rx, ry = ball.ry, rz = ball.rz;
         c0[0] = cell_of(rx - rad, a.lo[0], a.inv_h, a.dim[0]); c1[0] = cell_of(rx + rad, a.lo[0], a.inv_h, a.dim[0]);
@@ -1559,6 +1577,7 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
         if (a.mark) __hip_atomic_store(&a.mark[hp], (uint32_t)(m >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       a.keys[ord] = found ? ((m & 0xFFFFFFFF00000000ull) | low) : kKeyInit;
+      if (a.cert) a.cert[qpos] = (grant && bi == kNone) ? batch.cert_margin : 0.f;
     }
     __syncthreads();                                // lq / ubox / lbest are reused by the next set
   }
@@ -1603,6 +1622,7 @@ int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     if (!any) continue;
     batch.cap2 = cap2;
     batch.light_rows = c->grid_light_rows;
+    batch.cert_margin = 1.0e-3f * (float)c->rim_cert_um;
     const unsigned wide_blocks = (unsigned)std::max(1, c->n_cu * c->grid_wide_waves / (std::max(1, m) * kWideWaves * 4));
     const unsigned set_blocks = (unsigned)std::max(1, c->n_cu * 8 / std::max(1, m));
     const bool per_launch = c->prof && !c->prof_totals;
@@ -1871,6 +1891,7 @@ int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     if (!any) continue;
     batch.cap2 = cap2;
     batch.light_rows = c->grid_light_rows;
+    batch.cert_margin = 1.0e-3f * (float)c->rim_cert_um;
     const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * 8 / std::max(1, m));      // listed sets are strided over (every block's loop ends at the count)
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));

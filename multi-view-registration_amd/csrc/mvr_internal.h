@@ -259,6 +259,15 @@ struct Ctx {
   // 0.336 / 0.330 without (same box, 50 um): the two gathers it removes are latency other waves cover.  Kept as a knob; the
   // per-view motion bound it rests on (PoseRec::delta, Cloud::moved) is what a certificate for the rim queries would need too.
   int seed_delta_um = 0;
+  // rim certificates: a forward query without any target point within the cap + rim_cert_um micrometres (found so by the listed-sets
+  // search) is not searched again -- no distance-map read, no probe, no place in a listed set -- while the pair has moved by less
+  // than that since (the same per-view motion bounds; 0: off, the default).  Results do not change (knob tests) -- and neither does
+  // the time: of the ~30 k rim queries per 1.2 M of a settled pass, 50 / 200 / 500 / 1000 um of margin take 0 / 2 / 8 / 9 k out and the
+  // listed SETS (a block each: what the tail launch costs) go from 950 to 800 at best -- a rim query is not a query with nothing
+  // near, it is one whose nearest target point lies just beyond the cap, and a registration that still moves 0.02 mm per view and
+  // pass spends a small margin at once.  The tail launch stays at 22-24 us either way (profiles/r04_c_rim_cert.txt).
+  int rim_cert_um = 0;
+  float *bcert = nullptr; size_t bcert_cap = 0; bool bcert_zero = false; float bcert_cap2 = -1.f;      // (the cap the certificates in bcert[] were granted for)
   int seed_forward = 1;                               // fused pass: forward searches start from the previous pass's matches when the same pairs are searched again
   int fused_mark = 1;                                 // fused pass: the forward launches themselves record the matched targets' start bounds -- 1: when they are the grid walk, 2: always, 0: never (a separate launch re-reads the keys)
   bool marked_in_search = false;                      // ... what this pass does (decided with its forward launches)
@@ -581,6 +590,10 @@ struct GridPair {
   uint32_t key_by_pos = 0, seed_from_keys = 0;
   const PoseRec *pose_dev = nullptr;     // optional: minv / stretch are read from here (device-visible) instead of the two by-value members
   const PoseRec *qpose_dev = nullptr;    // ... and the QUERY cloud's record (for its `delta`)
+  // rim certificates (round 4): per plain forward query (by position), how much more (mm) the pair may move before the finding "no
+  // target point within the cap" of an earlier pass has to be proved again; 0 = none.  Granted by the listed-sets search (which then
+  // looks cert_margin beyond the cap), spent by the walk (GridBatch::cert_margin; delta as for seed_delta)
+  float *cert = nullptr;
   float delta = -1.f;                    // without records: how far the two clouds have moved against each other since the searches that left keys[] (mm, upper bound; < 0: unknown)
   float stretch = 1.f;                   // distances in the searched cloud's canonical frame are at most this times the posed ones (Cloud::pose_stretch, rounded up)
   int dt_max = 12;                       // what dt == 255 stands for (the grid's dt_steps)
@@ -594,7 +607,7 @@ constexpr int kGridBatchPairs = 12;
 constexpr int kWideCounters = 64;          // pairs of one fused pass that can have wide lists (more: the pass takes the culled kernel)
 constexpr int kGridDtMax = 12;        // most dilation steps of the distance map (a grid is built with as many as the first search radius it serves needs)
 constexpr int kGridLightRows = 24;    // default number of rows of cells (x-runs) a thread walks by itself (with the probe at its own threshold of 12 rows: 24 takes 0.19 ms off the first four passes of a window that restarts from the prior, settled passes equal; 32 and 48 within 2 % of it; before the probe had a threshold of its own, on the 12 x 200k ring: 9..16 equal, 4 and 27 slower)
-struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; int probe = 0; int probe_rows = 1 << 30; float delta_max = 0.f; };
+struct GridBatch { GridPair p[kGridBatchPairs]; float cap2; int light_rows; int cluster = 65; int probe = 0; int probe_rows = 1 << 30; float delta_max = 0.f; float cert_margin = 0.f; };
 int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_wide_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);
 int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2, bool fma);     // the two launches below in one

@@ -241,6 +241,8 @@ def test_grid_search_equals_culled_search_over_passes(mvr, orc):
     # with huge cells and wide balls walked in-thread (more points than a wave's LDS holds: the rows behind are walked from global memory)
     dict(grid_stage=0), dict(grid_stage=2), dict(grid_stage=2, grid_cell_points=1), dict(grid_stage=2, grid_cell_points=40, grid_light_rows=64),
     dict(order_batch=0), dict(order_batch=0, grid_stage=0),
+    # rim certificates (round 4): off, with a margin of 1 mm, with the compact index and the staged walk everywhere
+    dict(rim_cert_um=50), dict(rim_cert_um=1000), dict(rim_cert_um=1000, seed_delta_um=1000, grid_stage=2, grid_index=1), dict(rim_cert_um=200, pipeline=0),
     # seed_delta (round 4): start bounds from the previous distance + the clouds' motion instead of the old match's coordinates: off, always on
     dict(seed_delta_um=50), dict(seed_delta_um=100000), dict(seed_delta_um=100000, grid_stage=0), dict(seed_delta_um=100000, pipeline=0, grid_index=1),
     # the compact cell-start tables (round 4): forced for these small grids, with the staged walk everywhere, with tiny / huge cells, dense forced
