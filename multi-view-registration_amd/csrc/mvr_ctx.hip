@@ -1565,10 +1565,11 @@ int pipe_setup(Ctx *c, int n_views)
 struct Spin { double t0 = now_ms(); unsigned n = 0; };
 // the host's wait for "pass seq has drained": a spin on pinned memory (a wake-up from hipStreamSynchronize costs tens of
 // microseconds), with a look at the stream every few thousand rounds so that a failed launch ends the wait, and a bound
-int wait_done(Ctx *c, uint32_t seq, bool *timed_out = nullptr)
+int wait_done(Ctx *c, uint32_t seq, bool *timed_out = nullptr, bool *async_error = nullptr)
 {
   Spin sp;
   if (timed_out) *timed_out = false;
+  if (async_error) *async_error = false;
   for (;;) {
     if ((int32_t)(__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) - seq) >= 0) return MVR_OK;
     __builtin_ia32_pause();
@@ -1576,7 +1577,7 @@ int wait_done(Ctx *c, uint32_t seq, bool *timed_out = nullptr)
       const hipError_t e = hipStreamQuery(c->stream);
       if (e != hipSuccess && e != hipErrorNotReady) return set_error(c, MVR_E_HIP, "a pass of the pipelined ring run failed on the device", e);
       if (e == hipSuccess && (int32_t)(__atomic_load_n(c->h_done, __ATOMIC_ACQUIRE) - seq) >= 0) return MVR_OK;
-      if (int rc = comm_poll(c)) return rc;                 // (a peer's failure surfaces here: the communicator is aborted, the pass will not finish)
+      if (int rc = comm_poll(c, async_error == nullptr)) { if (async_error) *async_error = true; return rc; }      // (a peer's failure surfaces here; a caller that asks for it aborts the communicator ITSELF, after it has opened the gate of a chain queued behind this pass)
       if (now_ms() - sp.t0 > (double)c->wait_timeout_ms) {
         // (with a communicator the caller aborts it -- after it has opened the gate of the chain queued behind this pass:
         // ncclCommAbort waits for the stream, and the stream would wait for the gate)
@@ -1741,8 +1742,8 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
         sum[0] += now_ms() - t0;
       }
       t0 = now_ms();
-      bool timed_out = false;
-      rc = wait_done(c, seq_cur, &timed_out);
+      bool timed_out = false, async_error = false;
+      rc = wait_done(c, seq_cur, &timed_out, &async_error);
       const double t1 = now_ms();
       if (rc == MVR_OK) rc = L.solve(L.self);
       sum[1] += t1 - t0; sum[2] += now_ms() - t1;
@@ -1752,8 +1753,11 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &L, double timing_ms[3])
           const bool had_comm = c->comm != nullptr;
           const int r2 = comm_abort(c, "a pass did not finish in time: a peer failed or never arrived");
           if (had_comm) rc = r2; else (void)set_error(c, rc, "a pass of the pipelined ring run did not finish in time");
+        } else if (async_error && c->comm) {           // RCCL reported an asynchronous error (wait_done only reports): abort now, the gate is open
+          const std::string why = c->last_error;
+          rc = comm_abort(c, why.c_str());
         }
-        (void)hipStreamSynchronize(c->stream);
+        (void)drain_bounded(c, 5000);
         leave();
         return rc;
       }
@@ -2357,14 +2361,17 @@ API int mvr_seq_align_sharded(mvr_ctx *ctx, int ss, int ts, int os, const mvr_ic
   const size_t ns = c->slots[ss].n;
   Cloud &cur = c->slots[kScratchCur];
   cur.n = 0;
-  if (int rc = cloud_reserve(c, cur, ns, false)) return rc;
-  if (ns) MVR_HIP_TRY(c, hipMemcpyAsync(cur.pts, c->slots[ss].pts, ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-  cur.n = ns;
-  if (c->nn_mode != 0 && ns) { if (int rc = ensure_index(c, c->slots[ss])) return rc; }
-  inherit_point_set(cur, c->slots[ss]);
-  cur.segs.clear();
+  // Everything that can fail for LOCAL reasons is reported through the iteration's collectives (neutral keys, a zero row, a failure
+  // count of 1), so that every rank leaves the iteration together (the set-up below and the transform inside the loop
+  // used to return at once, leaving the peers to wait_timeout_ms).  Only the two buffers the collectives themselves run on have
+  // to exist for that: a rank that cannot even allocate those cannot report, and its peers leave through the timeout.
   if (int rc = ensure(c, c->seq_keys, c->seq_keys_cap, std::max<size_t>(ns, 1))) return rc;
   if (!c->seq_row) MVR_HIP_TRY(c, hipMalloc(&c->seq_row, 40 * sizeof(double)));
+  int carry = cloud_reserve(c, cur, ns, false);
+  if (carry == MVR_OK && ns) { const hipError_t e = hipMemcpyAsync(cur.pts, c->slots[ss].pts, ns * sizeof(float4), hipMemcpyDeviceToDevice, c->stream); if (e != hipSuccess) carry = set_error(c, MVR_E_HIP, "copy of the source", e); }
+  if (carry == MVR_OK) cur.n = ns;
+  if (carry == MVR_OK && c->nn_mode != 0 && ns) carry = ensure_index(c, c->slots[ss]);
+  if (carry == MVR_OK) { inherit_point_set(cur, c->slots[ss]); cur.segs.clear(); }
   const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   float fin[16], tr[16];
   std::memcpy(fin, I, sizeof I); std::memcpy(tr, I, sizeof I);
@@ -2373,8 +2380,8 @@ API int mvr_seq_align_sharded(mvr_ctx *ctx, int ss, int ts, int os, const mvr_ic
   int iters = 0, converged = 0, state = MVR_CONV_NOT, ncorr = 0, status = MVR_OK;
   Cloud &tgt = c->slots[ts];
   do {
-    int local = MVR_OK;
-    if (c->inject_fail_at >= 0 && c->dist_pass == c->inject_fail_at) local = set_error(c, MVR_E_HIP, "injected failure of this rank's local work");
+    int local = carry;          // (a failure of the set-up, or of the transform that ended the iteration before)
+    if (local == MVR_OK && c->inject_fail_at >= 0 && c->dist_pass == c->inject_fail_at) local = set_error(c, MVR_E_HIP, "injected failure of this rank's local work");
     ++c->dist_pass;
     if (local == MVR_OK) local = forward_keys_impl(c, cur, tgt, p->max_corr_dist, p->fma_dist, c->seq_keys);
     if (local != MVR_OK && ns) (void)hipMemsetAsync(c->seq_keys, 0x7F, ns * sizeof(long long), c->stream);      // "no neighbour here" (any key above every real one)
@@ -2403,12 +2410,13 @@ API int mvr_seq_align_sharded(mvr_ctx *ctx, int ss, int ts, int os, const mvr_ic
     if (int rc = mvr_moments_from_moments2(&m2, &mom)) return set_error(c, rc, "moments of the sharded align");
     if (int rc = mvr_umeyama_from_moments(&mom, tr, nullptr)) return set_error(c, rc, "Umeyama of the sharded align");
     cur_mse = h[31] / h[0];                          // mean of the correspondences' (f32) squared distances, as PCL has it
-    if (int rc = launch_transform_f32(c, cur.pts, cur.pts, ns, tr)) return rc;
+    carry = launch_transform_f32(c, cur.pts, cur.pts, ns, tr);          // (reported through the NEXT iteration's collectives, if there is one)
     cur.stale_coords();
     mvr_mat4f_mul(tr, fin, fin);
     ++iters;
     converged = crit.converged(tr, cur_mse, iters, &state) ? 1 : 0;
   } while (!converged);
+  if (carry != MVR_OK) return carry;
   if (os >= 0) {            // output = final * (*input), from the ORIGINAL input (App. A.1)
     if (os != ss) { c->slots[os].n = 0; if (int rc = cloud_reserve(c, c->slots[os], ns, false)) return rc; }
     if (int rc = launch_transform_f32(c, c->slots[ss].pts, c->slots[os].pts, ns, fin)) return rc;

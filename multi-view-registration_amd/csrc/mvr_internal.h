@@ -348,6 +348,7 @@ struct Ctx {
   // multi-GPU (mvr_world.cpp): an RCCL communicator (ncclComm_t; null = this context is a world of its own)
   void *comm = nullptr; bool comm_owned = false; int comm_rank = 0, comm_world = 1;
   void **comm_lender = nullptr;                       // a world's communicator is lent: where the world keeps it (cleared when it is aborted here)
+  bool stream_stuck = false;                          // ncclCommAbort did not return: the stream may never drain (waits on it are bounded from then on)
   bool comm_broken = false;                           // the communicator was aborted (a peer failed or never arrived): the multi-GPU entry points refuse until a new one is set
   // PROJECTION of a rank's share on one GPU (mvr_ctx_project; tools/rank_share_bench.py): mvr_ring_run_sharded then plans as
   // rank project_rank of project_world whatever the communicator says (a world of one: the collective is really issued, its
@@ -637,7 +638,8 @@ int ring_passes(Ctx *c, int n_steps, const PassLoop &loop, double timing_ms[3]);
 // ---- collectives of a context (mvr_world.cpp); every one of them is a no-op returning MVR_OK without a communicator
 enum { kReduceMinI64 = 0, kReduceSumF64 = 1 };
 int comm_allreduce(Ctx *c, void *dev_buf, size_t count, int kind);      // in place, on the context's stream
-int comm_poll(Ctx *c);                        // RCCL's asynchronous error state; an error aborts the communicator -> MVR_E_RCCL
+int comm_poll(Ctx *c, bool abort_now = true); // RCCL's asynchronous error state; an error aborts the communicator (abort_now) -> MVR_E_RCCL
+bool drain_bounded(Ctx *c, int ms);           // hipStreamSynchronize -- bounded by ms once an abort has failed to free the stream (Ctx::stream_stuck)
 int comm_abort(Ctx *c, const char *why);      // ncclCommAbort + release of anything that could hold the stream; returns MVR_E_RCCL
 int stream_wait(Ctx *c);                      // hipStreamSynchronize; with a communicator: bounded by wait_timeout_ms and watching comm_poll, a timeout aborts
 GridPair make_grid_pair(const Cloud &q, size_t q_begin, size_t q_count, const Cloud &t, nnkey_t *keys);

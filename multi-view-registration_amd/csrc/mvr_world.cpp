@@ -139,6 +139,9 @@ int comm_abort(Ctx *c, const char *why)
       std::unique_lock<std::mutex> lk(box->m);
       const bool back = box->cv.wait_for(lk, std::chrono::seconds(5), [&] { return box->done; });
       MVR_TRACE("ncclCommAbort %s", back ? "returned" : "did NOT return within 5 s (left behind)");
+      // (a call that did not come back leaves its collective on the stream: nothing may wait for that stream without a bound
+      // any more -- drain_bounded -- and the process should end rather than go on with this device)
+      if (!back) c->stream_stuck = true;
     }
     if (c->comm_lender) *c->comm_lender = nullptr;                                // a world's communicator: the world must not destroy it again
     c->comm = nullptr; c->comm_owned = false; c->comm_lender = nullptr;
@@ -147,7 +150,24 @@ int comm_abort(Ctx *c, const char *why)
   return set_error(c, MVR_E_RCCL, why);
 }
 
-int comm_poll(Ctx *c)
+// waits for the context's stream, but not for ever once an abort has failed to free it: true = drained
+bool drain_bounded(Ctx *c, int ms)
+{
+  if (!c->stream_stuck) return hipStreamSynchronize(c->stream) == hipSuccess;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) return false;
+    if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)ms) {
+      MVR_TRACE("the stream did not drain within %d ms behind an abort that never returned: left as it is", ms);
+      return false;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+int comm_poll(Ctx *c, bool abort_now)
 {
   if (!c->comm) return MVR_OK;
   Rccl &r = rccl();
@@ -156,7 +176,8 @@ int comm_poll(Ctx *c)
   if (r.CommGetAsyncError(reinterpret_cast<ncclComm_t>(c->comm), &st) != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) {
     std::string msg = "RCCL reports an asynchronous error";
     if (r.GetErrorString) { msg += ": "; msg += r.GetErrorString(st); }
-    return comm_abort(c, msg.c_str());
+    // (a caller with a chain queued behind a gate opens the gate FIRST: ncclCommAbort waits for the stream, the stream for the gate)
+    return abort_now ? comm_abort(c, msg.c_str()) : set_error(c, MVR_E_RCCL, msg.c_str());
   }
   return MVR_OK;
 }
@@ -173,11 +194,11 @@ int stream_wait(Ctx *c)
     if (e == hipSuccess) return MVR_OK;
     if (e != hipErrorNotReady) return set_error(c, MVR_E_HIP, "hipStreamQuery", e);
     if ((++n & 0x3FFu) == 0u) {
-      if (int rc = comm_poll(c)) { (void)hipStreamSynchronize(c->stream); return rc; }
+      if (int rc = comm_poll(c)) { (void)drain_bounded(c, 5000); return rc; }
       if (std::chrono::duration<double, std::milli>(clk::now() - t0).count() > (double)c->wait_timeout_ms) {
         const int rc = comm_abort(c, "a pass with a collective did not finish in time: a peer failed or never arrived");
         MVR_TRACE("draining the stream");
-        (void)hipStreamSynchronize(c->stream);                                    // the aborted collective and everything behind it drain now
+        (void)drain_bounded(c, 5000);                                             // the aborted collective and everything behind it drain now
         MVR_TRACE("drained");
         return rc;
       }

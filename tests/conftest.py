@@ -17,13 +17,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_sessionstart(session):
+@pytest.hookimpl(trylast=True)
+def pytest_collection_modifyitems(config, items):
     """The first `import torch` on a fresh box pages in ~1.3 GB of shared objects (libtorch_hip, librccl, ...) and can
     take minutes; round 1 met that cost in the middle of the session, inside the first ring test, and read it as a GPU
     hang (the library's streams play no part, tools/hang_probe.py, profiles/r02_a_hang_probe.log).
-    Pay it here, where the log says what it is.  The library itself needs no import order: the `gpu` fixture no longer
-    touches torch."""
-    if "gpu" in (session.config.getoption("-m") or "") and "not gpu" not in (session.config.getoption("-m") or ""):
+    Pay it here, where the log says what it is, whenever a GPU test is going to run -- by marker expression or by file
+    (`pytest tests/test_gpu_world.py`).  The library itself needs no import order to WORK (the `gpu` fixture does not touch
+    torch), but a process that first runs a collective through the library's RCCL and only then imports torch aborts at
+    interpreter exit ("double free or corruption", after every test has passed: the two runtimes' exit handlers run in
+    the wrong order; tools/scratch/bisect2.sh), so the tests that count devices with torch must not be
+    the ones that import it."""
+    if any(it.get_closest_marker("gpu") is not None for it in items):
         import time
         t0 = time.time()
         import torch  # noqa: F401
