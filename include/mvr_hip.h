@@ -464,8 +464,10 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * "lazy_super" (1, default: a posing launch that also writes a view's grid-ordered coordinates leaves its super boxes -- read by
  * the culled kernel alone -- to the first culled launch that follows, if any; 0: refreshed by every posing launch);
  * the aligns of the sequential mode: "seq_search" (mvr_icp_align of a posed scan against a model made of posed scans: 1, default:
- * the reverse searches walk the source scan's cell grid; 2: the forward search goes through the merged scans' grids as well; 0:
- * the culled kernel both ways), "seq_seed" (1, default: an align's forward searches start from the distance, now, of the point
+ * the reverse searches walk the source scan's cell grid; 2: the forward search goes through the merged scans' grids as well; 3: the
+ * forward search walks ONE grid over the model's own coordinates -- built from scratch per align, exact, measured no faster than the
+ * culled kernel even on a free grid: DESIGN.md 4.5 --, with "seq_cell_points" points per cell (default 4) and the flagged query sets
+ * through the culled kernel's listed-set launch ("seq_model_tail" 1, default) or the grid's set kernel (0); 0: the culled kernel both ways), "seq_seed" (1, default: an align's forward searches start from the distance, now, of the point
  * each query matched when the same scan was last aligned on this context -- the sweeps of registrationICP, the rounds of
  * AutoReg; 0: off, and what the aligns so far have left is forgotten), "align_spin" (1, default: the last sums launch of a
  * point-to-point iteration stores the iteration's row into mapped pinned memory itself and the host spins on a sequence word;

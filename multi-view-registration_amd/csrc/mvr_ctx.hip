@@ -403,7 +403,7 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_GRID_DEBUG")) c->grid_debug = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_SEQ_SEED")) c->seq_seed = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_ALIGN_SPIN")) c->align_spin = std::atoi(m) != 0;      // 0: an align's iteration row by copy + synchronise
-  if (const char *m = std::getenv("MVR_SEQ_SEARCH")) c->seq_search = std::max(0, std::min(2, std::atoi(m)));    // align against a target made of posed scans: 1 = through the scans' grids, 0 = culled kernel
+  if (const char *m = std::getenv("MVR_SEQ_SEARCH")) c->seq_search = std::max(0, std::min(3, std::atoi(m)));    // align against a target made of posed scans: 1 = through the scans' grids, 0 = culled kernel
   if (const char *m = std::getenv("MVR_RING_SEARCH")) c->ring_search = std::atoi(m);   // fused pass: 1 = grid search for bounded queries, 0 = culled kernel only
   if (const char *m = std::getenv("MVR_INPLACE_RATIO")) c->inplace_ratio = std::atoi(m);
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
@@ -723,6 +723,7 @@ API int mvr_cloud_append(mvr_ctx *ctx, int dst, int src)
   if (int rc = cloud_reserve(c, d, d.n + add, true)) return rc;
   const Cloud &s = c->slots[src];
   if (add) {
+    d.mgrid_ok = false;
     ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)add);
     MVR_HIP_TRY(c, hipMemcpyAsync(d.pts + d.n, s.pts, add * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     // a different point set.  Its ordering: the old one extended by the appended scan's own (the points that were
@@ -2130,6 +2131,59 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
   }
   // seq_search 2: forward through the parts' grids (measured slower)
   const bool through_parts = parts_forward && c->seq_search == 2;
+  // seq_search 3: forward through ONE grid over the model's own coordinates (Cloud::mgrid): the thread-per-query walk, then the
+  // wide bounded queries a wave each and the flagged 64-query sets a block each, as a fused pass's forward searches
+  bool model_ok = false;
+  if (c->seq_search == 3 && !through_parts) { if (int rc = ensure_model_grid(c, tgt, max_dist + 0.5, &model_ok)) return rc; }
+  if (model_ok) {
+    if (!c->bwide_count) {
+      MVR_MAY_BLOCK(c, "the wide-query counters are not allocated yet");
+      MVR_HIP_TRY(c, hipMalloc(&c->bwide_count, 3 * kWideCounters * sizeof(uint32_t)));
+      MVR_HIP_TRY(c, hipMemsetAsync(c->bwide_count, 0, 3 * kWideCounters * sizeof(uint32_t), c->stream));
+    }
+    if (int rc = ensure(c, c->bwide, c->bwide_cap, std::max(ns, std::min(ns, nt)))) return rc;
+    if (int rc = ensure(c, c->bcull_sets, c->bcull_sets_cap, ns / 64 + 2)) return rc;
+    GridPair f = make_model_pair(cur, tgt, c->keys);
+    f.qbound = qb;
+    f.heavy = c->bheavy;
+    f.wide_list = c->bwide; f.wide_count = c->bwide_count + kWideCounters - 2;
+    f.cull_sets = c->bcull_sets; f.cull_count = c->bwide_count + 2 * kWideCounters + kWideCounters - 1;
+    MVR_HIP_TRY(c, hipMemsetAsync(f.wide_count, 0, sizeof(uint32_t), c->stream));
+    MVR_HIP_TRY(c, hipMemsetAsync(f.cull_count, 0, sizeof(uint32_t), c->stream));
+    if (int rc = launch_nn_grid_batch(c, &f, 1, cap2, fma)) return rc;
+    if (c->grid_debug) {           // diagnostics: how many queries left the thread-per-query walk
+      std::vector<uint8_t> hv(ns); uint32_t wc = 0, sc = 0;
+      MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      MVR_HIP_TRY(c, hipMemcpy(hv.data(), c->bheavy, ns, hipMemcpyDeviceToHost));
+      MVR_HIP_TRY(c, hipMemcpy(&wc, f.wide_count, 4, hipMemcpyDeviceToHost));
+      MVR_HIP_TRY(c, hipMemcpy(&sc, f.cull_count, 4, hipMemcpyDeviceToHost));
+      size_t fl = 0;
+      for (size_t i = 0; i < ns; ++i) fl += hv[i];
+      if (qb) {
+        std::vector<uint32_t> sbv(ns);
+        MVR_HIP_TRY(c, hipMemcpy(sbv.data(), qb, ns * 4, hipMemcpyDeviceToHost));
+        size_t z = 0, in = 0, out = 0, none = 0, fz = 0, fin = 0, fout = 0, fnone = 0;
+        uint32_t capb; std::memcpy(&capb, &cap2, 4);
+        for (size_t i = 0; i < ns; ++i) {
+          const uint32_t v = sbv[i];
+          if (v == 0) { ++z; fz += hv[i]; } else if (v == 0xFFFFFFFFu) { ++none; fnone += hv[i]; } else if (v <= capb) { ++in; fin += hv[i]; } else { ++out; fout += hv[i]; }
+        }
+        std::fprintf(stderr, "[model]   start bounds: %zu zero (%zu flagged), %zu within the cap (%zu), %zu beyond (%zu), %zu none (%zu)\n", z, fz, in, fin, out, fout, none, fnone);
+      }
+      std::fprintf(stderr, "[model] nt %zu, h %.3f, dim %d x %d x %d, %zu queries (%s): %u to a wave each, %zu flagged in %u sets\n", nt, tgt.mgrid->h, tgt.mgrid->dim[0], tgt.mgrid->dim[1],
+                   tgt.mgrid->dim[2], ns, qb ? "seeded" : "no seeds", wc, fl, sc);
+    }
+    if (c->seq_model_tail == 0) { if (int rc = launch_nn_grid_tail_batch(c, &f, 1, cap2, fma)) return rc; }
+    else {
+      // the wide bounded queries a wave each; the flagged sets through the culled kernel over the model's composite ordering
+      // (its box hierarchy throws out the sets that have nothing within the cap at once), keys by sorted position, then merged
+      if (int rc = launch_nn_grid_wide_batch(c, &f, 1, cap2, fma)) return rc;
+      CullPair p = make_cull_pair(cur, 0, ns, c->bheavy, tgt, c->rkeys);
+      p.qbound = qb; p.setlist = f.cull_sets; p.setcount = f.cull_count;
+      if (int rc = launch_nn_cull_list_batch(c, &p, 1, cap2, fma)) return rc;
+      if (int rc = launch_merge_flagged_keys(c, cur.sorted, c->bheavy, c->rkeys, ns, c->keys)) return rc;
+    }
+  } else
   if (!through_parts) {
     // forward: the culled kernel over the target's composite index (keys are written by exactly one wave per query)
     CullPair fp = make_cull_pair(cur, 0, ns, nullptr, tgt, c->keys);
@@ -2590,7 +2644,9 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "lazy_super")) { if (value < 0 || value > 1) return MVR_E_ARG; c->lazy_super = value; }
   else if (!std::strcmp(key, "fused_mark")) { if (value < 0 || value > 2) return MVR_E_ARG; c->fused_mark = value; }
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
-  else if (!std::strcmp(key, "seq_search")) { if (value < 0 || value > 2) return MVR_E_ARG; c->seq_search = value; }
+  else if (!std::strcmp(key, "seq_search")) { if (value < 0 || value > 3) return MVR_E_ARG; c->seq_search = value; }
+  else if (!std::strcmp(key, "seq_model_tail")) { if (value < 0 || value > 1) return MVR_E_ARG; c->seq_model_tail = value; }
+  else if (!std::strcmp(key, "seq_cell_points")) { if (value < 1) return MVR_E_ARG; c->seq_cell_points = value; }
   else if (!std::strcmp(key, "seq_seed")) {          // 0 also forgets what the aligns so far have left behind
     c->seq_seed = value != 0;
     if (!c->seq_seed) {

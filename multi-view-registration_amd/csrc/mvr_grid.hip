@@ -1297,6 +1297,73 @@ bool ensure_grid(Ctx *c, Cloud &canon, double reach)
   return canon.grid != nullptr && canon.grid->n == canon.n;
 }
 
+// ---- the grid of a cloud over its OWN coordinates: the growing model of the sequential mode (`*target += aligned source`,
+// registrator.cpp:576) searched as ONE point set -- one walk per query, where the part-by-part search (nn_parts_kernel) walks a
+// ball in each of the ~5 merged scans that cover a query's surface.  Compact form (segment directory + records), points in grid
+// order with w = the point's index in the cloud: the keys of a walk over it are the keys of a search of the merged cloud.
+int ensure_model_grid(Ctx *c, Cloud &t, double reach, bool *ok)
+{
+  *ok = false;
+  if (t.n < 4 || t.n > 0x7FFFFFF0ull || !t.segs.empty() || t.pts_stale) return MVR_OK;
+  if (t.mgrid && t.mgrid_ok && t.mgrid->n == t.n) { *ok = true; return MVR_OK; }
+  t.mgrid.reset(); t.mgrid_ok = false;
+  MVR_MAY_BLOCK(c, "the model has no grid yet");
+  float bb[6];
+  if (int rc = cloud_bbox(c, t.pts, t.n, bb)) return rc;
+  auto g = std::make_shared<CellGrid>();
+  g->n = t.n;
+  double ext[3];
+  for (int j = 0; j < 3; ++j) { g->lo[j] = bb[j]; ext[j] = std::max(1e-6, (double)bb[3 + j] - (double)bb[j]); }
+  const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2];
+  double h = std::sqrt((double)std::max(1, c->seq_cell_points) * area / (double)t.n);
+  h = std::max(h, std::max(ext[0], std::max(ext[1], ext[2])) / 512.0);
+  for (;;) {
+    double cells = 1.0;
+    for (int j = 0; j < 3; ++j) { g->dim[j] = (int)std::floor(ext[j] / h) + 1; cells *= g->dim[j]; }
+    if (cells <= 32.0e6) break;
+    h *= 1.25;
+  }
+  g->h = (float)h; g->inv_h = (float)(1.0 / h);
+  const size_t cells = (size_t)g->dim[0] * g->dim[1] * g->dim[2], n = t.n;
+  g->nseg = (uint32_t)((cells + 1 + 31) / 32);
+  g->dt_shift = 1;
+  for (int j = 0; j < 3; ++j) g->dtdim[j] = (g->dim[j] + 1) >> 1;
+  const size_t cells2 = (size_t)g->dtdim[0] * g->dtdim[1] * g->dtdim[2], max_slots = std::min(n, (size_t)g->nseg + 1) + 1;
+  const size_t o_dir = 0, o_recs = o_dir + align256(((size_t)g->nseg + 2) * 4), o_gperm = o_recs + align256(max_slots * 32 * 4), o_graw = o_gperm + align256(n * 4),
+               o_dt = o_graw + align256((n + 4) * sizeof(float4)), total = o_dt + align256(cells2);
+  if (hipMalloc(&g->block, total) != hipSuccess) { (void)hipGetLastError(); return set_error(c, MVR_E_NOMEM, "model grid: out of device memory"); }
+  g->dir = reinterpret_cast<uint32_t *>(g->block + o_dir); g->recs = reinterpret_cast<uint32_t *>(g->block + o_recs);
+  g->gperm = reinterpret_cast<uint32_t *>(g->block + o_gperm); g->graw = reinterpret_cast<float4 *>(g->block + o_graw);
+  g->dt = reinterpret_cast<uint8_t *>(g->block + o_dt);
+  const int steps2 = (int)std::ceil(std::max(0.0, reach) / (2.0 * h)) + 2;
+  g->dt_steps = std::min(kGridDtMax, std::max(2, steps2));
+  std::vector<Cloud *> cc{&t}; std::vector<std::shared_ptr<CellGrid> > cg{g};
+  if (int rc = build_compact_grids(c, cc, cg, c->stream)) return rc;
+  if (!c->scratch_event) MVR_HIP_TRY(c, hipEventCreateWithFlags(&c->scratch_event, hipEventDisableTiming));
+  MVR_HIP_TRY(c, hipEventRecord(c->scratch_event, c->stream));
+  c->scratch_stream = c->stream;
+  t.mgrid = g; t.mgrid_ok = true;
+  *ok = true;
+  return MVR_OK;
+}
+
+// the forward searches of q's Hilbert-ordered points in t's model grid: keys by the query's ORIGINAL index, low word = the match's
+// index in t (what the culled kernel over t's composite ordering leaves)
+GridPair make_model_pair(const Cloud &q, const Cloud &t, nnkey_t *keys)
+{
+  GridPair p;
+  const CellGrid &g = *t.mgrid;
+  p.qs = q.sorted; p.q_begin = 0; p.q_count = (uint32_t)q.n;
+  p.gts = g.graw; p.ts = t.sorted; p.start = g.start; p.dir = g.dir; p.recs = g.recs; p.dt_shift = g.dt_shift;
+  for (int k = 0; k < 3; ++k) { p.dtdim[k] = g.dtdim[k]; p.lo[k] = g.lo[k]; p.dim[k] = g.dim[k]; }
+  p.dt = g.dt; p.dt_max = g.dt_steps; p.inv_h = g.inv_h; p.h = g.h;
+  p.tinv = t.order ? t.order->inv : nullptr;
+  p.stretch = std::nextafterf(1.000001f, INFINITY);      // (the grid lies in the frame the queries are in: the identity map)
+  p.nt = (uint32_t)t.n;
+  p.keys = keys;
+  return p;
+}
+
 // posed copies: coordinates in grid order (and the grid-position -> Hilbert-position map, once per ordering)
 int grid_coords_prepare(Ctx *c, Cloud *cl, bool *ok)
 {

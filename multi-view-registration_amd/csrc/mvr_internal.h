@@ -122,7 +122,7 @@ struct Cloud {
   bool super_stale = false;            // sbox[] was NOT refreshed with the tile boxes (a posed copy about to be searched over its grid): flush_super_boxes() before a culled launch
   bool coords_valid = false;           // sorted[] / tlo / thi / cbox match pts[]
   size_t fresh_tiles = 0;              // with !coords_valid: that many LEADING tiles of sorted[] / boxes are still current (a cloud that only grew at its end: mvr_cloud_append with an extended ordering); any other change of the coordinates resets it
-  void stale_coords() { coords_valid = false; fresh_tiles = 0; gcoords_valid = false; }
+  void stale_coords() { coords_valid = false; fresh_tiles = 0; gcoords_valid = false; mgrid_ok = false; }
   // optional unit normals {nx,ny,nz,0} (point-to-plane extension, K10)
   float4 *nrm = nullptr; size_t nrm_cap = 0;
   bool has_normals = false;
@@ -135,6 +135,8 @@ struct Cloud {
   std::shared_ptr<CellGrid> grid;          // the set's grid (shared)
   float4 *gsorted = nullptr; size_t gsorted_cap = 0;      // posed coordinates in grid order, w = bits(original index)
   bool gcoords_valid = false;          // gsorted matches pts
+  std::shared_ptr<CellGrid> mgrid;     // a grid over THESE coordinates (the sequential mode's model searched as one point set: ensure_model_grid), valid while mgrid_ok
+  bool mgrid_ok = false;
   // pipelined ring run (mvr_ctx.hip: ring_passes): where the kernels of a pass that is enqueued BEFORE its poses are known
   // find this posed copy's pose, inverse and stretch (device memory, filled by pose_prep_kernel once the host's solve has
   // released the pass); null outside such a run
@@ -211,6 +213,8 @@ struct Ctx {
   struct SeedBuf { uint32_t *d = nullptr; size_t n = 0, cap = 0; };
   std::unordered_map<unsigned long long, SeedBuf> seq_seeds;      // by the source's point-set id
   uint32_t *seed_bound = nullptr; size_t seed_bound_cap = 0;
+  int seq_model_tail = 1;                             // seq_search 3: the flagged query sets go 1 = to the culled kernel (listed sets), 0 = to the grid's set kernel
+  int seq_cell_points = 4;                            // points per occupied cell the MODEL's grid aims at (seq_search 3)
   int seq_search = 1;                                 // mvr_icp_align of a posed scan: 1 (default) = the REVERSE searches walk the source scan's cell grid (compaction by the fused pass's kernels, no hipCUB), the forward search stays with the culled kernel; 2 = the forward search too, through the grids of the posed scans the target is made of (nn_parts_kernel: exact, measured slower -- DESIGN.md 4.5); 0 = the culled kernel for both
   int parts_lanes = 0, parts_max_rows = 25;           // nn_parts_kernel: lanes per query (1, 2, 4, 8; 0 = by the number of parts) and the widest ball (rows of cells) a lane walks itself
   int ring_search = 1;                                // fused pass: 1 = seeded searches walk the uniform grid (thread per query), 0 = always the culled kernel
@@ -617,6 +621,8 @@ int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
 // coordinates; false = not available (the caller uses the culled kernel)
 int cloud_bbox(Ctx *c, const float4 *pts, size_t n, float out[6]);      // {lo xyz, hi xyz} on the host (synchronises the stream)
 bool ensure_grid(Ctx *c, Cloud &canon, double reach);
+int ensure_model_grid(Ctx *c, Cloud &t, double reach, bool *ok);      // the grid of a cloud over its own coordinates (Cloud::mgrid)
+GridPair make_model_pair(const Cloud &q, const Cloud &t, nnkey_t *keys);
 int ensure_grids(Ctx *c, Cloud *const *canon, int count, double reach, hipStream_t on, hipEvent_t after);      // the same for many sets at once, enqueued on `on` (no wait afterwards)      // reach: the search radius the distance map should be able to rule out (mm)
 int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
 int ensure_pose_table(Ctx *c);      // (mvr_ctx.hip) fills the device pose records of the chain being enqueued if nobody has yet

@@ -26,7 +26,7 @@ def pytest_collection_modifyitems(config, items):
     (`pytest tests/test_gpu_world.py`).  The library itself needs no import order to WORK (the `gpu` fixture does not touch
     torch), but a process that first runs a collective through the library's RCCL and only then imports torch aborts at
     interpreter exit ("double free or corruption", after every test has passed: the two runtimes' exit handlers run in
-    the wrong order; tools/scratch/bisect2.sh), so the tests that count devices with torch must not be
+    the wrong order; tools/exit_abort_bisect.sh), so the tests that count devices with torch must not be
     the ones that import it."""
     if any(it.get_closest_marker("gpu") is not None for it in items):
         import time

@@ -189,7 +189,7 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
         kw = dict(max_dist=40.0, max_iter=1000)
     params = mvr.icp_params(**kw)
     runs = []
-    for mode in (0, 1, 2):           # culled both ways; reverse over the source's grid (default); forward through the parts as well
+    for mode in (0, 1, 2, 3):        # culled both ways; reverse over the source's grid (default); forward through the parts as well; forward through ONE grid over the model
         with mvr.Context(0) as ctx:
             ctx.tune(seq_search=mode)
             for v in range(V):
@@ -206,7 +206,7 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
     # the matches of the sweep before) -- three sweeps, so that seeds left by seeded searches are used as well
     seeded = []
     # (last arm: the iteration's row fetched by a copy and a synchronise instead of stored to the host by the sums launch itself, align_spin 0)
-    for seed, mode, spin in ((1, 1, 1), (0, 1, 1), (1, 2, 1), (1, 0, 1), (1, 1, 0)):      # (the seeds serve the culled kernel and the walk through the parts' grids alike)
+    for seed, mode, spin in ((1, 1, 1), (0, 1, 1), (1, 2, 1), (1, 0, 1), (1, 1, 0), (1, 3, 1), (0, 3, 1)):      # (the seeds serve the culled kernel and the walk through the parts' grids alike)
         with mvr.Context(0) as ctx:
             ctx.tune(seq_seed=seed, seq_search=mode, align_spin=spin, lazy_super=spin)
             for v in range(V):
