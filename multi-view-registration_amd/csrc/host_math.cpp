@@ -814,47 +814,65 @@ API int mvr_lum_compute(int n, int ne, const int *es, const int *et, const mvr_p
   if (n < 2 || ne < 0 || !es || !et || !m2 || !poses) return MVR_E_ARG;
   for (int e = 0; e < ne; ++e) if (es[e] < 0 || es[e] >= n || et[e] < 0 || et[e] >= n) return MVR_E_ARG;
   const int dim = 6 * (n - 1);
-  std::vector<double> G, B(dim), cinv((size_t)ne * 36), cinvd((size_t)ne * 6);      // (G: the dense matrix, only if the dense route runs)
-  // edge between an (unordered) vertex pair, looked up once: first as (s, t), then as (t, s)
-  std::vector<int> eidx((size_t)n * n, -1);
-  std::vector<char> efwd((size_t)n * n, 0);
-  for (int vi = 0; vi < n; ++vi)
-    for (int vj = 0; vj < n; ++vj) {
-      int e = -1; bool fwd = false;
-      for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vi && et[k] == vj) { e = k; fwd = true; }
-      for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vj && et[k] == vi) e = k;
-      eidx[(size_t)vi * n + vj] = e; efwd[(size_t)vi * n + vj] = fwd;
-    }
-  // structure of G (the same in every iteration): block row vi - 1 reaches as far as its highest neighbour
-  std::vector<int> row_end((size_t)dim, 0);
-  for (int vi = 1; vi < n; ++vi) {
-    int hi = vi;
-    for (int vj = 1; vj < n; ++vj) if (eidx[(size_t)vi * n + vj] >= 0) hi = std::max(hi, vj);
-    for (int r = 0; r < 6; ++r) row_end[6 * (vi - 1) + r] = 6 * hi;
-  }
-  // a ring or a chain (every neighbour of a view is the next or the previous one, or the fixed view 0): the upper rows of G
-  // reach 12 entries from the diagonal at most -- assembled and factorised on band storage (solve_spd_band)
+  // Everything that depends on the graph alone -- who is whose neighbour, the structure of G, which solver runs -- and every work
+  // array are kept from call to call (per thread): a registration calls this once per pass with the same views and edges, on the
+  // critical path between two passes (the GPU waits for the poses), and looking the edges up and allocating a dozen vectors was
+  // ~25 us of a 53 us call.  The arithmetic is untouched.
+  struct Nbr { int vj, e; double sign; };
+  struct Plan {
+    int n = -1, ne = -1; std::vector<int> es, et;
+    std::vector<double> G, B, cinv, cinvd, Dc, Oc, band, bscratch, Tv;
+    std::vector<int> eidx, row_end; std::vector<char> efwd;
+    std::vector<std::vector<Nbr>> nbrs;
+    std::vector<PoseTrig> trig;
+    bool banded = false, chain = false;
+  };
+  static thread_local Plan plan;
   constexpr int kBandW = 12;
-  int reach = 0;
-  for (int j = 0; j < dim; ++j) reach = std::max(reach, row_end[(size_t)j] - j);
   static const bool force_dense = std::getenv("MVR_LUM_DENSE") != nullptr;       // (tests: the two row-wise routes give the same bits)
   static const bool force_band = std::getenv("MVR_LUM_BAND") != nullptr;         // (tests: the block route agrees with them to rounding)
-  const bool banded = reach <= kBandW && !force_dense;
-  const bool chain = banded && !force_band && n >= 2;                            // (reach <= 12: a view's neighbours are the next, the previous and view 0)
-  // every view's edges in ascending order of the neighbour (the order all three assemblies add the diagonal blocks up in)
-  struct Nbr { int vj, e; double sign; };
-  std::vector<std::vector<Nbr>> nbrs((size_t)n);
-  for (int vi = 1; vi < n; ++vi)
-    for (int vj = 0; vj < n; ++vj) {
-      const int e = eidx[(size_t)vi * n + vj];
-      if (e >= 0) nbrs[(size_t)vi].push_back(Nbr{vj, e, efwd[(size_t)vi * n + vj] ? 1.0 : -1.0});
+  const bool same_graph = plan.n == n && plan.ne == ne && std::equal(es, es + ne, plan.es.begin()) && std::equal(et, et + ne, plan.et.begin());
+  if (!same_graph) {
+    plan.n = n; plan.ne = ne; plan.es.assign(es, es + ne); plan.et.assign(et, et + ne);
+    // edge between an (unordered) vertex pair, looked up once: first as (s, t), then as (t, s)
+    plan.eidx.assign((size_t)n * n, -1); plan.efwd.assign((size_t)n * n, 0);
+    for (int vi = 0; vi < n; ++vi)
+      for (int vj = 0; vj < n; ++vj) {
+        int e = -1; bool fwd = false;
+        for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vi && et[k] == vj) { e = k; fwd = true; }
+        for (int k = 0; k < ne && e < 0; ++k) if (es[k] == vj && et[k] == vi) e = k;
+        plan.eidx[(size_t)vi * n + vj] = e; plan.efwd[(size_t)vi * n + vj] = fwd;
+      }
+    // structure of G (the same in every iteration): block row vi - 1 reaches as far as its highest neighbour
+    plan.row_end.assign((size_t)dim, 0);
+    for (int vi = 1; vi < n; ++vi) {
+      int hi = vi;
+      for (int vj = 1; vj < n; ++vj) if (plan.eidx[(size_t)vi * n + vj] >= 0) hi = std::max(hi, vj);
+      for (int r = 0; r < 6; ++r) plan.row_end[6 * (vi - 1) + r] = 6 * hi;
     }
-  std::vector<double> Dc, Oc;
-  if (chain) { Dc.resize((size_t)(n - 1) * 48 + 8); Oc.resize((size_t)std::max(n - 2, 1) * 48 + 8); }      // (blocks of 6 rows of 8: solve_chain6)
-  std::vector<double> band, bscratch;
-
-  std::vector<double> Tv((size_t)n * 16);
-  std::vector<PoseTrig> trig((size_t)n);
+    // a ring or a chain (every neighbour of a view is the next or the previous one, or the fixed view 0): the upper rows of G
+    // reach 12 entries from the diagonal at most -- assembled and factorised on band storage (solve_spd_band)
+    int reach = 0;
+    for (int j = 0; j < dim; ++j) reach = std::max(reach, plan.row_end[(size_t)j] - j);
+    plan.banded = reach <= kBandW && !force_dense;
+    plan.chain = plan.banded && !force_band && n >= 2;                            // (reach <= 12: a view's neighbours are the next, the previous and view 0)
+    // every view's edges in ascending order of the neighbour (the order all three assemblies add the diagonal blocks up in)
+    plan.nbrs.assign((size_t)n, std::vector<Nbr>());
+    for (int vi = 1; vi < n; ++vi)
+      for (int vj = 0; vj < n; ++vj) {
+        const int e = plan.eidx[(size_t)vi * n + vj];
+        if (e >= 0) plan.nbrs[(size_t)vi].push_back(Nbr{vj, e, plan.efwd[(size_t)vi * n + vj] ? 1.0 : -1.0});
+      }
+    plan.B.assign((size_t)dim, 0.0); plan.cinv.assign((size_t)ne * 36, 0.0); plan.cinvd.assign((size_t)ne * 6, 0.0);
+    plan.Dc.clear(); plan.Oc.clear();
+    if (plan.chain) { plan.Dc.resize((size_t)(n - 1) * 48 + 8); plan.Oc.resize((size_t)std::max(n - 2, 1) * 48 + 8); }      // (blocks of 6 rows of 8: solve_chain6)
+    plan.Tv.assign((size_t)n * 16, 0.0); plan.trig.assign((size_t)n, PoseTrig());
+  }
+  std::vector<double> &G = plan.G, &B = plan.B, &cinv = plan.cinv, &cinvd = plan.cinvd, &Dc = plan.Dc, &Oc = plan.Oc, &band = plan.band, &bscratch = plan.bscratch, &Tv = plan.Tv;
+  const std::vector<int> &eidx = plan.eidx, &row_end = plan.row_end; const std::vector<char> &efwd = plan.efwd;
+  const std::vector<std::vector<Nbr>> &nbrs = plan.nbrs;
+  std::vector<PoseTrig> &trig = plan.trig;
+  const bool banded = plan.banded, chain = plan.chain;
   int it = 0;
   for (; it < max_iterations; ++it) {
     for (int v = 0; v < n; ++v) { trig[(size_t)v] = pose_trig(poses + 6 * v); pose_to_mat4_trig(poses + 6 * v, trig[(size_t)v], &Tv[(size_t)v * 16]); }
@@ -960,7 +978,8 @@ API int mvr_ring_host_step(int n_views, int ne, const int *es, const int *et, co
                            int *lum_iters)
 {
   if (n_views < 2 || ne < 0 || !es || !et || !rows || !origin || !poses || !lum_pose) return MVR_E_ARG;
-  std::vector<mvr_pair_moments2_t> m2((size_t)ne);
+  static thread_local std::vector<mvr_pair_moments2_t> m2;      // (kept from call to call: this runs between two passes, the GPU waiting)
+  m2.resize((size_t)ne);
   for (int e = 0; e < ne; ++e) {
     std::memcpy(&m2[e], rows + 32 * (size_t)e, sizeof(mvr_pair_moments2_t));
     for (int k = 0; k < 3; ++k) m2[e].origin[k] = origin[k];     // a constant, not a sum over ranks

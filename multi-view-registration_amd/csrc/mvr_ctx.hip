@@ -1811,6 +1811,7 @@ struct RingRun {
   mvr_ctx *ctx; int n_views; const int *posed_slots, *raw_slots; int ne; const int *edge_src, *edge_tgt; double max_dist; int reciprocal, fma;
   const double *origin; int lum_iterations; double *poses, *lum_pose; float *pair_T; double *pair_n, *pair_mse; int *lum_iters; double *rows;
   std::vector<int> ss, ts; std::vector<double> pn, pm, h;
+  int passes_left = 1;      // the per-pair transformations (a 3 x 3 SVD per edge: 6 us between two passes, the GPU waiting) are only computed for the LAST pass of the run -- the one the caller's pair_T describes
   static int enqueue(void *p)
   {
     RingRun &r = *static_cast<RingRun *>(p);
@@ -1839,7 +1840,7 @@ struct RingRun {
     Ctx *c = CTX(r.ctx);
     r.h.assign(c->h_table, c->h_table + (size_t)r.ne * 32);
     if (r.rows && r.ne) std::memcpy(r.rows, r.h.data(), r.h.size() * sizeof(double));
-    const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, r.h.data(), r.origin, r.lum_iterations, r.poses, r.lum_pose, r.pair_T,
+    const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, r.h.data(), r.origin, r.lum_iterations, r.poses, r.lum_pose, --r.passes_left <= 0 ? r.pair_T : nullptr,
                                       r.pair_n ? r.pair_n : r.pn.data(), r.pair_mse ? r.pair_mse : r.pm.data(), r.lum_iters);
     return rc != MVR_OK ? set_error(c, rc, "LUM solve") : MVR_OK;
   }
@@ -1864,6 +1865,7 @@ API int mvr_ring_run(mvr_ctx *ctx, int n_steps, int n_views, const int *posed_sl
   RingRun r{ctx, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin, lum_iterations, poses, lum_pose, pair_T,
             pair_n, pair_mse, lum_iters, rows, {}, {}, {}, {}, {}};
   r.ss.resize((size_t)ne); r.ts.resize((size_t)ne); r.pn.resize((size_t)ne); r.pm.resize((size_t)ne);
+  r.passes_left = n_steps;
   for (int e = 0; e < ne; ++e) { r.ss[(size_t)e] = posed_slots[edge_src[e]]; r.ts[(size_t)e] = posed_slots[edge_tgt[e]]; }
   PassLoop L;
   L.n_views = n_views; L.posed_slots = posed_slots; L.raw_slots = raw_slots; L.poses = poses;

@@ -434,6 +434,7 @@ struct RankRun {
   int lum_iterations; double *poses, *lum_pose; float *pair_T; double *pair_n, *pair_mse; int *lum_iters; double *rows;
   std::vector<double> pn, pm;
   int rank = 0, world = 1;
+  int passes_left = 1;      // (pair_T only for the last pass of the run: RingRun, mvr_ctx.hip)
   static int enqueue(void *p)
   {
     RankRun &r = *static_cast<RankRun *>(p);
@@ -476,7 +477,7 @@ struct RankRun {
       return set_error(c, MVR_E_RCCL, "a peer's local work failed in this pass");
     }
     if (r.rows && r.ne) std::memcpy(r.rows, c->h_table, (size_t)r.ne * 32 * sizeof(double));
-    const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, c->h_table, r.origin, r.lum_iterations, r.poses, r.lum_pose, r.pair_T,
+    const int rc = mvr_ring_host_step(r.n_views, r.ne, r.edge_src, r.edge_tgt, c->h_table, r.origin, r.lum_iterations, r.poses, r.lum_pose, --r.passes_left <= 0 ? r.pair_T : nullptr,
                                       r.pair_n ? r.pair_n : r.pn.data(), r.pair_mse ? r.pair_mse : r.pm.data(), r.lum_iters);
     return rc != MVR_OK ? set_error(c, rc, "LUM solve") : MVR_OK;
   }
@@ -504,6 +505,7 @@ API int mvr_ring_run_sharded(mvr_ctx *ctx, int n_steps, int n_views, const int *
   // the tables (the passes themselves report later failures through the collective, see RankRun::enqueue)
   RankRun run{ctx, RankPlan(), n_views, ne, edge_src, edge_tgt, max_dist, reciprocal, fma, origin, lum_iterations, poses, lum_pose, pair_T,
               pair_n, pair_mse, lum_iters, rows, std::vector<double>((size_t)ne), std::vector<double>((size_t)ne), rank, world};
+  run.passes_left = n_steps;
   if (int rc = make_rank_plan(ctx, rank, world, n_views, posed_slots, raw_slots, ne, edge_src, edge_tgt, &run.plan)) return rc;
   if (int rc = ensure_tables(c, ne + 1)) return rc;
   PassLoop L;
