@@ -781,7 +781,10 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
 // contiguous range of the grid-ordered array each), their lengths prefix-summed, and the candidates -- a few hundred
 // for a 4 mm ball -- shared out evenly: lane l takes candidates l, l + 64, ...  (a thread walking them alone would hold
 // its whole wave up: a wave is as slow as its slowest lane).
-constexpr int kWideWaves = 4;      // waves per block
+#ifndef MVR_TAIL_WAVES
+#define MVR_TAIL_WAVES 4
+#endif
+constexpr int kWideWaves = MVR_TAIL_WAVES;      // waves per block of the stragglers' launches (wide queries: a wave each; listed sets: a block each)
 template <bool FMA>
 __device__ __forceinline__ void nn_grid_wide_body(const GridBatch &batch, unsigned long long *__restrict__ evals, const uint32_t bx, const uint32_t nbx)
 {
@@ -1511,7 +1514,10 @@ __global__ void __launch_bounds__(64 * kWideWaves) nn_grid_wide_kernel(GridBatch
 // (lane = query; a broadcast LDS read feeds 64 evaluations).  Same bounds (inclusive), same distances, same
 // (d2, original index) minimum: the keys the culled kernel would have written.
 constexpr int kSetRows = 512;        // rows of cells staged per round
-constexpr int kSetPoints = 768;      // points staged per round (the shared arrays stay under 20 KB: eight blocks per CU)
+#ifndef MVR_SET_POINTS
+#define MVR_SET_POINTS (MVR_TAIL_WAVES == 8 ? 1024 : 768)
+#endif
+constexpr int kSetPoints = MVR_SET_POINTS;      // points staged per round (768 with four waves: the shared arrays stay under 20 KB, eight blocks per CU)
 template <bool FMA>
 __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigned long long *__restrict__ evals, const uint32_t bx, const uint32_t nbx)
 {
@@ -1519,9 +1525,10 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
   if (!a.cull_count) return;
   __shared__ float4 lq[64];                       // query (x, y, z, bound as bits)
   __shared__ int ubox[8];
-  __shared__ uint32_t rs[kSetRows], roff[kSetRows + 1], wtot[4];
+  constexpr int W = kWideWaves, kThreads = 64 * W, kRowsPer = (kSetRows + kThreads - 1) / kThreads;
+  __shared__ uint32_t rs[kSetRows], roff[kSetRows + 1], wtot[W];
   __shared__ float4 lpts[kSetPoints];
-  __shared__ unsigned long long lbest[4][64];
+  __shared__ unsigned long long lbest[W][64];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const float cap2 = batch.cap2;
   const uint32_t n_sets = *a.cull_count;
@@ -1576,7 +1583,7 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
         const int nr = min(kSetRows, rows - r0);
         // ---- the rows' ranges, and where each begins in the staged list (block-wide exclusive scan of the lengths)
         uint32_t mine = 0;
-        for (int r = t * 2; r < min(nr, t * 2 + 2); ++r) {
+        for (int r = t * kRowsPer; r < min(nr, t * kRowsPer + kRowsPer); ++r) {
           const int rr = r0 + r;
           const uint32_t row = (uint32_t)(((Z0 + rr / ny) * a.dim[1] + (Y0 + rr % ny)) * a.dim[0]);
           const uint32_t s = cell_start_of(a, row + (uint32_t)X0), e = cell_start_of(a, row + (uint32_t)X1 + 1u);
@@ -1590,8 +1597,10 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
         __syncthreads();
         uint32_t before = incl - mine;
         for (int w = 0; w < wv; ++w) before += wtot[w];
-        const uint32_t total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        for (int r = t * 2; r < min(nr, t * 2 + 2); ++r) { const uint32_t len = roff[r]; roff[r] = before; before += len; }
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) total += wtot[w];
+        for (int r = t * kRowsPer; r < min(nr, t * kRowsPer + kRowsPer); ++r) { const uint32_t len = roff[r]; roff[r] = before; before += len; }
         if (t == 0) roff[nr] = total;
         __syncthreads();
         // ---- stage the points of those ranges, kSetPoints at a time, and evaluate: wave w takes every fourth point
@@ -1600,8 +1609,8 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
           // (one staged point per thread and round, its row found by bisection of the offsets: independent loads, all in
           // flight at once -- a thread copying its rows point after point waited for every one of them)
 #pragma unroll
-          for (int u = 0; u < kSetPoints / 256; ++u) {
-            const uint32_t j = base + (uint32_t)(u * 256 + t);
+          for (int u = 0; u < kSetPoints / kThreads; ++u) {
+            const uint32_t j = base + (uint32_t)(u * kThreads + t);
             if (j - base < cnt) {
               int lo = 0, hi = nr - 1;
               while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (roff[mid] <= j) lo = mid; else hi = mid - 1; }
@@ -1610,8 +1619,8 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
           }
           __syncthreads();
           uint32_t j = (uint32_t)wv;
-          for (; j + 4u < cnt; j += 8u) {            // two points in flight
-            const float4 p0 = lpts[j], p1 = lpts[j + 4u];
+          for (; j + (uint32_t)W < cnt; j += 2u * W) {            // two points in flight
+            const float4 p0 = lpts[j], p1 = lpts[j + (uint32_t)W];
             const unsigned long long k0 = ((unsigned long long)__float_as_uint(gdist2<FMA>(p0, mq.x, mq.y, mq.z)) << 32) | __float_as_uint(p0.w);
             const unsigned long long k1 = ((unsigned long long)__float_as_uint(gdist2<FMA>(p1, mq.x, mq.y, mq.z)) << 32) | __float_as_uint(p1.w);
             const unsigned long long k = k0 < k1 ? k0 : k1;
@@ -1633,7 +1642,7 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
     if (wv == 0 && valid) {
       unsigned long long m = lbest[0][lane];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) { const unsigned long long v = lbest[w][lane]; m = v < m ? v : m; }
+      for (int w = 1; w < W; ++w) { const unsigned long long v = lbest[w][lane]; m = v < m ? v : m; }
       const uint32_t bi = (uint32_t)m;
       const bool found = bi != kNone && __uint_as_float((uint32_t)(m >> 32)) <= cap2;
       const uint32_t ord = a.key_by_pos ? qpos : __float_as_uint(q.w);
@@ -1649,23 +1658,23 @@ __device__ __forceinline__ void nn_grid_set_body(const GridBatch &batch, unsigne
     __syncthreads();                                // lq / ubox / lbest are reused by the next set
   }
   if (evals && lane == 0 && n_eval) {
-    unsigned long long *sh = evals + (size_t)((bx * 4u + (uint32_t)wv) & (kEvalShards - 1)) * kEvalStride;
-    atomicAdd(sh, n_eval * 16ull);      // every staged point is evaluated by the 64 lanes of one of the four waves
-    atomicAdd(sh + kEvalRegion, n_eval * 16ull);
+    unsigned long long *sh = evals + (size_t)((bx * (uint32_t)W + (uint32_t)wv) & (kEvalShards - 1)) * kEvalStride;
+    atomicAdd(sh, n_eval * (64ull / W));      // every staged point is evaluated by the 64 lanes of ONE of the W waves
+    atomicAdd(sh + kEvalRegion, n_eval * (64ull / W));
   }
 }
 
 template <bool FMA>
-__global__ void __launch_bounds__(256, 8) nn_grid_set_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
+__global__ void __launch_bounds__(64 * kWideWaves, 2048 / (64 * kWideWaves)) nn_grid_set_kernel(GridBatch batch, unsigned long long *__restrict__ evals)
 {
   nn_grid_set_body<FMA>(batch, evals, blockIdx.x, gridDim.x);
 }
 
 // both stragglers' launches in one: the first `wide_blocks` blocks of a pair give the wide bounded queries a wave each,
 // the others take the listed query sets -- neither waits for the other (two launches of 8 and 24 us ran one after the other)
-static_assert(64 * kWideWaves == 256, "the two bodies share a block shape");
+static_assert(kSetPoints % (64 * kWideWaves) == 0 && (kWideWaves == 4 || kWideWaves == 8), "the two bodies share a block shape");
 template <bool FMA>
-__global__ void __launch_bounds__(256, 8) nn_grid_tail_kernel(GridBatch batch, unsigned long long *__restrict__ evals, uint32_t wide_blocks)
+__global__ void __launch_bounds__(64 * kWideWaves, 2048 / (64 * kWideWaves)) nn_grid_tail_kernel(GridBatch batch, unsigned long long *__restrict__ evals, uint32_t wide_blocks)
 {
   if (blockIdx.x < wide_blocks) nn_grid_wide_body<FMA>(batch, evals, blockIdx.x, wide_blocks);
   else nn_grid_set_body<FMA>(batch, evals, blockIdx.x - wide_blocks, gridDim.x - wide_blocks);
@@ -1691,12 +1700,12 @@ int launch_nn_grid_tail_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     batch.light_rows = c->grid_light_rows;
     batch.cert_margin = 1.0e-3f * (float)c->rim_cert_um;
     const unsigned wide_blocks = (unsigned)std::max(1, c->n_cu * c->grid_wide_waves / (std::max(1, m) * kWideWaves * 4));
-    const unsigned set_blocks = (unsigned)std::max(1, c->n_cu * 8 / std::max(1, m));
+    const unsigned set_blocks = (unsigned)std::max(1, c->n_cu * (2048 / (64 * kWideWaves)) / std::max(1, m));
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
     ProfScope ps(c, MVR_K_NN_WIDE, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
-    if (fma) hipLaunchKernelGGL((nn_grid_tail_kernel<true>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals, wide_blocks);
-    else hipLaunchKernelGGL((nn_grid_tail_kernel<false>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals, wide_blocks);
+    if (fma) hipLaunchKernelGGL((nn_grid_tail_kernel<true>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals, wide_blocks);
+    else hipLaunchKernelGGL((nn_grid_tail_kernel<false>), dim3(wide_blocks + set_blocks, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals, wide_blocks);
     MVR_HIP_TRY(c, hipGetLastError());
   }
   return MVR_OK;
@@ -1959,12 +1968,12 @@ int launch_nn_grid_sets_batch(Ctx *c, const GridPair *pairs, int n_pairs, float 
     batch.cap2 = cap2;
     batch.light_rows = c->grid_light_rows;
     batch.cert_margin = 1.0e-3f * (float)c->rim_cert_um;
-    const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * 8 / std::max(1, m));      // listed sets are strided over (every block's loop ends at the count)
+    const unsigned blocks_x = (unsigned)std::max(1, c->n_cu * (2048 / (64 * kWideWaves)) / std::max(1, m));      // listed sets are strided over (every block's loop ends at the count)
     const bool per_launch = c->prof && !c->prof_totals;
     if (per_launch) MVR_HIP_TRY(c, hipMemsetAsync(c->evals, 0, kEvalRegion * sizeof(unsigned long long), c->stream));
     ProfScope ps(c, MVR_K_NN_WIDE, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
-    if (fma) hipLaunchKernelGGL((nn_grid_set_kernel<true>), dim3(blocks_x, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals);
-    else hipLaunchKernelGGL((nn_grid_set_kernel<false>), dim3(blocks_x, (unsigned)m), dim3(256), 0, c->stream, batch, c->evals);
+    if (fma) hipLaunchKernelGGL((nn_grid_set_kernel<true>), dim3(blocks_x, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals);
+    else hipLaunchKernelGGL((nn_grid_set_kernel<false>), dim3(blocks_x, (unsigned)m), dim3(64 * kWideWaves), 0, c->stream, batch, c->evals);
     MVR_HIP_TRY(c, hipGetLastError());
   }
   return MVR_OK;
