@@ -397,14 +397,42 @@ static bool solve_chain6(int nb, double *D, double *O, double *b)
   for (int v = 0; v < nb; ++v) for (int k = 0; k < 6; ++k) amax = std::max(amax, std::fabs(D[B2 * (size_t)v + (R + 1) * k]));
   if (!(amax > 0.0)) return false;
   const double tiny = 1e-13 * amax;
-  for (int v = 0; v < nb; ++v) {
+  // W = L^-1 C (C: six rows of eight, overwritten), then Dn -= W^T W, bn -= W^T y: the two O(6^3) parts of a block step, a row of
+  // two 4-wide vectors at a time.  A: the factorised block (L below the diagonal), dinv: its inverted diagonal.
+  auto couple = [](const double *A, const double *dinv, const double *y, double *W, double *Dn, double *bn) {
+    __m256d w0[6], w1[6];
+    for (int i = 0; i < 6; ++i) {
+      __m256d r0 = _mm256_loadu_pd(W + R * i), r1 = _mm256_loadu_pd(W + R * i + 4);
+      for (int k = 0; k < i; ++k) {
+        const __m256d l = _mm256_set1_pd(A[R * i + k]);
+        r0 = _mm256_sub_pd(r0, _mm256_mul_pd(l, w0[k])); r1 = _mm256_sub_pd(r1, _mm256_mul_pd(l, w1[k]));
+      }
+      const __m256d di = _mm256_set1_pd(dinv[i]);
+      w0[i] = _mm256_mul_pd(r0, di); w1[i] = _mm256_mul_pd(r1, di);
+      _mm256_storeu_pd(W + R * i, w0[i]); _mm256_storeu_pd(W + R * i + 4, w1[i]);
+    }
+    for (int r = 0; r < 6; ++r) {            // Dn -= W^T W (row r: sum over k of W[k][r] * row k of W), bn -= W^T y
+      __m256d a0 = _mm256_loadu_pd(Dn + R * r), a1 = _mm256_loadu_pd(Dn + R * r + 4);
+      double t = 0.0;
+      for (int k = 0; k < 6; ++k) {
+        const double wkr = W[R * k + r];
+        const __m256d f = _mm256_set1_pd(wkr);
+        a0 = _mm256_sub_pd(a0, _mm256_mul_pd(f, w0[k])); a1 = _mm256_sub_pd(a1, _mm256_mul_pd(f, w1[k]));
+        t += wkr * y[k];
+      }
+      _mm256_storeu_pd(Dn + R * r, a0); _mm256_storeu_pd(Dn + R * r + 4, a1);
+      bn[r] -= t;
+    }
+  };
+  // one block by itself: D_v = L L^T, y_v = L^-1 b_v, and (next) the coupling to block v + 1
+  auto step_single = [&](int v, bool next) -> bool {
     double *A = D + B2 * (size_t)v;          // becomes L (lower triangle), diagonal inverted in dinv
     double dinv[6];
     for (int j = 0; j < 6; ++j) {
       double d = A[(R + 1) * j];
       for (int k = 0; k < j; ++k) d -= A[R * j + k] * A[R * j + k];
       if (!(d > tiny)) return false;
-      const double l = std::sqrt(d), inv = l * (1.0 / d);      // 1 / sqrt(d): the root and the reciprocal run side by side (the chain of 6 nb pivots is what this routine costs)
+      const double l = std::sqrt(d), inv = l * (1.0 / d);      // 1 / sqrt(d): the root and the reciprocal run side by side
       A[(R + 1) * j] = l; dinv[j] = inv;
       for (int i = j + 1; i < 6; ++i) {
         double sacc = A[R * i + j];
@@ -418,51 +446,78 @@ static bool solve_chain6(int nb, double *D, double *O, double *b)
       for (int k = 0; k < i; ++k) sacc -= A[R * i + k] * y[k];
       y[i] = sacc * dinv[i];
     }
-    if (v + 1 < nb) {
-      double *W = O + B2 * (size_t)v;        // O_v (rows: block v, columns: block v + 1) -> W = L^-1 O_v, a row of W at a time
-      __m256d w0[6], w1[6];
-      for (int i = 0; i < 6; ++i) {
-        __m256d r0 = _mm256_loadu_pd(W + R * i), r1 = _mm256_loadu_pd(W + R * i + 4);
-        for (int k = 0; k < i; ++k) {
-          const __m256d l = _mm256_set1_pd(A[R * i + k]);
-          r0 = _mm256_sub_pd(r0, _mm256_mul_pd(l, w0[k])); r1 = _mm256_sub_pd(r1, _mm256_mul_pd(l, w1[k]));
-        }
-        const __m256d di = _mm256_set1_pd(dinv[i]);
-        w0[i] = _mm256_mul_pd(r0, di); w1[i] = _mm256_mul_pd(r1, di);
-        _mm256_storeu_pd(W + R * i, w0[i]); _mm256_storeu_pd(W + R * i + 4, w1[i]);
-      }
-      double *Dn = D + B2 * (size_t)(v + 1), *bn = b + 6 * (size_t)(v + 1);
-      for (int r = 0; r < 6; ++r) {            // D_{v+1} -= W^T W (row r: sum over k of W[k][r] * row k of W), b_{v+1} -= W^T y
-        __m256d a0 = _mm256_loadu_pd(Dn + R * r), a1 = _mm256_loadu_pd(Dn + R * r + 4);
-        double t = 0.0;
-        for (int k = 0; k < 6; ++k) {
-          const double wkr = W[R * k + r];
-          const __m256d f = _mm256_set1_pd(wkr);
-          a0 = _mm256_sub_pd(a0, _mm256_mul_pd(f, w0[k])); a1 = _mm256_sub_pd(a1, _mm256_mul_pd(f, w1[k]));
-          t += wkr * y[k];
-        }
-        _mm256_storeu_pd(Dn + R * r, a0); _mm256_storeu_pd(Dn + R * r + 4, a1);
-        bn[r] -= t;
+    if (next) couple(A, dinv, y, O + B2 * (size_t)v, D + B2 * (size_t)(v + 1), b + 6 * (size_t)(v + 1));
+    for (int j = 0; j < 6; ++j) A[(R + 1) * j] = dinv[j];      // (the back substitution wants the inverted diagonal)
+    return true;
+  };
+  // What this routine costs is its chain of 6 nb dependent pivots (a square root and a division each).  So the chain is eliminated
+  // from BOTH ends at once (a twisted factorisation): block s upwards and block nb - 1 - s downwards are two independent
+  // factorisations, run as the two lanes of 128-bit vectors -- the same instructions, half the chain; the one or two blocks in the
+  // middle take both sides' updates and are factorised last.  Lane 0 does exactly what step_single does.
+  const int pairs = (nb - 1) / 2;
+  for (int s = 0; s < pairs; ++s) {
+    const int va = s, vb = nb - 1 - s;
+    double *A = D + B2 * (size_t)va, *Bk = D + B2 * (size_t)vb;
+    double *ya = b + 6 * (size_t)va, *yb = b + 6 * (size_t)vb;
+    __m128d L2[6][6], dinv2[6], y2[6];
+    const __m128d tiny2 = _mm_set1_pd(tiny), one2 = _mm_set1_pd(1.0);
+    for (int j = 0; j < 6; ++j) {
+      __m128d d = _mm_set_pd(Bk[(R + 1) * j], A[(R + 1) * j]);
+      for (int k = 0; k < j; ++k) d = _mm_sub_pd(d, _mm_mul_pd(L2[j][k], L2[j][k]));
+      if (_mm_movemask_pd(_mm_cmpgt_pd(d, tiny2)) != 3) return false;
+      const __m128d l = _mm_sqrt_pd(d), inv = _mm_mul_pd(l, _mm_div_pd(one2, d));
+      L2[j][j] = l; dinv2[j] = inv;
+      for (int i = j + 1; i < 6; ++i) {
+        __m128d sacc = _mm_set_pd(Bk[R * i + j], A[R * i + j]);
+        for (int k = 0; k < j; ++k) sacc = _mm_sub_pd(sacc, _mm_mul_pd(L2[i][k], L2[j][k]));
+        L2[i][j] = _mm_mul_pd(sacc, inv);
       }
     }
-    for (int j = 0; j < 6; ++j) A[(R + 1) * j] = dinv[j];      // (the back substitution wants the inverted diagonal)
+    for (int i = 0; i < 6; ++i) {              // y = L^-1 b, both
+      __m128d sacc = _mm_set_pd(yb[i], ya[i]);
+      for (int k = 0; k < i; ++k) sacc = _mm_sub_pd(sacc, _mm_mul_pd(L2[i][k], y2[k]));
+      y2[i] = _mm_mul_pd(sacc, dinv2[i]);
+    }
+    double da[6], db[6];
+    for (int i = 0; i < 6; ++i) {
+      for (int j = 0; j <= i; ++j) { _mm_storel_pd(A + R * i + j, L2[i][j]); _mm_storeh_pd(Bk + R * i + j, L2[i][j]); }
+      _mm_storel_pd(ya + i, y2[i]); _mm_storeh_pd(yb + i, y2[i]);
+      _mm_storel_pd(da + i, dinv2[i]); _mm_storeh_pd(db + i, dinv2[i]);
+    }
+    // upwards: W = La^-1 O_va onto block va + 1; downwards: U = Lb^-1 O_(vb-1)^T onto block vb - 1 (U replaces O_(vb-1), row-major)
+    couple(A, da, ya, O + B2 * (size_t)va, D + B2 * (size_t)(va + 1), b + 6 * (size_t)(va + 1));
+    {
+      double *Ob = O + B2 * (size_t)(vb - 1), Ct[B2];
+      for (int i = 0; i < 6; ++i) { for (int c = 0; c < 6; ++c) Ct[R * i + c] = Ob[R * c + i]; Ct[R * i + 6] = 0.0; Ct[R * i + 7] = 0.0; }
+      std::memcpy(Ob, Ct, sizeof Ct);
+      couple(Bk, db, yb, Ob, D + B2 * (size_t)(vb - 1), b + 6 * (size_t)(vb - 1));
+    }
+    for (int j = 0; j < 6; ++j) { A[(R + 1) * j] = da[j]; Bk[(R + 1) * j] = db[j]; }
   }
-  for (int v = nb - 1; v >= 0; --v) {
+  const int lo = pairs, hi = nb - 1 - pairs;      // the middle: one block (nb odd) or two
+  for (int v = lo; v <= hi; ++v) if (!step_single(v, v < hi)) return false;
+  // back substitution: the middle first, then outwards on both sides
+  auto back = [&](int v, const double *Wc, const double *xn) {      // x_v = L^-T (y_v - Wc x_n)
     const double *A = D + B2 * (size_t)v;
     double *x = b + 6 * (size_t)v;
-    if (v + 1 < nb) {
-      const double *W = O + B2 * (size_t)v, *xn = b + 6 * (size_t)(v + 1);
+    if (Wc) {
       for (int i = 0; i < 6; ++i) {
         double t = 0.0;
-        for (int c = 0; c < 6; ++c) t += W[R * i + c] * xn[c];
+        for (int c = 0; c < 6; ++c) t += Wc[R * i + c] * xn[c];
         x[i] -= t;
       }
     }
-    for (int i = 5; i >= 0; --i) {             // x = L^-T x
+    for (int i = 5; i >= 0; --i) {
       double sacc = x[i];
       for (int k = i + 1; k < 6; ++k) sacc -= A[R * k + i] * x[k];
       x[i] = sacc * A[(R + 1) * i];
     }
+  };
+  for (int v = hi; v >= lo; --v) back(v, v < hi ? O + B2 * (size_t)v : nullptr, b + 6 * (size_t)(v + 1));
+  for (int s = pairs - 1; s >= 0; --s) {
+    const int va = s, vb = nb - 1 - s;
+    back(va, O + B2 * (size_t)va, b + 6 * (size_t)(va + 1));
+    back(vb, O + B2 * (size_t)(vb - 1), b + 6 * (size_t)(vb - 1));
   }
   return true;
 }
