@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/kt; mkdir -p $O
 : > $O/kern.txt
 for v in "$@"; do
   rm -rf $O/t; mkdir -p $O/t
-  MVR_PROBE_PROF=0 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 $R/tools/step_probe.py 12 200000 40 20 pipeline=1 $v > $O/t/probe.json 2> $O/t/probe.err || exit 1
+  MVR_PROBE_PROF=0 timeout -k 10 ${PROBE_TIMEOUT:-200} rocprofv3 --kernel-trace --output-format csv -d $O/t -- python3 $R/tools/step_probe.py ${PROBE_VIEWS:-12} ${PROBE_POINTS:-200000} ${PROBE_STEPS:-40} ${PROBE_WARM:-20} pipeline=1 $v > $O/t/probe.json 2> $O/t/probe.err || exit 1
   python3 - "$(find $O/t -name '*kernel_trace.csv' | head -1)" "$v" >> $O/kern.txt <<'P'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1]))); rows.sort(key=lambda r: int(r['Start_Timestamp']))
