@@ -209,6 +209,10 @@ def main():
     run(max(args.warmup, 1))
     reset()
     ctx.prof_reset(); ctx.prof_enable(prof_level)
+    # (no collection of Python's heap inside a timed window, as timeit does: a window is a few milliseconds, a collection of this
+    # process's heap -- 100 MB of scans -- one of them; it showed as a slow "rank" in the projection leg, twice at the same place)
+    import gc
+    gc.collect(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -234,6 +238,7 @@ def main():
         run(args.steps)
         barrier()
         conv_s = time.perf_counter() - tc
+    gc.enable()
     if use_dist:
         tt = torch.tensor([elapsed] + rep_s, dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -518,6 +523,8 @@ def main():
                 "rccl": prccl, "workload": "%d-view ring x %d pts" % (V, N),
                 "ms_per_step": {w: {"unpipelined": v["ms_per_step_pipeline0"], "pipelined": v["ms_per_step_pipeline1"]} for w, v in proj.items()},
                 "rank0_timing_ms_unpipelined": {w: v["ranks"][0]["timing_ms_pipeline0"] for w, v in proj.items()},
+                "pass_ms_median_max_of_slowest_rank": {w: {"unpipelined": max(v["ranks"], key=lambda r: r["ms_per_step_pipeline0"])["pass_ms_median_max_pipeline0"],
+                                                           "pipelined": max(v["ranks"], key=lambda r: r["ms_per_step_pipeline1"])["pass_ms_median_max_pipeline1"]} for w, v in proj.items()},
                 "note": "unpipelined is what a world of more than one rank runs today (a pass with a multi-rank collective is not queued "
                         "ahead of its poses: ADVICE r3); pipelined is what lifting that rule would give; timing = {enqueue, wait for the GPU, host solve}"}
         finally:

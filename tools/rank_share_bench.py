@@ -13,7 +13,7 @@ lifting that rule would give.
 
     python tools/rank_share_bench.py [views] [points] [steps] [worlds, e.g. 1,2,4,8] [knob=value ...]
 Prints one JSON line."""
-import importlib, json, os, sys, time
+import gc, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 
@@ -34,12 +34,18 @@ def project(mvr, ctx, V, edges, posed, raw, poses_c, origin, max_d, worlds, step
                 ctx.tune(pipeline=pipe)
                 ctx.ring_run_sharded(posed, raw, edges, poses_c, max_d, origin, steps=warm)          # the rank's buffers, seeds, the pipe
                 ctx.sync()
-                t0 = time.perf_counter()
-                new, info = ctx.ring_run_sharded(posed, raw, edges, poses_c, max_d, origin, steps=steps)
-                ctx.sync()
-                dt = time.perf_counter() - t0
+                gc.collect(); gc.disable()      # (a collection of the caller's heap inside the 3 ms window showed as a slow "rank": bench.py holds 100 MB of scans)
+                try:
+                    t0 = time.perf_counter()
+                    new, info = ctx.ring_run_sharded(posed, raw, edges, poses_c, max_d, origin, steps=steps)
+                    ctx.sync()
+                    dt = time.perf_counter() - t0
+                finally:
+                    gc.enable()
                 rec["ms_per_step_pipeline%d" % pipe] = 1e3 * dt / steps
                 rec["timing_ms_pipeline%d" % pipe] = [t / steps for t in info["timing_ms"]]
+                pl = sorted(ctx.pass_log())      # (a single slow pass -- an allocation, a stall of the box -- shows here, not in the mean)
+                rec["pass_ms_median_max_pipeline%d" % pipe] = [round(pl[len(pl) // 2], 4), round(pl[-1], 4)] if pl else None
             rec["rank"] = r
             per_rank.append(rec)
         ctx.project(1)
