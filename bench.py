@@ -206,13 +206,14 @@ def main():
     # its idle clocks; 20 untimed passes before the contract's W warm-up steps take that out of short (K = 10) windows
     run(int(os.environ.get("MVR_BENCH_PREWARM", "20")))
     reset()
+    # (no collection of Python's heap inside a timed window, as timeit does: a window is a few milliseconds, a collection of this
+    # process's heap -- 100 MB of scans -- one of them; it showed as a slow "rank" in the projection leg, twice at the same place.
+    # Collected HERE, ahead of the warm-up steps, so that they also put back what the collection pushed out of the host's caches.)
+    import gc
+    gc.collect(); gc.disable()
     run(max(args.warmup, 1))
     reset()
     ctx.prof_reset(); ctx.prof_enable(prof_level)
-    # (no collection of Python's heap inside a timed window, as timeit does: a window is a few milliseconds, a collection of this
-    # process's heap -- 100 MB of scans -- one of them; it showed as a slow "rank" in the projection leg, twice at the same place)
-    import gc
-    gc.collect(); gc.disable()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
