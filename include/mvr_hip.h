@@ -326,6 +326,8 @@ int  mvr_ring_step(mvr_ctx *ctx, int n_views, const int *posed_slots, const int 
                    double *rows, double *timing_ms);
 /* n_steps outer passes (the loop of registrator.cpp:625-664), each exactly one mvr_ring_step; the outputs are those
  * of the LAST pass, timing_ms the SUM over the passes.  Stops at the first pass that fails and returns its status.
+ * (pair_T is computed for the last pass only -- a 3 x 3 SVD per pair that no pass in between needs: it is left untouched when
+ * the run stops early; pair_n, pair_mse, lum_pose and rows are those of the last pass that was solved.)
  * In steady state (no allocation, no index or grid to build: from the third or fourth pass of a registration on) the
  * passes are PIPELINED: the launch chain of pass k+1 is queued behind a gate while pass k runs and released by the host's
  * solve with one store (tune key "pipeline"); same results, bit for bit. */
