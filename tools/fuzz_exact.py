@@ -35,7 +35,8 @@ while time.time() < t_end:
     origin = np.array(sp.pivot)
     edges = [(i, (i + 1) % V) for i in range(V)]
     runs = []
-    for knobs in ({}, dict(ring_search=0), dict(pipeline=0, grid_probe=0), dict(grid_light_rows=3, grid_cluster=2, cull_w=4), dict(grid_probe_rows=1), dict(grid_probe_rows=2, grid_light_rows=40)):
+    for knobs in ({}, dict(ring_search=0), dict(pipeline=0, grid_probe=0), dict(grid_light_rows=3, grid_cluster=2, cull_w=4), dict(grid_probe_rows=1), dict(grid_probe_rows=2, grid_light_rows=40),
+                  dict(grid_stage=0), dict(grid_stage=2, grid_index=1), dict(order_batch=0, grid_index=0, seed_delta_um=50, rim_cert_um=200)):      # (round 4: the staged walk off / on for every launch, the three index forms, the motion-bound seeds and certificates)
         with mvr.Context(0) as ctx:
             ctx.tune(**knobs)
             for v in range(V):
@@ -76,6 +77,7 @@ while time.time() < t_end:
         print("BRUTE MISMATCH V=%d sizes=%s far=%g max_d=%g: %s vs %s" % (V, sizes, far, max_d, one[0] if isinstance(one[0], str) else one[0][:, 0].tolist(),
                                                                              one[1] if isinstance(one[1], str) else one[1][:, 0].tolist()), flush=True)
     cases += 1
+    if cases % 20 == 0: print("... %d cases, %d failures so far" % (cases, fails), flush=True)
     if not all(r == runs[0] for r in runs[1:]):
         fails += 1
         print("RING MISMATCH V=%d sizes=%s far=%g max_d=%g passes=%d: %s" % (V, sizes, far, max_d, passes, [r == runs[0] for r in runs]), flush=True)
@@ -83,7 +85,7 @@ while time.time() < t_end:
     if 4 <= V <= 12:
         params = mvr.icp_params(max_dist=max_d, max_iter=int(rng.choice([1000, 3])), teps=float(rng.choice([1e-6, 0.0])), feps=float(rng.choice([64.0, -1e300])), fma=fma)
         seq = []
-        for knobs in (dict(seq_seed=1), dict(seq_seed=0), dict(seq_search=0, seq_seed=0)):
+        for knobs in (dict(seq_seed=1), dict(seq_seed=0), dict(seq_search=0, seq_seed=0), dict(seq_search=3), dict(seq_search=3, seq_model_tail=0, seq_cell_points=16)):      # (round 4: one grid over the model)
             with mvr.Context(0) as ctx:
                 ctx.tune(**knobs)
                 for v in range(V):
