@@ -172,6 +172,7 @@ SIGNATURES = {
     "mvr_ctx_comm_destroy": (C.c_int, [_vp]),
     "mvr_ctx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mvr_rccl_library": (C.c_char_p, []),
+    "mvr_pool_trim": (C.c_uint64, [C.POINTER(C.c_uint64)]),
     "mvr_ring_segments": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "mvr_ring_run_sharded": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int),
@@ -774,6 +775,14 @@ def comm_unique_id() -> bytes:
 
 def rccl_library() -> str:
     return _lib.mvr_rccl_library().decode()
+
+
+def pool_trim():
+    """give the idle blocks of the library's allocation cache back to the runtime (mvr_pool_trim); returns
+    dict(freed_bytes, cached_bytes, hits, misses)"""
+    st = (C.c_uint64 * 3)()
+    freed = _lib.mvr_pool_trim(st)
+    return dict(freed_bytes=int(freed), cached_bytes=int(st[0]), hits=int(st[1]), misses=int(st[2]))
 
 
 def ring_segments(edge_queries, world, rank):

@@ -13,6 +13,24 @@
 
 #include "mvr_hip.h"
 
+// ---- every device / pinned-host allocation of the library goes through a process-wide cache of freed blocks (mvr_pool.cpp): the names
+// of the runtime's four calls are redirected HERE, after the runtime's and hipCUB's own headers (a translation unit that uses hipCUB
+// includes it before this file), so that no call site has to know
+namespace mvr {
+hipError_t pool_malloc(void **p, size_t bytes);
+hipError_t pool_free(void *p);
+hipError_t pool_host_malloc(void **p, size_t bytes, unsigned flags);
+hipError_t pool_host_free(void *p);
+template <class T> inline hipError_t pool_malloc_t(T **p, size_t bytes) { return pool_malloc(reinterpret_cast<void **>(p), bytes); }
+template <class T> inline hipError_t pool_host_malloc_t(T **p, size_t bytes, unsigned flags = 0) { return pool_host_malloc(reinterpret_cast<void **>(p), bytes, flags); }
+template <class T> inline hipError_t pool_free_t(T *p) { return pool_free(const_cast<void *>(static_cast<const void *>(p))); }
+template <class T> inline hipError_t pool_host_free_t(T *p) { return pool_host_free(const_cast<void *>(static_cast<const void *>(p))); }
+}  // namespace mvr
+#define hipMalloc(p, n) ::mvr::pool_malloc_t((p), (n))
+#define hipFree(p) ::mvr::pool_free_t(p)
+#define hipHostMalloc(...) ::mvr::pool_host_malloc_t(__VA_ARGS__)
+#define hipHostFree(p) ::mvr::pool_host_free_t(p)
+
 namespace mvr {
 
 // ---- device data layout ------------------------------------------------------

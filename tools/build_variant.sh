@@ -14,5 +14,5 @@ mkdir -p build/obj
 /opt/rocm/bin/hipcc $F -x hip -c multi-view-registration_amd/csrc/mvr_reduce.hip -o build/obj/mvr_reduce_$name.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libmvr_hip_$name.so build/obj/mvr_nn.hip.o build/obj/mvr_index.hip.o \
-  build/obj/mvr_cull_$name.o build/obj/mvr_grid_$name.o build/obj/mvr_denoise.hip.o build/obj/mvr_reduce_$name.o build/obj/mvr_ctx_$name.o build/obj/host_math.cpp.o build/obj/mvr_world.cpp.o build/obj/synth.c.o -lm -ldl -lpthread
+  build/obj/mvr_cull_$name.o build/obj/mvr_grid_$name.o build/obj/mvr_denoise.hip.o build/obj/mvr_reduce_$name.o build/obj/mvr_ctx_$name.o build/obj/host_math.cpp.o build/obj/mvr_world.cpp.o build/obj/mvr_pool.cpp.o build/obj/synth.c.o -lm -ldl -lpthread
 ls -la build/libmvr_hip_$name.so
