@@ -1144,7 +1144,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
       const Cloud &s = c->slots[src[k]], &t = c->slots[dst[k]];
       if (qn[k] == 0) { gfwd[k] = GridPair(); grev[k] = GridPair(); continue; }
       gfwd[k] = make_grid_pair(s, qb[k], qn[k], t, w->bkeys + off_s[k]);
-      gfwd[k].key_by_pos = 1; gfwd[k].seed_from_keys = 1; gfwd[k].mark = fwd[k].mark;
+      gfwd[k].key_by_pos = 1; gfwd[k].seed_from_keys = seed ? 1u : 0u; gfwd[k].mark = fwd[k].mark;
       // seed_delta: how far the pair has moved since the searches that left the keys -- from the device records of a pass that
       // is enqueued ahead of its poses, else from what note_pose() has added up since both clouds were last searched
       gfwd[k].qpose_dev = s.pose_dev;
@@ -1167,7 +1167,10 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
   // they are the grid walk (+5 us there, a launch of 12 us less), a separate launch over the keys when the culled kernel
   // answers every query (marking inside it measured 3 % slower); fused_mark = 2 / 0 force one or the other.  Decided with
   // the forward launches (phase 1), remembered for the rest of the pass.
-  if (phases & 1) w->marked_in_search = reciprocal && (c->fused_mark == 2 || (c->fused_mark == 1 && grid_ok && seed));
+  // (unseeded_grid: the forward searches of a pass WITHOUT seeds -- a registration's first -- walk the grid too: every query probes
+  // the cells next to it, what finds nothing there goes to the listed sets; the culled kernel took 0.59 ms for such a pass)
+  const bool grid_fwd = grid_ok && (seed || c->unseeded_grid);
+  if (phases & 1) w->marked_in_search = reciprocal && (c->fused_mark == 2 || (c->fused_mark == 1 && grid_fwd));
   if (w->marked_in_search)
     for (int k = 0; k < n_pairs; ++k) if (qn[k]) { fwd[k].mark = w->bbound + off_t[k]; if (grid_ok) gfwd[k].mark = fwd[k].mark; }
   if (phases & 1) {
@@ -1178,7 +1181,7 @@ static int pair_batch_fused(Ctx *c, Ctx *w, int n_pairs, const int *src, const i
     }
     if (reciprocal && !w->bbound_clean) MVR_HIP_TRY(w, hipMemsetAsync(w->bbound, 0xFF, w->bbound_cap * sizeof(uint32_t), w->stream));
     if (reciprocal) w->bbound_clean = false;        // dirty until this pass's moments launch has put it back
-    if (grid_ok && seed) {
+    if (grid_fwd) {
       if (int rc = launch_nn_grid_batch(w, gfwd.data(), n_pairs, cap2, fma != 0)) return rc;
       if (c->grid_debug) {          // diagnostics (tune key grid_debug): how many queries left the thread-per-query walk, per pass
         MVR_MAY_BLOCK(c, "grid_debug reads counters back");
@@ -1822,8 +1825,9 @@ struct RingRun {
     // to enqueue, nothing to wait for but the stream itself)
     if (c->h_table_cap < (size_t)std::max(r.ne, 1) * 32) {
       MVR_MAY_BLOCK(c, "the host edge table has to grow");
-      MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
-      if (c->h_table) (void)hipHostFree(c->h_table);
+      // (the stream is only waited for when there IS an old table it may still write to: a fresh context has none, and the wait
+      // held the host behind the orderings and the posing of a registration's first pass -- 0.5 ms once its allocations were fast)
+      if (c->h_table) { MVR_HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_table); }
       c->h_table = nullptr; c->h_table_cap = 0;
       const size_t cap = (size_t)std::max(r.ne, 16) * 32;
       MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), cap * sizeof(double), hipHostMallocMapped));
@@ -2647,6 +2651,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "fused_mark")) { if (value < 0 || value > 2) return MVR_E_ARG; c->fused_mark = value; }
   else if (!std::strcmp(key, "ring_search")) c->ring_search = value;
   else if (!std::strcmp(key, "seq_search")) { if (value < 0 || value > 3) return MVR_E_ARG; c->seq_search = value; }
+  else if (!std::strcmp(key, "unseeded_grid")) { if (value < 0 || value > 1) return MVR_E_ARG; c->unseeded_grid = value; }
   else if (!std::strcmp(key, "seq_model_tail")) { if (value < 0 || value > 1) return MVR_E_ARG; c->seq_model_tail = value; }
   else if (!std::strcmp(key, "seq_cell_points")) { if (value < 1) return MVR_E_ARG; c->seq_cell_points = value; }
   else if (!std::strcmp(key, "seq_seed")) {          // 0 also forgets what the aligns so far have left behind

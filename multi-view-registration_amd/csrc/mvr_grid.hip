@@ -139,11 +139,13 @@ __global__ void grid_gather_kernel(const float4 *__restrict__ p, const uint32_t 
   graw[k] = v;
 }
 
-__global__ void g2h_kernel(const uint32_t *__restrict__ gperm, const uint32_t *__restrict__ inv, size_t n, uint32_t *__restrict__ g2h,
-                           uint32_t *__restrict__ h2g)
+// (for several grids at once, blockIdx.y = grid: a registration's first pass asked for twelve, one launch each with the gap between them)
+struct G2HBatch { const uint32_t *gperm[kBatchClouds], *inv[kBatchClouds]; uint32_t *g2h[kBatchClouds], *h2g[kBatchClouds]; unsigned long long n[kBatchClouds]; };
+__global__ void g2h_kernel(G2HBatch b)
 {
+  const int g = blockIdx.y;
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) { const uint32_t h = inv[gperm[k]]; g2h[k] = h; h2g[h] = (uint32_t)k; }
+  if (k < (size_t)b.n[g]) { const uint32_t h = b.inv[g][b.gperm[g][k]]; b.g2h[g][k] = h; b.h2g[g][h] = (uint32_t)k; }
 }
 
 // posed coordinates in grid order: the SAME function of the same inputs as the posed points themselves
@@ -1378,10 +1380,34 @@ int grid_coords_prepare(Ctx *c, Cloud *cl, bool *ok)
     cl->grid->ready_waited = true;
   }
   if (cl->order && cl->grid->built_for != cl->order.get()) {
-    hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((cl->n + 255) / 256)), dim3(256), 0, c->stream, cl->grid->gperm, cl->order->inv, cl->n, cl->grid->g2h, cl->grid->h2g);
-    cl->grid->built_for = cl->order.get();
+    // (queued: flush_g2h() launches the maps of all the grids a batch asked for at once, ahead of the batch's own launch)
+    // (the job keeps grid and ordering alive: a call that fails between here and the flush leaves it for the next flush)
+    bool queued = false;
+    for (const Ctx::G2HJob &j : c->g2h_todo) queued = queued || (j.grid == cl->grid && j.order == cl->order);
+    if (!queued) c->g2h_todo.push_back(Ctx::G2HJob{cl->grid, cl->order, cl->n});
   }
   *ok = true;
+  return MVR_OK;
+}
+
+int flush_g2h(Ctx *c)
+{
+  for (size_t base = 0; base < c->g2h_todo.size(); base += kBatchClouds) {
+    G2HBatch b;
+    const int m = (int)std::min<size_t>(kBatchClouds, c->g2h_todo.size() - base);
+    size_t nmax = 0;
+    for (int k = 0; k < kBatchClouds; ++k) {
+      if (k < m) {
+        const Ctx::G2HJob &j = c->g2h_todo[base + (size_t)k];
+        b.gperm[k] = j.grid->gperm; b.inv[k] = j.order->inv; b.g2h[k] = j.grid->g2h; b.h2g[k] = j.grid->h2g; b.n[k] = j.n; nmax = std::max(nmax, j.n);
+        j.grid->built_for = j.order.get();
+      }
+      else { b.gperm[k] = b.inv[k] = nullptr; b.g2h[k] = b.h2g[k] = nullptr; b.n[k] = 0; }
+    }
+    if (nmax) hipLaunchKernelGGL(g2h_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)m), dim3(256), 0, c->stream, b);
+  }
+  c->g2h_todo.clear();
+  MVR_HIP_TRY(c, hipGetLastError());
   return MVR_OK;
 }
 
@@ -1406,6 +1432,7 @@ int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count)
       cl->gcoords_valid = true;
       ++used;
     }
+    if (int rc = flush_g2h(c)) return rc;
     if (!used) continue;
     for (int k = used; k < kBatchClouds; ++k) { b.graw[k] = nullptr; b.out[k] = nullptr; b.n[k] = 0; b.Tp[k] = nullptr; }
     ProfScope ps(c, MVR_K_XFORM, 32.0 * (double)nmax * used);

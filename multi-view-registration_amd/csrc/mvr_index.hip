@@ -856,6 +856,7 @@ static int refresh_batch(Ctx *c, Cloud *const *clouds, int count, const float4 *
       rb.tile_begin[k] = (unsigned)t0;
       if (cl) { tmax = std::max(tmax, (cl->n + kCullTile - 1) / kCullTile - t0); work += 36.0 * (double)(cl->n - t0 * kCullTile); }
     }
+    if (int rc = flush_g2h(c)) return rc;      // (the position maps of the grids this batch met for the first time: one launch)
     if (tmax == 0) continue;
     ProfScope ps(c, MVR_K_GLUE, work);
     hipLaunchKernelGGL(refresh_sorted_kernel, dim3((unsigned)((tmax + 3) / 4), (unsigned)m), dim3(256), 0, c->stream, rb);
@@ -965,6 +966,7 @@ int ensure_index(Ctx *c, Cloud &cl)
 int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
 {
   if (count >= 2) { if (int rc = build_orders_batch(c, clouds, count)) return rc; }
+  host_mark("      index batch: orderings");
   std::vector<Cloud *> todo;
   for (int k = 0; k < count; ++k) {
     Cloud *cl = clouds[k];
@@ -973,7 +975,10 @@ int ensure_index_batch(Ctx *c, Cloud *const *clouds, int count)
     if (int rc = prepare_index(c, *cl, &stale)) return rc;
     if (stale) todo.push_back(cl);
   }
-  return todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
+  host_mark("      index batch: buffers");
+  const int rc = todo.empty() ? MVR_OK : refresh_batch(c, todo.data(), (int)todo.size());
+  host_mark("      index batch: refreshed");
+  return rc;
 }
 
 int launch_compact_flags_batch(Ctx *c, const GlueBatch &b, int n_pairs)

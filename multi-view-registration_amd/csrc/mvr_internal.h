@@ -231,6 +231,9 @@ struct Ctx {
   struct SeedBuf { uint32_t *d = nullptr; size_t n = 0, cap = 0; };
   std::unordered_map<unsigned long long, SeedBuf> seq_seeds;      // by the source's point-set id
   uint32_t *seed_bound = nullptr; size_t seed_bound_cap = 0;
+  struct G2HJob { std::shared_ptr<CellGrid> grid; std::shared_ptr<Order> order; size_t n; };
+  std::vector<G2HJob> g2h_todo;                       // grid_coords_prepare -> flush_g2h
+  int unseeded_grid = 0;                              // 1: the forward searches of a fused pass WITHOUT seeds (a registration's first) walk the grid as well (probe, then the listed sets) instead of the culled kernel
   int seq_model_tail = 1;                             // seq_search 3: the flagged query sets go 1 = to the culled kernel (listed sets), 0 = to the grid's set kernel
   int seq_cell_points = 4;                            // points per occupied cell the MODEL's grid aims at (seq_search 3)
   int seq_search = 1;                                 // mvr_icp_align of a posed scan: 1 (default) = the REVERSE searches walk the source scan's cell grid (compaction by the fused pass's kernels, no hipCUB), the forward search stays with the culled kernel; 2 = the forward search too, through the grids of the posed scans the target is made of (nn_parts_kernel: exact, measured slower -- DESIGN.md 4.5); 0 = the culled kernel for both
@@ -646,7 +649,8 @@ int refresh_grid_coords_batch(Ctx *c, Cloud *const *posed, int count);
 int ensure_pose_table(Ctx *c);      // (mvr_ctx.hip) fills the device pose records of the chain being enqueued if nobody has yet
 // can the posed cloud's grid-ordered coordinates be written now (grid there and ready, buffer, position maps)?  Queues what that needs
 // on the context's stream; the caller then writes gsorted[] and sets gcoords_valid.
-int grid_coords_prepare(Ctx *c, Cloud *cl, bool *ok);      // (*ok = false: no grid to write for; the return value is a status)
+int grid_coords_prepare(Ctx *c, Cloud *cl, bool *ok);
+int flush_g2h(Ctx *c);      // launches what grid_coords_prepare queued (grid position <-> Hilbert position maps), all grids in one launch      // (*ok = false: no grid to write for; the return value is a status)
 // the pipelined pass loop shared by mvr_ring_run and mvr_ring_run_sharded (mvr_ctx.hip).  enqueue(): one pass's GPU work on
 // c->stream, ending with the edge table on its way to c->h_table; solve(): the host step on c->h_table, poses in / out.
 struct PassLoop {

@@ -10,11 +10,13 @@
 //   * a block enters the cache only after the device has drained (hipDeviceSynchronize: what hipFree did implicitly), so whoever
 //     gets it next may use it on any stream;
 //   * size classes: multiples of 1/8 of the enclosing power of two (a request gets at most 12.5 % more than it asked for); a cached
-//     block serves requests down to 2/3 of its size;
+//     block serves requests of ITS class only (a larger block handed to a smaller request would be missing when its own request
+//     comes: identical workloads then find every block they freed);
 //   * the cache holds at most MVR_POOL_CAP_MB (default 16384) per process: beyond that a freed block goes back to the runtime; when
 //     the runtime is out of memory the cache is emptied and the request repeated; mvr_pool_trim() empties it on demand;
 //   * MVR_POOL=0: every call goes straight to the runtime (tools/leak_probe.py, debugging).
 // The cache is never destroyed (no static destructor: the HIP runtime may be gone by then); the process's exit frees the memory.
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -36,11 +38,12 @@ struct Pool {
   std::multimap<Key, void *> idle;
   std::unordered_map<void *, Key> live;
   size_t cached = 0, cap = 0;
-  bool on = true;
+  bool on = true, debug = false;
   unsigned long long hits = 0, misses = 0;
   Pool()
   {
     if (const char *e = std::getenv("MVR_POOL")) on = std::atoi(e) != 0;
+    debug = std::getenv("MVR_POOL_DEBUG") != nullptr;      // every request the cache could not serve, on stderr
     size_t mb = 16384;
     if (const char *e = std::getenv("MVR_POOL_CAP_MB")) mb = (size_t)std::max(0, std::atoi(e));
     cap = mb << 20;
@@ -88,7 +91,7 @@ hipError_t alloc(void **p, size_t bytes, unsigned flags)
   {
     std::lock_guard<std::mutex> lk(P.mu);
     auto it = P.idle.lower_bound(Key{dev, flags, want});
-    if (it != P.idle.end() && it->first.device == dev && it->first.flags == flags && it->first.bytes <= want + want / 2) {
+    if (it != P.idle.end() && it->first.device == dev && it->first.flags == flags && it->first.bytes == want) {
       *p = it->second;
       P.live[*p] = it->first;
       P.cached -= it->first.bytes;
@@ -97,6 +100,7 @@ hipError_t alloc(void **p, size_t bytes, unsigned flags)
       return hipSuccess;
     }
     ++P.misses;
+    if (P.debug) std::fprintf(stderr, "[mvr pool] %zu bytes (class %zu, %s) from the runtime\n", bytes, want, flags == kDeviceMem ? "device" : "pinned");
   }
   hipError_t e = raw_alloc(p, want, flags);
   if (e != hipSuccess) {                       // out of memory with blocks lying idle: give them back and ask again

@@ -377,8 +377,7 @@ int ensure_tables(Ctx *c, int ne)
   const size_t table_n = (size_t)std::max(ne, 1) * 32;
   if (int rc = ensure(c, c->dist_table, c->dist_table_cap, table_n)) return rc;
   if (c->h_table_cap < table_n) {
-    MVR_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_table) (void)hipHostFree(c->h_table);
+    if (c->h_table) { MVR_HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_table); }      // (only an OLD table can still be written to)
     c->h_table = nullptr; c->h_table_cap = 0;
     MVR_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_table), std::max(table_n, (size_t)512) * sizeof(double), hipHostMallocMapped));
     c->h_table_cap = std::max(table_n, (size_t)512);

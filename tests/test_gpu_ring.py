@@ -276,6 +276,32 @@ def test_grid_search_knobs_never_show_in_a_result(mvr, knobs):
     assert runs[0] == runs[1], knobs
 
 
+@pytest.mark.parametrize("n_points", [20000, 3000])
+def test_unseeded_first_pass_through_the_grid(mvr, n_points):
+    """unseeded_grid = 1: the forward searches of a registration's FIRST pass -- no seeds yet, the scans' grids being built on the
+    side stream -- walk the grid as well (every query probes the cells next to it; what finds nothing there goes to the listed
+    sets or the culled kernel) instead of the culled kernel: five passes in one call from a fresh context give the same poses
+    and edge tables, bit for bit, with the probe off, with the sets on the culled kernel and the plain walk too."""
+    V, max_d = 12, 4.0
+    sp = mvr.synth_params(V, 3)
+    scans = [mvr.synth_view(sp, v, n_points) for v in range(V)]
+    piv, ax = mvr.synth_prior(sp)
+    poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+    origin = np.array(sp.pivot)
+    edges = [(i, (i + 1) % V) for i in range(V)]
+    runs = []
+    for kn in ({}, dict(unseeded_grid=1), dict(unseeded_grid=1, grid_probe=0), dict(unseeded_grid=1, grid_sets=0, grid_stage=0), dict(unseeded_grid=1, grid_index=1, grid_light_rows=2)):
+        with mvr.Context(0) as ctx:
+            ctx.tune(**kn)
+            for v in range(V):
+                ctx.upload(V + v, scans[v])
+            poses, info = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=5)
+            one, info1 = ctx.ring_step(list(range(V)), [V + v for v in range(V)], edges, [p.copy() for p in poses0], max_d, origin, steps=1)      # (a restart: seeds 2 mm off)
+            runs.append((np.asarray(poses).tobytes(), info["rows"].tobytes(), np.asarray(one).tobytes(), info1["rows"].tobytes()))
+    for r in runs[1:]:
+        assert r == runs[0]
+
+
 def test_a_culled_pass_after_grid_passes_finds_its_super_boxes(mvr):
     """The posing launch of a pass on the grid kernels leaves the views' super boxes (read by the culled kernel alone) stale
     (lazy_super); a pass that then takes the culled kernel -- ring_search switched off in mid-registration, a one-pair search
