@@ -5,6 +5,8 @@ against the committed golden fixtures.
 Bars (BASELINE.json north_star): indices and float distances bit-exact;
 rotation entries within 1e-5 and translation within 1e-4 mm of the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -395,3 +397,26 @@ def test_one_million_point_pair_properties(gpu, mvr):
     assert mom.n == len(q)
     assert np.allclose(np.ctypeslib.as_array(mom.sp), p.sum(0), rtol=1e-10) and np.allclose(np.ctypeslib.as_array(mom.sq), t.sum(0), rtol=1e-10)
     assert np.allclose(np.ctypeslib.as_array(mom.spq).reshape(3, 3), p.T @ t, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_freed_blocks_serve_the_next_context_and_trim_gives_them_back(mvr):
+    """csrc/mvr_pool.cpp: what a context frees stays in the library's process-wide cache (by device and size class) and serves
+    the next context's requests of the same sizes; mvr_pool_trim hands every idle block back to the runtime.  Results do not
+    depend on where a buffer came from: the second context's search equals the first's."""
+    rng = np.random.default_rng(11)
+    a = np.c_[rng.normal(size=(5000, 3)).astype(np.float32) * 30, np.ones(5000, np.float32)]
+    b = a.copy(); b[:, :3] += rng.normal(size=(5000, 3)).astype(np.float32) * 0.2
+    mvr.pool_trim()
+    before = mvr.pool_trim()
+    outs = []
+    for _ in range(2):
+        with mvr.Context(0) as ctx:
+            ctx.upload(0, a); ctx.upload(1, b)
+            outs.append(bytes(ctx.pair_moments2(0, 1, 4.0, np.zeros(3))))
+    assert outs[0] == outs[1]
+    after = mvr.pool_trim()
+    if os.environ.get("MVR_POOL", "1") != "0":
+        assert after["hits"] > before["hits"]                 # the second context found the first one's blocks
+        assert after["freed_bytes"] > 0 and after["cached_bytes"] == 0
+    assert mvr.pool_trim()["freed_bytes"] == 0                # nothing idle is left
