@@ -84,7 +84,7 @@ hipError_t alloc(void **p, size_t bytes, unsigned flags)
 {
   Pool &P = pool();
   if (!p) return hipErrorInvalidValue;
-  if (!P.on || bytes == 0) return raw_alloc(p, bytes, flags);
+  if (!P.on || bytes == 0 || bytes > ((size_t)1 << 46)) return raw_alloc(p, bytes, flags);      // (an absurd size: the runtime's answer, no class arithmetic)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return raw_alloc(p, bytes, flags); }
   const size_t want = size_class(bytes);
