@@ -196,7 +196,10 @@ __device__ __forceinline__ Ball grid_ball(const GridPair &a, const float4 q, con
   return b;
 }
 
-constexpr int kGridThreads = 256;
+#ifndef MVR_GRID_THREADS
+#define MVR_GRID_THREADS 256
+#endif
+constexpr int kGridThreads = MVR_GRID_THREADS;      // (threads per block of the walk: 128 measured equal -- 281 against 282.5 us of kernels per pass --, 512 slower -- 297; tools/ab_variant_kernels.sh)
 #ifndef MVR_GRID_ROW4
 #define MVR_GRID_ROW4 1
 #endif
