@@ -208,9 +208,9 @@ def main():
     reset()
     # (no collection of Python's heap inside a timed window, as timeit does: a window is a few milliseconds, a collection of this
     # process's heap -- 100 MB of scans -- one of them; it showed as a slow "rank" in the projection leg, twice at the same place.
-    # Collected HERE, ahead of the warm-up steps, so that they also put back what the collection pushed out of the host's caches.)
+    # Switched off ahead of the warm-up steps and back on after the windows.)
     import gc
-    gc.collect(); gc.disable()
+    gc.disable()      # (and no gc.collect() here: a full collection right before the window cost the window 3 % -- the host code ran on cold caches)
     run(max(args.warmup, 1))
     reset()
     ctx.prof_reset(); ctx.prof_enable(prof_level)

@@ -32,7 +32,7 @@ def project(mvr, ctx, V, edges, posed, raw, poses_c, origin, max_d, worlds, step
             rec = {}
             for pipe in (0, 1):
                 ctx.tune(pipeline=pipe)
-                gc.collect(); gc.disable()      # (a collection of the caller's heap inside the 3 ms window showed as a slow "rank": bench.py holds 100 MB of scans; ahead of the warm-up, which also re-warms the host's caches)
+                gc.disable()      # (a collection of the caller's heap inside the 3 ms window showed as a slow "rank": bench.py holds 100 MB of scans; no collection here either -- it leaves the host's caches cold for the window)
                 try:
                     ctx.ring_run_sharded(posed, raw, edges, poses_c, max_d, origin, steps=warm)          # the rank's buffers, seeds, the pipe
                     ctx.sync()
