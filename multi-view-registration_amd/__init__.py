@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -589,6 +590,7 @@ class Context:
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         """ncclCommInitRank on this context's device (collective: every rank calls it with rank 0's unique id)."""
         assert len(unique_id) == 128
+        _torch_before_rccl()
         _chk(_lib.mvr_ctx_comm_init(self._h, unique_id, int(rank), int(world)), self._h)
 
     def project(self, world, rank=0, peer_rows=None):
@@ -766,8 +768,22 @@ class Context:
 
 # ------------------------------------------------------------------ multi-GPU
 
+def _torch_before_rccl():
+    """The library's collectives run on PyTorch-ROCm's copy of RCCL when this process can import torch (MVR_RCCL_LIB above).  A
+    process that initialises that RCCL through the library and imports torch only AFTERWARDS aborts when it exits ("double free or
+    corruption": the two libraries' exit handlers then run in the wrong order -- DESIGN.md section 10); imported first, never.  So the
+    first multi-GPU entry point imports it, if it is there and this RCCL is the one in use."""
+    if "torch" in sys.modules or "torch" not in os.environ.get("MVR_RCCL_LIB", ""):
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def comm_unique_id() -> bytes:
     """ncclGetUniqueId (rank 0); hand the 128 bytes to the other ranks by the launcher's means."""
+    _torch_before_rccl()
     buf = C.create_string_buffer(128)
     _chk(_lib.mvr_comm_unique_id(buf))
     return buf.raw
@@ -810,6 +826,7 @@ class World:
     def __init__(self, n_dev, device_ids=None):
         h = _vp()
         ids = (C.c_int * n_dev)(*device_ids) if device_ids is not None else None
+        _torch_before_rccl()
         rc = _lib.mvr_world_create(C.byref(h), int(n_dev), ids)
         if rc != OK:
             raise MvrError(rc, "mvr_world_create(%d): %s" % (n_dev, rccl_library()))

@@ -4,6 +4,7 @@ single-context loop bit for bit.  More ranks: the partition itself is covered on
 tests/test_host.py::test_ring_segments...) and by the fake worlds of tests/test_gpu_ring.py; the 8-GPU run is the
 driver's."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -308,3 +309,33 @@ def test_bench_with_two_ranks(mvr):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_a_process_that_imports_torch_after_a_collective_exits_cleanly(built):
+    """A process that ran a collective through the library's RCCL (PyTorch-ROCm's copy) and imported torch only afterwards used to
+    abort at interpreter exit ("double free or corruption"); the package now imports torch ahead of its first
+    multi-GPU entry point.  In a fresh interpreter: a world of one, a sharded run, THEN `import torch` -- exit code 0."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, importlib
+import numpy as np
+sys.path.insert(0, %r)
+mvr = importlib.import_module("multi-view-registration_amd")
+assert "torch" not in sys.modules
+V = 4
+sp = mvr.synth_params(V, 3)
+piv, ax = mvr.synth_prior(sp)
+poses0 = [np.eye(4)] + [mvr.axis_rotation(piv, ax, mvr.turntable_angle(v, V)) for v in range(1, V)]
+edges = [(i, (i + 1) %% V) for i in range(V)]
+with mvr.Context(0) as ctx:
+    ctx.comm_init(mvr.comm_unique_id(), 0, 1)
+    for v in range(V):
+        ctx.upload(V + v, mvr.synth_view(sp, v, 3000))
+    ctx.ring_run_sharded(list(range(V)), [V + v for v in range(V)], edges, poses0, 4.0, np.array(sp.pivot), steps=2)
+import torch
+print("done", torch.cuda.device_count() >= 1)
+""" % root
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "done True" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
