@@ -197,9 +197,9 @@ __device__ __forceinline__ Ball grid_ball(const GridPair &a, const float4 q, con
 }
 
 #ifndef MVR_GRID_THREADS
-#define MVR_GRID_THREADS 256
+#define MVR_GRID_THREADS 128
 #endif
-constexpr int kGridThreads = MVR_GRID_THREADS;      // (threads per block of the walk: 128 measured equal -- 281 against 282.5 us of kernels per pass --, 512 slower -- 297; tools/ab_variant_kernels.sh)
+constexpr int kGridThreads = MVR_GRID_THREADS;      // (threads per block of the walk: 128 and 256 measured equal -- 281 against 282.5 us of kernels per pass --, 512 slower -- 297; 128 it is since the two waves of a block stage ONE region together, MVR_STAGE_BLOCK; tools/ab_variant_kernels.sh)
 #ifndef MVR_GRID_ROW4
 #define MVR_GRID_ROW4 1
 #endif
@@ -322,6 +322,9 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t x, uint32_t *tot
 #endif
 #ifndef MVR_STAGE_PROBE
 #define MVR_STAGE_PROBE 0
+#endif
+#ifndef MVR_STAGE_BLOCK
+#define MVR_STAGE_BLOCK (MVR_GRID_THREADS == 128)
 #endif
 constexpr int kStageRows = MVR_STAGE_ROWS;     // rows of cells of a wave's box: one or two per lane
 constexpr int kStagePts = MVR_STAGE_PTS;       // points a wave stages at most (16 bytes each; + the table: ~7.5 KB of LDS per wave at 384)
@@ -546,16 +549,32 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
   MVR_CK();
   if constexpr (STAGE) {
     static_assert(kStageRows == 64, "one row of the box per lane");
-    constexpr int kMarkBytes = (kStagePts + 3 + 63) / 64 * 64 < 256 ? 256 : (kStagePts + 3 + 63) / 64 * 64;      // (at least the 64 words the lanes clear with one store each)
-    __shared__ float4 s_pts[kGridThreads / 64][kStagePts + 4];
-    __shared__ uint2 s_rows[kGridThreads / 64][kStageRows];          // per row of the box: {grid position of its first staged point, staged position of that point} ({~0, ~0}: not staged)
-    __shared__ uint32_t s_mask[kGridThreads / 64][kStageRows];       // per row of the box: the cells (bit c = cell X0 + c) some lane's ball overlaps
-    __shared__ uint32_t s_mark[kGridThreads / 64][kMarkBytes / 4];   // per staged position (a byte each): row + 1 where a row's points begin, else 0
+    // (MVR_STAGE_BLOCK, the default with blocks of 128 threads: the two waves of a block stage ONE region for their 128 queries -- the
+    // hull of both, a row of it per THREAD, twice the points -- instead of one each.  Settled passes equal (the hull of 128 Hilbert
+    // neighbours holds 1.4 x the points of 64, the waves wait for each other at five barriers); the passes after a large motion, whose
+    // balls are wide, fit the shared 384 points where they overflowed 192: pass 1 of a window from the prior 0.58 -> 0.54 ms, its first
+    // ten passes 0.372 -> 0.364 ms.  -DMVR_GRID_THREADS=256 -DMVR_STAGE_BLOCK=0 builds the per-wave form.)
+    constexpr bool kBlk = MVR_STAGE_BLOCK != 0;
+    static_assert(!kBlk || (kGridThreads == 128 && !kStageProbe), "block-wide staging: two waves per block, no staged probe");
+    constexpr int kWaves = kGridThreads / 64, kSets = kBlk ? 1 : kWaves;
+    constexpr int kRowsT = kBlk ? 2 * kStageRows : kStageRows, kPtsT = kBlk ? 2 * kStagePts : kStagePts, kClear = kBlk ? 512 : 256;
+    constexpr int kMarkBytes = (kPtsT + 3 + 63) / 64 * 64 < kClear ? kClear : (kPtsT + 3 + 63) / 64 * 64;      // (at least the words the threads clear with one store each)
+    __shared__ float4 s_pts[kSets][kPtsT + 4];
+    __shared__ uint2 s_rows[kSets][kRowsT];          // per row of the box: {grid position of its first staged point, staged position of that point} ({~0, ~0}: not staged)
+    __shared__ uint32_t s_mask[kSets][kRowsT];       // per row of the box: the cells (bit c = cell X0 + c) some lane's ball overlaps
+    __shared__ uint32_t s_mark[kSets][kMarkBytes / 4];   // per staged position (a byte each): row + 1 where a row's points begin, else 0
+    __shared__ int s_red[kBlk ? kWaves : 1][8];       // (block-wide staging: the waves' partial results meet here)
+    __shared__ uint32_t s_ends[kBlk ? kRowsT : 1], s_cmax[kBlk ? (kPtsT + 3 + 63) / 64 + 1 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4 *const pts = s_pts[wv];
-    uint2 *const rowtab = s_rows[wv];
-    uint32_t *const rmask = s_mask[wv];
-    uint8_t *const mark = reinterpret_cast<uint8_t *>(s_mark[wv]);
+    const int sw = kBlk ? 0 : wv, tid = kBlk ? (int)threadIdx.x : lane;
+    float4 *const pts = s_pts[sw];
+    uint2 *const rowtab = s_rows[sw];
+    uint32_t *const rmask = s_mask[sw];
+    uint8_t *const mark = reinterpret_cast<uint8_t *>(s_mark[sw]);
+    auto sync = [&]() {
+      if constexpr (kBlk) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    };
     // what a lane walks in the staged step: the box of its ball -- or, for a ball that is to be probed first, the probe's
     // 2 x 2 x 2 cells (the probe IS a walk: in the passes after a large motion nearly every lane probes, and four rows from
     // global memory per lane was what those passes' launches were made of)
@@ -584,58 +603,84 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
         }
     }
     // ---- 1. the box of the walking lanes' cells
-    const int X0 = wave_min_i32(swalk ? bx0 : 0x7FFFFFFF), X1 = wave_max_i32(swalk ? bx1 : -1);
+    int X0 = wave_min_i32(swalk ? bx0 : 0x7FFFFFFF), X1 = wave_max_i32(swalk ? bx1 : -1);
+    int Y0 = 0, Y1 = -1, Z0 = 0, Z1 = -1;
+    if constexpr (kBlk) {
+      Y0 = wave_min_i32(swalk ? by0 : 0x7FFFFFFF); Y1 = wave_max_i32(swalk ? by1 : -1);
+      Z0 = wave_min_i32(swalk ? bz0 : 0x7FFFFFFF); Z1 = wave_max_i32(swalk ? bz1 : -1);
+      if (lane == 0) { s_red[wv][0] = X0; s_red[wv][1] = X1; s_red[wv][2] = Y0; s_red[wv][3] = Y1; s_red[wv][4] = Z0; s_red[wv][5] = Z1; }
+      __syncthreads();
+      X0 = min(s_red[0][0], s_red[1][0]); X1 = max(s_red[0][1], s_red[1][1]); Y0 = min(s_red[0][2], s_red[1][2]); Y1 = max(s_red[0][3], s_red[1][3]);
+      Z0 = min(s_red[0][4], s_red[1][4]); Z1 = max(s_red[0][5], s_red[1][5]);
+    }
     uint32_t why = 0;      // diagnostics: 1 staged in full, 2 more rows than the table holds (the rows behind it from global memory), 3 too wide, 4 more points than fit (the rows behind from global memory)
     if (X1 >= X0) {
-      const int Y0 = wave_min_i32(swalk ? by0 : 0x7FFFFFFF), Y1 = wave_max_i32(swalk ? by1 : -1);
-      const int Z0 = wave_min_i32(swalk ? bz0 : 0x7FFFFFFF), Z1 = wave_max_i32(swalk ? bz1 : -1);
+      if constexpr (!kBlk) {
+        Y0 = wave_min_i32(swalk ? by0 : 0x7FFFFFFF); Y1 = wave_max_i32(swalk ? by1 : -1);
+        Z0 = wave_min_i32(swalk ? bz0 : 0x7FFFFFFF); Z1 = wave_max_i32(swalk ? bz1 : -1);
+      }
       const int NY = Y1 - Y0 + 1, R = NY * (Z1 - Z0 + 1), W = X1 - X0 + 1;
       if (W > 32) why = 3u;
       else {
-        const int Rs = min(R, kStageRows);          // rows of the box that get a table entry: the first Rs in y-major order
+        const int Rs = min(R, kRowsT);          // rows of the box that get a table entry: the first Rs in y-major order
         // ---- 2a. which cells of which rows are wanted at all: every lane ORs the x-range of its ball into the masks of its rows
         // (the box is the hull of the balls -- a surface runs through it at an angle, most of its cells are nobody's)
-        rmask[lane] = 0u;
-        reinterpret_cast<uint32_t *>(mark)[lane] = 0u;
-        if (kMarkBytes > 256) { for (int i = 64 + lane; i < kMarkBytes / 4; i += 64) reinterpret_cast<uint32_t *>(mark)[i] = 0u; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        rmask[tid] = 0u;
+        reinterpret_cast<uint32_t *>(mark)[tid] = 0u;
+        if (kMarkBytes > kClear) { for (int i = kClear / 4 + tid; i < kMarkBytes / 4; i += kClear / 4) reinterpret_cast<uint32_t *>(mark)[i] = 0u; }
+        sync();
         const uint32_t z_step_r = (uint32_t)(NY - ny);
         if (swalk) {
           const uint32_t bits = ((nxm >= 31u ? 0xFFFFFFFFu : ((2u << nxm) - 1u))) << (uint32_t)(bx0 - X0);
           uint32_t ridx = (uint32_t)((bz0 - Z0) * NY + (by0 - Y0));
           int ryi = 0;
           for (int k = 0; k < nrows; ++k) {
-            if (ridx < (uint32_t)kStageRows) __hip_atomic_fetch_or(&rmask[ridx], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (ridx < (uint32_t)kRowsT) __hip_atomic_fetch_or(&rmask[ridx], bits, __ATOMIC_RELAXED, kBlk ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_WAVEFRONT);
             ridx += 1u;
             if (++ryi == ny) { ryi = 0; ridx += z_step_r; }
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sync();
         // ---- 2b. the rows of the box, a lane each (row `lane` = (Y0 + lane % NY, Z0 + lane / NY)): where its wanted cells
         // [first, last] begin and end in the grid-ordered array
         uint32_t sA = 0, len = 0, P = 0;
-        const uint32_t m = lane < Rs ? rmask[lane] : 0u;
+        const uint32_t m = tid < Rs ? rmask[tid] : 0u;
         if (m) {
-          const int zq = (int)(((float)lane + 0.5f) * (1.0f / (float)NY)), yq = lane - zq * NY;      // (lane / NY: the float quotient is off by 1e-5 at most, the true one sits 1 / (2 NY) from an integer)
+          const int zq = (int)(((float)tid + 0.5f) * (1.0f / (float)NY)), yq = tid - zq * NY;      // (tid / NY: the float quotient is off by 1e-5 at most, the true one sits 1 / (2 NY) from an integer)
           const uint32_t base = (uint32_t)(((Z0 + zq) * a.dim[1] + (Y0 + yq)) * a.dim[0] + X0);
           const uint32_t first = (uint32_t)__builtin_ctz(m), last = 31u - (uint32_t)__builtin_clz(m);
           sA = cell_start_of(a, base + first);
           len = cell_start_of(a, base + last + 1u) - sA;
         }
-        const uint32_t off = wave_scan_incl_u32(len, &P) - len;
+        uint32_t off = wave_scan_incl_u32(len, &P) - len;
+        if constexpr (kBlk) {      // (the second wave's rows begin behind the first wave's)
+          if (lane == 0) s_red[wv][6] = (int)P;
+          __syncthreads();
+          if (wv == 1) off += (uint32_t)s_red[0][6];
+          P = (uint32_t)s_red[0][6] + (uint32_t)s_red[1][6];
+        }
         // rows are staged in order while they fit: a row that does not fit any more (and every row behind it) is walked from
         // global memory by the lanes that want it -- the staging degrades row by row instead of failing for the wave
         staged = true;
-        const bool fits = off + len <= (uint32_t)kStagePts;
-        why = P > (uint32_t)kStagePts ? 4u : R > kStageRows ? 2u : 1u;
-        rowtab[lane] = fits ? make_uint2(sA, off) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (fits && len) mark[off] = (uint8_t)(lane + 1);
+        const bool fits = off + len <= (uint32_t)kPtsT;
+        why = P > (uint32_t)kPtsT ? 4u : R > kRowsT ? 2u : 1u;
+        rowtab[tid] = fits ? make_uint2(sA, off) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (fits && len) mark[off] = (uint8_t)(tid + 1);
         uint32_t Ps = P;
-        if (P > (uint32_t)kStagePts) {      // (what is staged: the rows before the first that does not fit -- `fits` is monotone)
-          const int nfit = __popcll(__ballot(fits));
-          Ps = nfit ? (uint32_t)__builtin_amdgcn_readlane((int)(off + len), nfit - 1) : 0u;
+        if (P > (uint32_t)kPtsT) {      // (what is staged: the rows before the first that does not fit -- `fits` is monotone)
+          if constexpr (kBlk) {
+            s_ends[tid] = off + len;
+            const int nf = __popcll(__ballot(fits));
+            if (lane == 0) s_red[wv][7] = nf;
+            __syncthreads();
+            const int nfit = s_red[0][7] + s_red[1][7];
+            Ps = nfit ? s_ends[nfit - 1] : 0u;
+          } else {
+            const int nfit = __popcll(__ballot(fits));
+            Ps = nfit ? (uint32_t)__builtin_amdgcn_readlane((int)(off + len), nfit - 1) : 0u;
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sync();
         MVR_CK();
         // ---- 3. the points: staged position j <- the row whose range holds it: the last row that begins at or before j -- a
         // running maximum over the positions' marks (row + 1 where a row begins), 64 positions at a time; three more positions
@@ -643,6 +688,44 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
         // instruction, and the instruction is an LDS-DMA load (global_load_lds_dwordx4: per-lane source address, destination
         // = a wave-uniform LDS address + 16 x lane): no registers for the data, no ds_write, ALL of a wave's point loads in
         // flight at once.
+        if constexpr (kBlk) {
+          // (chunks of 64 staged positions alternate between the two waves; the running maximum of the marks is taken inside a
+          // chunk first, the chunks' maxima meet in LDS, then every chunk adds what lies before it)
+          constexpr int kChunks = (kPtsT + 3 + 63) / 64, kOwn = (kChunks + 1) / 2;
+          const uint32_t Pm1 = Ps ? Ps - 1u : 0u, n_stage = Ps ? Ps + 3u : 0u;
+          int vv[kOwn];
+#pragma unroll
+          for (int k = 0; k < kOwn; ++k) {
+            const int c = 2 * k + wv;
+            vv[k] = 0;
+            if (c < kChunks && (uint32_t)(c * 64) < n_stage) {
+              const uint32_t j = (uint32_t)(c * 64 + lane);
+              int v = j <= Pm1 ? (int)mark[j] : 0;
+              v = max(v, dpp_keep<0x111>(v)); v = max(v, dpp_keep<0x112>(v)); v = max(v, dpp_keep<0x114>(v)); v = max(v, dpp_keep<0x118>(v));
+              const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+              const int q4 = lane >> 4;
+              const int before = q4 == 0 ? 0 : q4 == 1 ? r0 : q4 == 2 ? max(r0, r1) : max(max(r0, r1), r2);
+              vv[k] = max(v, before);
+              if (lane == 0) s_cmax[c] = (uint32_t)max(max(r0, r1), max(r2, r3));
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < kOwn; ++k) {
+            const int c = 2 * k + wv;
+            if (c < kChunks && (uint32_t)(c * 64) < n_stage) {
+              int carry = 0;
+              for (int cc = 0; cc < c; ++cc) carry = max(carry, (int)s_cmax[cc]);
+              const uint32_t j = (uint32_t)(c * 64 + lane), jj = min(j, Pm1);
+              const int v = max(vv[k], carry);
+              const uint2 t = rowtab[v - 1];          // (v >= 1: position 0 is the beginning of the first row with points)
+              if (j < n_stage)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.gts + (t.x + (jj - t.y))),
+                                                 (__attribute__((address_space(3))) void *)(pts + c * 64), 16, 0, 0);
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else
         if (Ps) {
           const uint32_t Pm1 = Ps - 1u, n_stage = Ps + 3u;
           int carry = 0;
@@ -665,7 +748,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA writes count as vector memory operations of this wave
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sync();
         MVR_CK();
         // ---- 4. every lane walks its own cells: a row's range in the grid-ordered array (asked for above, kBurst rows at a
         // time) becomes a range of staged positions through the row's table entry -- or stays what it is for a row that was
@@ -687,7 +770,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
             for (int u = 0; u < kBurst; ++u)
               if (k0 + u < nrows) {
                 uint2 t = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-                if (ridx < (uint32_t)kStageRows) t = rowtab[ridx];
+                if (ridx < (uint32_t)kRowsT) t = rowtab[ridx];
                 ridx += 1u;
                 if (++ryi == ny) { ryi = 0; ridx += z_step_r; }
                 n_eval += be[u] - bs[u];
