@@ -487,8 +487,8 @@ enum { MVR_K_NN = 0, MVR_K_REDUCE = 1, MVR_K_XFORM = 2, MVR_K_GLUE = 3,
  * communicator), and the test hooks "inject_fail_pass" / "inject_stall_pass" (the k-th sharded pass or iteration from now:
  * this rank's local work fails / its stream stalls in front of the collective as if a peer never arrived; -1: off).
  * Round 4: "grid_stage" (the staged walk: a wave of the grid walk copies the cells its lanes want into LDS -- LDS-DMA loads -- and
- * walks them there; 1, default: the launches over a scan's own query order, i.e. the forward searches; 2: the reverse searches'
- * launches too; 0: off; also MVR_GRID_STAGE), "grid_stage_stat" (1: counters of the staged walk's waves by outcome, read with
+ * walks them there -- the two waves of a block one region together; 2, default: every walk launch; 1: only the launches over a scan's
+ * own query order, i.e. the forward searches; 0: off; also MVR_GRID_STAGE), "grid_stage_stat" (1: counters of the staged walk's waves by outcome, read with
  * mvr_ctx_stat "stage_staged" / "stage_rows" / "stage_width" / "stage_points"), "grid_index" (a grid's cell-start table, for grids
  * built from then on: 2, default = dense, built through the compact form and expanded; 1 = compact: a directory of 32-cell segments
  * + records of the occupied ones, a tenth of the bytes, walks 8-11 % slower; 0 = the round-3 dense build; also MVR_GRID_INDEX),

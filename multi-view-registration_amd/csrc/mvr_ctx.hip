@@ -409,7 +409,7 @@ static int ctx_create_impl(mvr_ctx **out, int device_id, void *hip_stream, bool 
   if (const char *m = std::getenv("MVR_PAIR_FUSED")) c->pair_fused = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PIPELINE")) c->pipeline = std::atoi(m) != 0;      // 0: no pass is enqueued ahead of its poses
   if (const char *m = std::getenv("MVR_GRID_INDEX")) c->grid_index = std::max(0, std::min(2, std::atoi(m)));      // 0 dense cell starts, 1 compact, 2 by size (default)
-  if (const char *m = std::getenv("MVR_GRID_STAGE")) c->grid_stage = std::max(0, std::min(2, std::atoi(m)));      // the staged walk: 0 off, 1 forward launches (default), 2 all
+  if (const char *m = std::getenv("MVR_GRID_STAGE")) c->grid_stage = std::max(0, std::min(2, std::atoi(m)));      // the staged walk: 0 off, 1 forward launches, 2 all (default)
   if (const char *m = std::getenv("MVR_POSED_REFRESH")) c->posed_refresh = std::atoi(m) != 0;
   if (const char *m = std::getenv("MVR_PAIR_GROUPS")) c->pair_groups = std::max(1, std::min(8, std::atoi(m)));
   if (const char *m = std::getenv("MVR_PAIR_STREAMS")) c->pair_streams = std::max(1, std::min(16, std::atoi(m)));
@@ -2682,7 +2682,7 @@ API int mvr_ctx_tune(mvr_ctx *ctx, const char *key, int value)
   else if (!std::strcmp(key, "grid_cluster")) { if (value < 1) return MVR_E_ARG; c->grid_cluster = value; }
   else if (!std::strcmp(key, "grid_wide_waves")) { if (value < 1 || value > 64) return MVR_E_ARG; c->grid_wide_waves = value; }
   else if (!std::strcmp(key, "grid_stage")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_stage = value; }
-  else if (!std::strcmp(key, "grid_stage_lone")) c->grid_stage_lone = value != 0;
+  else if (!std::strcmp(key, "grid_stage_lone")) { if (value < 0 || value > 2) return MVR_E_ARG; c->grid_stage_lone = value; }      // a lone pair's launches: 0 never staged, 1 (default) the ones over a scan's own query order, 2 all
   else if (!std::strcmp(key, "grid_stage_stat")) {
     if (value && !c->stage_stat) { MVR_HIP_TRY(c, hipMalloc(&c->stage_stat, 64 * 64 * sizeof(unsigned long long))); }
     if (c->stage_stat) { MVR_HIP_TRY(c, hipStreamSynchronize(c->stream)); MVR_HIP_TRY(c, hipMemset(c->stage_stat, 0, 64 * 64 * sizeof(unsigned long long))); }

@@ -312,7 +312,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t x, uint32_t *tot
 // plain walk (70 us against 72 staged).  Memory-side traffic is unchanged (286 MB per forward launch): a wave's lines were
 // shared through the L1 / L2 before, they are fetched once per wave now -- the misses are the same lines.
 #ifndef MVR_STAGE_PTS
-#define MVR_STAGE_PTS 192
+#define MVR_STAGE_PTS 224
 #endif
 #ifndef MVR_STAGE_ROWS
 #define MVR_STAGE_ROWS 64
@@ -1593,11 +1593,14 @@ int launch_nn_grid_batch(Ctx *c, const GridPair *pairs, int n_pairs, float cap2,
     ProfScope ps(c, MVR_K_NN_GRID, per_launch ? c->evals : nullptr, (int)(kEvalRegion * sizeof(unsigned long long)), 1.0, 0.0, per_launch ? kEvalShards : 0);
 #define MVR_GRID_LAUNCH(F, GG) hipLaunchKernelGGL((nn_grid_kernel<F, GG, false>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals, (unsigned long long *)nullptr)
 #define MVR_GRID_LAUNCH_STAGED(F) hipLaunchKernelGGL((nn_grid_kernel<F, 1, true>), dim3(grid_blocks), dim3(kGridThreads), 0, c->stream, batch, map, c->evals, c->stage_stat)
-    // (the staged walk for launches over a scan's OWN query order -- the forward searches; a launch over a compacted list, the
-    // reverse searches, has queries 2.4 x sparser and boxes that do not fit: measured equal or slower there.  grid_stage = 2: both)
+    // (grid_stage 1: the staged walk for launches over a scan's OWN query order only -- the forward searches; a launch over a compacted
+    // list, the reverse searches, has queries 2.4 x sparser: with a region per WAVE its boxes did not fit, measured equal or slower.
+    // grid_stage 2, the default since a block's two waves stage one region of 448 points together: both -- the step -1.4 %)
     bool listed = false;
     for (int k = 0; k < m; ++k) listed = listed || (batch.p[k].q_count != 0 && batch.p[k].qlist != nullptr);
-    const bool stage = lanes == 1 && c->grid_stage && (c->grid_stage == 2 || !listed) && (n_pairs > 1 || c->grid_stage_lone);
+    // (a LONE pair's launch over a list -- the reverse search of a sequential align, 3 waves per SIMD -- stays plain: staged it measured
+    // 1.5 % of an align slower; grid_stage_lone = 2 stages it all the same)
+    const bool stage = lanes == 1 && c->grid_stage && (c->grid_stage == 2 || !listed) && (n_pairs > 1 || (c->grid_stage_lone && (!listed || c->grid_stage_lone == 2)));
     if (stage) { if (fma) MVR_GRID_LAUNCH_STAGED(true); else MVR_GRID_LAUNCH_STAGED(false); }
     else
     switch (lanes) {

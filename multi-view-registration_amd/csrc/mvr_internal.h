@@ -318,7 +318,7 @@ struct Ctx {
   // coalesced loads and every lane walks its own cells there -- the walk is bound by the number of vector memory instructions a
   // wave issues, not by bytes.  0: the plain walk; 1 (default): launches over a scan's own query order (the forward searches); 2: every
   // launch, compacted query lists too (measured equal or slower there).  A lone pair's launch has its own switch.
-  int grid_stage = 1, grid_stage_lone = 1;
+  int grid_stage = 2, grid_stage_lone = 1;      // (2 since the two waves of a block stage one region together: the reverse launches' sparser queries fit it too)
   unsigned long long *stage_stat = nullptr;              // diagnostics (tune key grid_stage_stat = 1): device counters [64 shards][64] of the staged walk's waves: [1] staged, [2] too many rows, [3] too wide, [4] too many points
   int grid_lanes = 1;                                    // lanes that share one query of the grid search (1, 2, 4 or 8): they deal the ball's rows of cells among them
   int grid_cluster = 8;                                  // a wave of the grid search with at least this many wide queries hands them ALL to the culled kernel (65: never)
