@@ -555,10 +555,12 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
     // balls are wide, fit the shared 384 points where they overflowed 192: pass 1 of a window from the prior 0.58 -> 0.54 ms, its first
     // ten passes 0.372 -> 0.364 ms.  -DMVR_GRID_THREADS=256 -DMVR_STAGE_BLOCK=0 builds the per-wave form.)
     constexpr bool kBlk = MVR_STAGE_BLOCK != 0;
-    static_assert(!kBlk || (kGridThreads == 128 && !kStageProbe), "block-wide staging: two waves per block, no staged probe");
+    static_assert(!kBlk || ((kGridThreads == 128 || kGridThreads == 256) && !kStageProbe), "block-wide staging: two or four waves per block, no staged probe");
     constexpr int kWaves = kGridThreads / 64, kSets = kBlk ? 1 : kWaves;
-    constexpr int kRowsT = kBlk ? 2 * kStageRows : kStageRows, kPtsT = kBlk ? 2 * kStagePts : kStagePts, kClear = kBlk ? 512 : 256;
-    constexpr int kMarkBytes = (kPtsT + 3 + 63) / 64 * 64 < kClear ? kClear : (kPtsT + 3 + 63) / 64 * 64;      // (at least the words the threads clear with one store each)
+    constexpr int kRowsT = kBlk ? kWaves * kStageRows : kStageRows, kPtsT = kBlk ? kWaves * kStagePts : kStagePts, kClear = kBlk ? 4 * kGridThreads : 256;
+    typedef typename std::conditional<(kRowsT > 255), uint16_t, uint8_t>::type mark_t;      // (row + 1 per staged position: 256 rows need nine bits)
+    constexpr int kMarkBytesRaw = (kPtsT + 3 + 63) / 64 * 64 * (int)sizeof(mark_t);
+    constexpr int kMarkBytes = kMarkBytesRaw < kClear ? kClear : (kMarkBytesRaw + kClear - 1) / kClear * kClear;      // (a multiple of what the threads clear with one store each)
     __shared__ float4 s_pts[kSets][kPtsT + 4];
     __shared__ uint2 s_rows[kSets][kRowsT];          // per row of the box: {grid position of its first staged point, staged position of that point} ({~0, ~0}: not staged)
     __shared__ uint32_t s_mask[kSets][kRowsT];       // per row of the box: the cells (bit c = cell X0 + c) some lane's ball overlaps
@@ -570,7 +572,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
     float4 *const pts = s_pts[sw];
     uint2 *const rowtab = s_rows[sw];
     uint32_t *const rmask = s_mask[sw];
-    uint8_t *const mark = reinterpret_cast<uint8_t *>(s_mark[sw]);
+    mark_t *const mark = reinterpret_cast<mark_t *>(s_mark[sw]);
     auto sync = [&]() {
       if constexpr (kBlk) __syncthreads();
       else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -610,8 +612,11 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
       Z0 = wave_min_i32(swalk ? bz0 : 0x7FFFFFFF); Z1 = wave_max_i32(swalk ? bz1 : -1);
       if (lane == 0) { s_red[wv][0] = X0; s_red[wv][1] = X1; s_red[wv][2] = Y0; s_red[wv][3] = Y1; s_red[wv][4] = Z0; s_red[wv][5] = Z1; }
       __syncthreads();
-      X0 = min(s_red[0][0], s_red[1][0]); X1 = max(s_red[0][1], s_red[1][1]); Y0 = min(s_red[0][2], s_red[1][2]); Y1 = max(s_red[0][3], s_red[1][3]);
-      Z0 = min(s_red[0][4], s_red[1][4]); Z1 = max(s_red[0][5], s_red[1][5]);
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        if (w == 0) { X0 = s_red[0][0]; X1 = s_red[0][1]; Y0 = s_red[0][2]; Y1 = s_red[0][3]; Z0 = s_red[0][4]; Z1 = s_red[0][5]; }
+        else { X0 = min(X0, s_red[w][0]); X1 = max(X1, s_red[w][1]); Y0 = min(Y0, s_red[w][2]); Y1 = max(Y1, s_red[w][3]); Z0 = min(Z0, s_red[w][4]); Z1 = max(Z1, s_red[w][5]); }
+      }
     }
     uint32_t why = 0;      // diagnostics: 1 staged in full, 2 more rows than the table holds (the rows behind it from global memory), 3 too wide, 4 more points than fit (the rows behind from global memory)
     if (X1 >= X0) {
@@ -627,7 +632,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
         // (the box is the hull of the balls -- a surface runs through it at an angle, most of its cells are nobody's)
         rmask[tid] = 0u;
         reinterpret_cast<uint32_t *>(mark)[tid] = 0u;
-        if (kMarkBytes > kClear) { for (int i = kClear / 4 + tid; i < kMarkBytes / 4; i += kClear / 4) reinterpret_cast<uint32_t *>(mark)[i] = 0u; }
+        if (kMarkBytes > kClear) { for (int i = kClear / 4 + tid; i < kMarkBytes / 4; i += kClear / 4) reinterpret_cast<uint32_t *>(mark)[i] = 0u; }      // (kClear / 4 = the threads that clear: 64 per wave form, all of the block)
         sync();
         const uint32_t z_step_r = (uint32_t)(NY - ny);
         if (swalk) {
@@ -656,8 +661,9 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
         if constexpr (kBlk) {      // (the second wave's rows begin behind the first wave's)
           if (lane == 0) s_red[wv][6] = (int)P;
           __syncthreads();
-          if (wv == 1) off += (uint32_t)s_red[0][6];
-          P = (uint32_t)s_red[0][6] + (uint32_t)s_red[1][6];
+          P = 0u;
+#pragma unroll
+          for (int w = 0; w < kWaves; ++w) { if (w < wv) off += (uint32_t)s_red[w][6]; P += (uint32_t)s_red[w][6]; }
         }
         // rows are staged in order while they fit: a row that does not fit any more (and every row behind it) is walked from
         // global memory by the lanes that want it -- the staging degrades row by row instead of failing for the wave
@@ -665,7 +671,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
         const bool fits = off + len <= (uint32_t)kPtsT;
         why = P > (uint32_t)kPtsT ? 4u : R > kRowsT ? 2u : 1u;
         rowtab[tid] = fits ? make_uint2(sA, off) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (fits && len) mark[off] = (uint8_t)(tid + 1);
+        if (fits && len) mark[off] = (mark_t)(tid + 1);
         uint32_t Ps = P;
         if (P > (uint32_t)kPtsT) {      // (what is staged: the rows before the first that does not fit -- `fits` is monotone)
           if constexpr (kBlk) {
@@ -673,7 +679,9 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
             const int nf = __popcll(__ballot(fits));
             if (lane == 0) s_red[wv][7] = nf;
             __syncthreads();
-            const int nfit = s_red[0][7] + s_red[1][7];
+            int nfit = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) nfit += s_red[w][7];
             Ps = nfit ? s_ends[nfit - 1] : 0u;
           } else {
             const int nfit = __popcll(__ballot(fits));
@@ -691,12 +699,12 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
         if constexpr (kBlk) {
           // (chunks of 64 staged positions alternate between the two waves; the running maximum of the marks is taken inside a
           // chunk first, the chunks' maxima meet in LDS, then every chunk adds what lies before it)
-          constexpr int kChunks = (kPtsT + 3 + 63) / 64, kOwn = (kChunks + 1) / 2;
+          constexpr int kChunks = (kPtsT + 3 + 63) / 64, kOwn = (kChunks + kWaves - 1) / kWaves;
           const uint32_t Pm1 = Ps ? Ps - 1u : 0u, n_stage = Ps ? Ps + 3u : 0u;
           int vv[kOwn];
 #pragma unroll
           for (int k = 0; k < kOwn; ++k) {
-            const int c = 2 * k + wv;
+            const int c = kWaves * k + wv;
             vv[k] = 0;
             if (c < kChunks && (uint32_t)(c * 64) < n_stage) {
               const uint32_t j = (uint32_t)(c * 64 + lane);
@@ -712,7 +720,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
           __syncthreads();
 #pragma unroll
           for (int k = 0; k < kOwn; ++k) {
-            const int c = 2 * k + wv;
+            const int c = kWaves * k + wv;
             if (c < kChunks && (uint32_t)(c * 64) < n_stage) {
               int carry = 0;
               for (int cc = 0; cc < c; ++cc) carry = max(carry, (int)s_cmax[cc]);
