@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LD
            "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  for st in 1 0; do
+  for st in 2 0; do
     mkdir -p $O/p${i}_s$st
     echo "pass $i stage=$st: $set" >> $O/progress.txt
     MVR_PROBE_PROF=0 timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p${i}_s$st -- python3 $R/tools/step_probe.py 12 200000 6 25 pair_groups=1 grid_stage=$st "$@" > $O/p${i}_s$st/log.txt 2>&1 || echo "pass $i stage=$st failed" >> $O/summary.txt

@@ -2,7 +2,7 @@
 # where a wave of the staged walk spends its cycles (diagnostics build: tools/build_variant.sh clock -DMVR_STAGE_CLOCK)
 #   tools/stage_clock.sh [knob=value ...]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/stage_clock; mkdir -p $O; cd $R
-MVR_LIB_VARIANT=clock MVR_PROBE_PROF=0 timeout -k 10 120 python3 tools/step_probe.py 12 200000 20 25 pipeline=1 grid_stage=1 grid_stage_stat=1 "$@" > $O/clock.json 2> $O/clock.err || { tail $O/clock.err; exit 1; }
+MVR_LIB_VARIANT=clock MVR_PROBE_PROF=0 timeout -k 10 120 python3 tools/step_probe.py 12 200000 20 25 pipeline=1 grid_stage_stat=1 "$@" > $O/clock.json 2> $O/clock.err || { tail $O/clock.err; exit 1; }
 python3 - $O/clock.json <<'P'
 import json, sys
 r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
