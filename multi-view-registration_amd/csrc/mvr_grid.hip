@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(kGridThreads) MVR_GRID_OCC nn_grid_kernel(Grid
     // balls are wide, fit the shared 384 points where they overflowed 192: pass 1 of a window from the prior 0.58 -> 0.54 ms, its first
     // ten passes 0.372 -> 0.364 ms.  -DMVR_GRID_THREADS=256 -DMVR_STAGE_BLOCK=0 builds the per-wave form.)
     constexpr bool kBlk = MVR_STAGE_BLOCK != 0;
-    static_assert(!kBlk || ((kGridThreads == 128 || kGridThreads == 256) && !kStageProbe), "block-wide staging: two or four waves per block, no staged probe");
+    static_assert(!kBlk || kGridThreads == 128 || kGridThreads == 256, "block-wide staging: two or four waves per block");
     constexpr int kWaves = kGridThreads / 64, kSets = kBlk ? 1 : kWaves;
     constexpr int kRowsT = kBlk ? kWaves * kStageRows : kStageRows, kPtsT = kBlk ? kWaves * kStagePts : kStagePts, kClear = kBlk ? 4 * kGridThreads : 256;
     typedef typename std::conditional<(kRowsT > 255), uint16_t, uint8_t>::type mark_t;      // (row + 1 per staged position: 256 rows need nine bits)
