@@ -2186,6 +2186,10 @@ static int run_search_parts(Ctx *c, Cloud &cur, Cloud &tgt, double max_dist, boo
       if (int rc = launch_nn_grid_wide_batch(c, &f, 1, cap2, fma)) return rc;
       CullPair p = make_cull_pair(cur, 0, ns, c->bheavy, tgt, c->rkeys);
       p.qbound = qb; p.setlist = f.cull_sets; p.setcount = f.cull_count;
+      // (several lanes per query -- grid_lanes 2 / 4 / 8 -- write no set list: the culled kernel then starts a block per set and the
+      // blocks without a flagged query leave at once)
+      if (c->grid_lanes == 2 || c->grid_lanes == 4 || c->grid_lanes == 8) { p.setlist = nullptr; p.setcount = nullptr; if (int rc = launch_nn_cull_batch(c, &p, 1, cap2, fma)) return rc; }
+      else
       if (int rc = launch_nn_cull_list_batch(c, &p, 1, cap2, fma)) return rc;
       if (int rc = launch_merge_flagged_keys(c, cur.sorted, c->bheavy, c->rkeys, ns, c->keys)) return rc;
     }

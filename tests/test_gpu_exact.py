@@ -189,9 +189,9 @@ def test_sequential_align_through_the_parts_equals_the_culled_search(mvr, orc, c
         kw = dict(max_dist=40.0, max_iter=1000)
     params = mvr.icp_params(**kw)
     runs = []
-    for mode in (0, 1, 2, 3, 4):     # culled both ways; reverse over the source's grid (default); forward through the parts as well; forward through ONE grid over the model -- its flagged query sets through the culled kernel's listed-set launch (3) or the grid's set kernel (4 here: seq_model_tail 0)
+    for mode in (0, 1, 2, 3, 4, 5):  # culled both ways; reverse over the source's grid (default); forward through the parts as well; forward through ONE grid over the model -- its flagged query sets through the culled kernel's listed-set launch (3), the grid's set kernel (4 here: seq_model_tail 0), or, with four lanes per query (no set list), the culled kernel over the flags (5)
         with mvr.Context(0) as ctx:
-            ctx.tune(seq_search=min(mode, 3), seq_model_tail=0 if mode == 4 else 1)
+            ctx.tune(seq_search=min(mode, 3), seq_model_tail=0 if mode == 4 else 1, grid_lanes=4 if mode == 5 else 1)
             for v in range(V):
                 ctx.upload(16 + v, scans[v])
             ctx.prof_reset(); ctx.prof_enable(1)
